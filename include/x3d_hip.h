@@ -1,0 +1,267 @@
+/* x3d_hip.h -- C ABI of libx3d_hip.so: the MI355X (gfx950) X3D forward/backward hot path.
+ *
+ * The reference (fcogidi/X3D-tf) has no native/FFI layer: its boundary is the Python class
+ * model.X3D plus the tf.keras layers it calls.  Every entry point below replaces one
+ * group of tf.keras ops on that path; the citation after each declaration is the reference call
+ * site it stands in for.  A reference maintainer binds these with ctypes.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every pointer is DEVICE memory unless marked host.
+ *  - Activations are NCTHW, contiguous, element type `dtype` (X3D_F32 or X3D_BF16).  Arithmetic,
+ *    weights, per-channel coefficients and reductions are fp32 (statistics accumulate in fp64).
+ *  - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing allocates,
+ *    nothing synchronises; functions are re-entrant.
+ *  - Return value: X3D_OK, or an error code with a message in x3d_last_error() (thread local).
+ *  - Accumulating outputs (stats, sums, dw, pool) are += : the caller zeroes them (one memset of
+ *    its workspace per step).
+ */
+#ifndef X3D_HIP_H
+#define X3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X3D_OK 0
+#define X3D_ERR_INVALID 1
+#define X3D_ERR_LAUNCH 2
+
+#define X3D_F32 0
+#define X3D_BF16 1
+
+#define X3D_ACT_NONE 0
+#define X3D_ACT_RELU 1
+#define X3D_ACT_SWISH 2
+#define X3D_ACT_SIGMOID 3
+
+/* epilogues of x3d_pw_dgrad */
+#define X3D_EPI_STORE 0       /* dx = W^T dY */
+#define X3D_EPI_ADD 1         /* dx = W^T dY + add                     (identity shortcut) */
+#define X3D_EPI_ADD_STRIDED 2 /* dx = W^T dY + upsample_zero(add, 2)   (shortcut conv, stride 2) */
+#define X3D_EPI_SWISH_BWD 3   /* dv = (W^T dY) * swish'(gate*bn_b(braw)); per-(n,c) sums */
+
+int x3d_version(void);
+const char* x3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  stem spatial conv: tf.pad(0,1,1) + Conv3D(k=(1,3,3), s=(1,2,2), valid, no bias)
+ *     reference model.py:161-166,178-184,203-204
+ *     x [N][Cin][T][H][W] -> y [N][Cout][T][Ho][Wo], Ho=(H-1)/2+1.  w [Cout][Cin][3][3] fp32.
+ * ------------------------------------------------------------------------------------------ */
+int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int Cin, int T, int H, int W,
+                   int Cout, int dtype, void* stream);
+/* dW of the same conv (the input needs no gradient).  dy = grad wrt y.  dw [Cout][Cin][3][3] += */
+int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, int T, int H, int W,
+                     int Cout, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  stem temporal depthwise conv: tf.pad(KT/2,0,0) + Conv3D(k=(KT,1,1), groups=C, no bias)
+ *     reference model.py:170-175,187-194,205-206.   x,y [N][C][T][HW]; w [C][KT] fp32.
+ *     stats [C][2] += (sum, sum of squares) of y as stored.
+ * ------------------------------------------------------------------------------------------ */
+int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
+                int KT, int dtype, void* stream);
+/* backward of K2 through the stem's BN+ReLU: g = grad wrt relu(bn(y)) masked by y's sign is
+ * produced by x3d_relu_bn_bwd_reduce; here dY = A*g + B*yraw + C (coef [C][4]).
+ * dx [N][C][T][HW] = conv_t^T dY ; dw [C][KT] += */
+int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, const void* x, const float* w,
+                void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  BatchNormalization(axis=-1, eps, momentum)   reference model.py:89-92,196-199,254-257,
+ *     268-271,300-303,368-371.
+ *   finalize (training): stats [C][2] (sum, sumsq over `count` elements per channel) ->
+ *     scale_shift [C][2] = (gamma*invstd, beta - mean*gamma*invstd), mean_invstd [C][2];
+ *     if update_moving: moving = moving*momentum + batch*(1-momentum) (variance unbiased).
+ *   eval_coef (inference): same outputs from the moving statistics.
+ *   bwd_finalize: sums [C][2] = (sum g, sum g*yraw) -> coef [C][4] = (A,B,C,0) such that
+ *     dYraw = A*g + B*yraw + C ; dgamma [C] += , dbeta [C] += .
+ * ------------------------------------------------------------------------------------------ */
+int x3d_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                    float* moving_mean, float* moving_var, float eps, float momentum,
+                    int update_moving, float* scale_shift, float* mean_invstd, int C, void* stream);
+int x3d_bn_eval_coef(const float* gamma, const float* beta, const float* moving_mean,
+                     const float* moving_var, float eps, float* scale_shift, float* mean_invstd,
+                     int C, void* stream);
+int x3d_bn_bwd_finalize(const double* sums, double count, const float* mean_invstd,
+                        const float* gamma, float* coef, float* dgamma, float* dbeta, int C,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  pointwise Conv3D(k=1, no bias) as a GEMM over points on MFMA: bottleneck a / c, shortcut
+ *     `residual` (stride (1,s,s) valid), conv5.  reference model.py:246-253,292-299,360-367,80-87
+ *     Input prologue (folded producer BN / SE gate / activation), applied on load:
+ *       v = x ; if in_scale_shift: v = s*v + t ; if in_gate: v *= gate[n][ci] ; v = act(v)
+ *     Epilogue: y stored raw; stats [Cout][2] += (sum, sumsq) of y as stored (may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x;               /* [N][Cin][T][H][W] */
+  const float* w;              /* [Cout][Cin] fp32 */
+  void* y;                     /* [N][Cout][T][Ho][Wo], Ho = ceil(H/stride) */
+  double* stats;               /* [Cout][2] or NULL */
+  const float* in_scale_shift; /* [Cin][2] or NULL */
+  const float* in_gate;        /* [N][Cin] or NULL */
+  int in_act;
+  int N, Cin, Cout, T, H, W, stride, dtype;
+} x3d_pw_fwd_args;
+int x3d_pw_fwd(const x3d_pw_fwd_args* a, void* stream);
+
+/* data gradient: dYraw = A*g + B*yraw + C on load (coef [Cout][4]; NULL coef: dYraw = g),
+ * dx = W^T dYraw with one of the X3D_EPI_* epilogues. All tensors at the conv's OUTPUT points. */
+typedef struct {
+  const void* g;               /* [N][Cout][P] grad wrt the BN output of this conv */
+  const void* yraw;            /* [N][Cout][P] raw conv output (NULL iff coef NULL) */
+  const float* coef;           /* [Cout][4] or NULL */
+  const float* w;              /* [Cout][Cin] fp32 */
+  void* dx;                    /* [N][Cin][P] */
+  int epi;
+  const void* add;             /* EPI_ADD: [N][Cin][P];  EPI_ADD_STRIDED: [N][Cin][T][ceil(H/2)][ceil(W/2)] */
+  const void* braw;            /* EPI_SWISH_BWD: [N][Cin][P] raw depthwise output */
+  const float* b_scale_shift;  /* EPI_SWISH_BWD: [Cin][2] */
+  const float* gate;           /* EPI_SWISH_BWD: [N][Cin] or NULL */
+  double* nc_sums;             /* EPI_SWISH_BWD: [N][Cin][2] += (sum dv, sum dv*braw) */
+  int N, Cin, Cout, T, H, W, dtype; /* T,H,W: extents of the P = T*H*W output points */
+} x3d_pw_dgrad_args;
+int x3d_pw_dgrad(const x3d_pw_dgrad_args* a, void* stream);
+
+/* weight gradient: dw [Cout][Cin] += sum_{n,p} dYraw[n][co][p] * act_in(x)[n][ci][q(p)] */
+typedef struct {
+  const void* g;
+  const void* yraw;
+  const float* coef;           /* as in dgrad */
+  const void* x;               /* conv input [N][Cin][T][H][W] */
+  const float* in_scale_shift; /* prologue of the forward pass, replayed */
+  const float* in_gate;
+  int in_act;
+  float* dw;                   /* [Cout][Cin] += */
+  int N, Cin, Cout, T, H, W, stride, dtype; /* T,H,W: INPUT extents (as in fwd) */
+} x3d_pw_wgrad_args;
+int x3d_pw_wgrad(const x3d_pw_wgrad_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  channelwise Conv3D(k=(3,3,3), s=(1,s,s), padding='same', groups=C, no bias)
+ *     reference model.py:259-267.  TF-SAME (asymmetric) padding.  The HBM-bound headline kernel.
+ *     Prologue on load: v = act(s*x + t) inside the image, 0 in the padding.
+ *     Epilogue: stats [C][2] += ; pool [N][C] += sum over T,Ho,Wo of y (SE squeeze, model.py:277,312)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x;               /* [N][C][T][H][W] */
+  const float* w;              /* [C][3][3][3] fp32 */
+  void* y;                     /* [N][C][T][Ho][Wo] */
+  const float* in_scale_shift; /* [C][2] or NULL */
+  int in_act;
+  double* stats;               /* [C][2] or NULL */
+  double* pool;                /* [N][C] or NULL */
+  int N, C, T, H, W, stride, dtype;
+} x3d_dw3d_fwd_args;
+int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* a, void* stream);
+
+/* fused backward: dB = A*dv + B*braw + C with per-(n,c) coef_nc [N][C][4];
+ *   ga = (conv^T dB) * [s_a*araw + t_a > 0]           -> [N][C][T][H][W]
+ *   a_sums [C][2] += (sum ga, sum ga*araw) ; dw [C][27] += sum dB * relu(bn_a(araw))_padded */
+typedef struct {
+  const void* dv;              /* [N][C][T][Ho][Wo] */
+  const void* braw;            /* [N][C][T][Ho][Wo] */
+  const float* coef_nc;        /* [N][C][4] */
+  const void* araw;            /* [N][C][T][H][W] */
+  const float* a_scale_shift;  /* [C][2] */
+  const float* w;              /* [C][27] */
+  void* ga;                    /* [N][C][T][H][W] */
+  double* a_sums;              /* [C][2] */
+  float* dw;                   /* [C][27] */
+  int N, C, T, H, W, stride, dtype;
+} x3d_dw3d_bwd_args;
+int x3d_dw3d_bwd(const x3d_dw3d_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7/K8  squeeze-excite MLP: se_pool -> se_fc1(+bias, ReLU) -> se_fc2(+bias, sigmoid)
+ *     reference model.py:274-290,311-315.  pool_sums [N][C] = sum over P points of braw (from K6);
+ *     pooled = s_b * pool_sums / P + t_b.  gate [N][C], hidden [N][Wd] (saved for backward).
+ * ------------------------------------------------------------------------------------------ */
+int x3d_se_fwd(const double* pool_sums, double P, const float* b_scale_shift, const float* w1,
+               const float* b1, const float* w2, const float* b2, float* gate, float* hidden, int N,
+               int C, int Wd, void* stream);
+/* backward of the SE branch + BN_b, from the per-(n,c) sums of x3d_pw_dgrad(EPI_SWISH_BWD):
+ *   nc_sums [N][C][2] = (S1 = sum dv, S2 = sum dv*braw)
+ *   dgate = s_b*S2 + t_b*S1 -> sigmoid' -> fc2^T -> relu' -> fc1^T -> dpool [N][C]
+ *   dw1,db1,dw2,db2 += ; then BN_b backward over du = dv*gate + dpool/P:
+ *   coef_nc [N][C][4] = (A*gate, B, C + A*dpool/P, 0) ; dgamma_b, dbeta_b += .
+ * Without SE (w1 == NULL): gate = 1, dpool = 0. */
+typedef struct {
+  const double* nc_sums;       /* [N][C][2] */
+  const double* pool_sums;     /* [N][C] (forward) or NULL without SE */
+  double P;
+  const float* b_scale_shift;  /* [C][2] */
+  const float* b_mean_invstd;  /* [C][2] */
+  const float* gamma_b;        /* [C] */
+  const float* w1; const float* b1; const float* w2; const float* b2; /* SE params or NULL */
+  const float* gate;           /* [N][C] or NULL */
+  const float* hidden;         /* [N][Wd] or NULL */
+  float* dw1; float* db1; float* dw2; float* db2;
+  float* dgamma_b; float* dbeta_b;
+  float* coef_nc;              /* out [N][C][4] */
+  float* scratch;              /* [N][C] floats (dpool) */
+  int N, C, Wd;
+} x3d_se_bnb_bwd_args;
+int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9  residual tail: Add + ReLU  (reference model.py:381-392)
+ *     y = relu(s_c*c + t_c + shortcut), shortcut = s_r*r + t_r (conv shortcut) or x (identity);
+ *     shortcut == NULL: y = relu(s_c*c + t_c)  (BN + ReLU after the stem, model.py:207-208)
+ * ------------------------------------------------------------------------------------------ */
+int x3d_tail_fwd(const void* c_raw, const float* c_scale_shift, const void* shortcut,
+                 const float* r_scale_shift /* NULL: identity */, void* y, int N, int C, long long P,
+                 int dtype, void* stream);
+/* g = dy * [y > 0] written in place over dy; sums_c [C][2] += (sum g, sum g*c_raw);
+ * if r_raw: sums_r [C][2] += (sum g, sum g*r_raw) */
+int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const void* r_raw, double* sums_c,
+                 double* sums_r, int N, int C, long long P, int dtype, void* stream);
+/* generic ReLU+BN backward reduce for stem / conv5: z = s*yraw + t.
+ *   dy != NULL : g = dy * [z > 0]                (g may alias dy)
+ *   dy == NULL : g = dpool[n][c] / P * [z > 0]   (global-average-pool backward, model.py:94,118)
+ * sums [C][2] += (sum g, sum g*yraw) */
+int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const void* yraw,
+                           const float* scale_shift, void* g, double* sums, int N, int C,
+                           long long P, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7/K10  head: pool5 (GlobalAveragePooling3D of relu(bn(conv5))), fc1 (1x1x1 conv on the pooled
+ *     vector, no bias, ReLU), Dropout, fc2 Dense(+bias), Softmax(fp32), view mean.
+ *     reference model.py:94-111,117-127
+ * ------------------------------------------------------------------------------------------ */
+int x3d_pool_fwd(const void* x_raw, const float* scale_shift, float* pooled /* [N][C] */, int N, int C,
+                 long long P, int dtype, void* stream);
+/* y[n][m] = act( sum_k (x[n][k] * (mask ? mask[n][k]*mask_scale : 1)) * w[m][k] + b[m] ), all fp32 */
+int x3d_dense_fwd(const float* x, const float* mask, float mask_scale, const float* w, const float* b,
+                  float* y, int act, int N, int K, int M, void* stream);
+/* dy is grad wrt the activated output y (ReLU only).  dx [N][K] (may be NULL), dw [M][K] +=, db [M] += */
+int x3d_dense_bwd(const float* dy, const float* y, int act, const float* x, const float* mask,
+                  float mask_scale, const float* w, float* dx, float* dw, float* db, int N, int K,
+                  int M, void* stream);
+/* probs = softmax(logits); loss_rows[n] = -log q_y + log sum_j q_j with q = clip(p,1e-7,1-1e-7)
+ * (tf.keras SparseCategoricalCrossentropy on probabilities, train.py:104); dlogits = d(mean loss)/dlogits
+ * scaled by grad_scale (= 1/global_batch).  labels int32; loss_rows / dlogits may be NULL. */
+int x3d_softmax_xent(const float* logits, const int* labels, float* probs, float* loss_rows,
+                     float* dlogits, float grad_scale, int N, int M, void* stream);
+/* out[v][m] = mean over `views` consecutive rows (model.py:123-126) */
+int x3d_view_mean(const float* probs, float* out, int videos, int views, int M, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K12  SGD with Nesterov momentum + L2 (train.py:89-92, model.py:47):
+ *     g' = g + 2*wd*w (where l2_mask) ; v = m*v - lr*g' ; w = w + m*v - lr*g'
+ *     flat fp32 arrays of n elements; wd_mask [n] in {0,1} as uint8 (NULL: no decay)
+ * ------------------------------------------------------------------------------------------ */
+int x3d_sgd_nesterov(float* w, float* v, const float* g, const unsigned char* l2_mask, float lr,
+                     float momentum, float weight_decay, float grad_scale, long long n, void* stream);
+/* sum of squares of the masked entries (L2 regularisation loss term), out [1] double += */
+int x3d_l2_sumsq(const float* w, const unsigned char* l2_mask, double* out, long long n, void* stream);
+
+/* layout helpers at the module boundary: NTHWC (reference, model.py:113) <-> NCTHW (internal) */
+int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C,
+                       long long P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X3D_HIP_H */

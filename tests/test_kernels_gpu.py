@@ -1,0 +1,557 @@
+"""Kernel-level parity: every C-ABI entry point against a CPU fp64 restatement of the same op
+(oracle/x3d_oracle.py for the conv primitives, torch autograd for the gradients) on shapes small
+enough for the CPU to finish in seconds.  Shapes cover stride 1/2, even/odd extents (TF-SAME 0/1 and
+1/1 pads, incl. X3D-L's 39 -> 20), channel counts that are not multiples of the MFMA tile, and point
+counts that are not multiples of the vector width.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import report, rnd, tol_for
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from x3d_tf_amd import ops
+    return ops
+
+
+def _oracle():
+    from oracle import x3d_oracle as O
+    return O
+
+
+def _gen(seed=0):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def _stats_ref(y, dtype):
+    yr = y.to(dtype).double()
+    return torch.stack([yr.sum((0, 2, 3, 4)), (yr * yr).sum((0, 2, 3, 4))], 1)
+
+
+def _affine(x, ss, gate=None, act=0):
+    u = x * ss[:, 0].view(1, -1, 1, 1, 1) + ss[:, 1].view(1, -1, 1, 1, 1)
+    if gate is not None:
+        u = u * gate[:, :, None, None, None]
+    if act == 1:
+        u = F.relu(u)
+    elif act == 2:
+        u = u * torch.sigmoid(u)
+    return u
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, T, H, W, stride, prologue
+    (2, 24, 54, 4, 12, 12, 1, None),       # bottleneck a (stage 2 widths)
+    (2, 54, 24, 3, 10, 10, 1, "swish"),    # bottleneck c with BN_b + SE gate + swish folded
+    (2, 24, 48, 4, 12, 12, 2, None),       # strided shortcut (valid, samples pixels 0,2,..)
+    (1, 48, 108, 13, 5, 5, 1, "relu"),     # P = 325 (odd): scalar path
+    (2, 96, 216, 2, 7, 7, 1, None),        # Cout > 128: two row blocks
+    (1, 216, 96, 2, 7, 7, 1, "swish"),     # K chunking (does not fit LDS resident)
+    (1, 24, 24, 2, 9, 11, 2, None),        # odd extents with stride 2
+    (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
+])
+def test_pw_fwd(gpu, dtype, shape):
+    ops, O = _ops(), _oracle()
+    n, cin, cout, t, h, w, stride, pro = shape
+    g = _gen(1)
+    x, xd = rnd((n, cin, t, h, w), dtype, g)
+    wt = torch.randn((cout, cin), generator=g) * 0.2
+    ss = gate = None
+    act = 0
+    xin = xd
+    if pro:
+        ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)], 1)
+        act = 2 if pro == "swish" else 1
+        if pro == "swish":
+            gate = torch.rand((n, cin), generator=g)
+        xin = _affine(xd, ss.double(), None if gate is None else gate.double(), act)
+    ref = O.pointwise(xin, wt.double(), stride)
+    stats = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+    y = ops.pw_fwd(x.to(gpu), wt.to(gpu), stats=stats, in_ss=None if ss is None else ss.to(gpu),
+                   in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride)
+    torch.cuda.synchronize()
+    rt, at = tol_for(dtype)
+    scale = ref.abs().max().item()
+    report("y", y, ref, rt, at * scale)
+    # statistics describe the tensor as stored
+    sref = _stats_ref(y.float().cpu(), dtype)
+    report("stats", stats, sref, 1e-5, 1e-4 * max(1.0, sref.abs().max().item()) * 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # N, C, T, H, W, stride
+    (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2),       # even, SW=2
+    (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),         # 7x7 planes, SW=1
+    (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1),       # X3D-L odd case 39 -> 20 (pads 1/1)
+    (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),     # X3D-M stage-2 planes, SW=4, H-tiled
+    (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1),        # T=1 / non-square / odd widths
+    (1, 2, 16, 28, 28, 1),                            # vec 4 path for bf16
+])
+def test_dw3d_fwd(gpu, dtype, shape):
+    ops, O = _ops(), _oracle()
+    n, c, t, h, w, stride = shape
+    g = _gen(2)
+    x, xd = rnd((n, c, t, h, w), dtype, g)
+    wt = torch.randn((c, 3, 3, 3), generator=g) * 0.3
+    ss = torch.stack([1 + 0.3 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)], 1)
+    ref = O.depthwise3x3x3(_affine(xd, ss.double(), None, 1), wt.double(), stride)
+    stats = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    pool = torch.zeros((n, c), dtype=torch.float64, device=gpu)
+    y = ops.dw3d_fwd(x.to(gpu), wt.to(gpu), stride, in_ss=ss.to(gpu), in_act=1, stats=stats, pool=pool)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(ref.shape)
+    rt, at = tol_for(dtype)
+    report("y", y, ref, rt, at * ref.abs().max().item())
+    ys = y.float().cpu()
+    report("stats", stats, _stats_ref(ys, dtype), 1e-5, 1e-5 * max(1.0, float(ys.numel())) ** 0.5)
+    report("pool", pool, ys.double().sum((2, 3, 4)), 1e-5, 1e-4)
+    # no prologue
+    y2 = ops.dw3d_fwd(x.to(gpu), wt.to(gpu), stride)
+    report("y_noprologue", y2, O.depthwise3x3x3(xd, wt.double(), stride), rt, at * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, T, H, W
+    (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
+    (1, 216, 96, 2, 7, 7), (1, 200, 40, 1, 4, 8),
+])
+@pytest.mark.parametrize("epi", ["store", "add", "add_strided", "swish_bwd"])
+def test_pw_dgrad(gpu, dtype, shape, epi):
+    ops = _ops()
+    n, cin, cout, t, h, w = shape
+    g_ = _gen(3)
+    g, gd = rnd((n, cout, t, h, w), dtype, g_)
+    yraw, yd = rnd((n, cout, t, h, w), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    dyraw = (coef[:, 0].double().view(1, -1, 1, 1, 1) * gd + coef[:, 1].double().view(1, -1, 1, 1, 1) * yd
+             + coef[:, 2].double().view(1, -1, 1, 1, 1))
+    ref = torch.einsum("oc,nothw->ncthw", wt.double(), dyraw)
+    dx = torch.empty((n, cin, t, h, w), dtype=dtype, device=gpu)
+    kw = {}
+    rt, at = tol_for(dtype)
+    if epi == "add":
+        add, addd = rnd((n, cin, t, h, w), dtype, g_)
+        ref = ref + addd
+        kw = dict(epi=ops.EPI_ADD, add=add.to(gpu))
+    elif epi == "add_strided":
+        hh, wh = (h + 1) // 2, (w + 1) // 2
+        add, addd = rnd((n, cin, t, hh, wh), dtype, g_)
+        up = torch.zeros_like(ref)
+        up[:, :, :, ::2, ::2] = addd
+        ref = ref + up
+        kw = dict(epi=ops.EPI_ADD_STRIDED, add=add.to(gpu))
+    elif epi == "swish_bwd":
+        braw, bd = rnd((n, cin, t, h, w), dtype, g_)
+        bss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1)
+        gate = torch.rand((n, cin), generator=g_)
+        v = _affine(bd, bss.double(), gate.double(), 0)
+        s = torch.sigmoid(v)
+        ref = ref * (s * (1 + v * (1 - s)))
+        ncs = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+        kw = dict(epi=ops.EPI_SWISH_BWD, braw=braw.to(gpu), b_ss=bss.to(gpu), gate=gate.to(gpu), nc_sums=ncs)
+    ops.pw_dgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), wt.to(gpu), dx, **kw)
+    torch.cuda.synchronize()
+    report("dx", dx, ref, rt, at * ref.abs().max().item())
+    if epi == "swish_bwd":
+        dvs = dx.float().cpu().double()
+        sref = torch.stack([dvs.sum((2, 3, 4)), (dvs * bd).sum((2, 3, 4))], -1)
+        report("nc_sums", ncs, sref, 1e-4, 1e-4 * max(1.0, sref.abs().max().item()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, T, H, W, stride, prologue
+    (2, 24, 54, 4, 12, 12, 1, None), (2, 54, 24, 3, 10, 10, 1, "swish"), (2, 24, 48, 4, 12, 12, 2, None),
+    (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
+    (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),
+])
+def test_pw_wgrad(gpu, dtype, shape):
+    ops = _ops()
+    n, cin, cout, t, h, w, stride, pro = shape
+    g_ = _gen(4)
+    ho, wo = -(-h // stride), -(-w // stride)
+    x, xd = rnd((n, cin, t, h, w), dtype, g_)
+    g, gd = rnd((n, cout, t, ho, wo), dtype, g_)
+    yraw, yd = rnd((n, cout, t, ho, wo), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    dyraw = (coef[:, 0].double().view(1, -1, 1, 1, 1) * gd + coef[:, 1].double().view(1, -1, 1, 1, 1) * yd
+             + coef[:, 2].double().view(1, -1, 1, 1, 1))
+    ss = gate = None
+    act = 0
+    xin = xd
+    if pro:
+        ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1)
+        gate = torch.rand((n, cin), generator=g_)
+        act = 2
+        xin = _affine(xd, ss.double(), gate.double(), act)
+    if stride > 1:
+        xin = xin[:, :, :, ::stride, ::stride]
+    ref = torch.einsum("nothw,ncthw->oc", dyraw, xin)
+    dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)   # += semantics
+    ops.pw_wgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), x.to(gpu), dw, in_ss=None if ss is None else ss.to(gpu),
+                 in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride)
+    torch.cuda.synchronize()
+    report("dw", dw, ref + 0.5, 2e-4, 2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2), (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),
+    (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1), (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),
+    (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1), (1, 2, 16, 28, 28, 1),
+])
+def test_dw3d_bwd(gpu, dtype, shape):
+    ops, O = _ops(), _oracle()
+    n, c, t, h, w, stride = shape
+    g_ = _gen(5)
+    ho, wo = -(-h // stride), -(-w // stride)
+    araw, ad = rnd((n, c, t, h, w), dtype, g_)
+    dv, dvd = rnd((n, c, t, ho, wo), dtype, g_)
+    braw, bd = rnd((n, c, t, ho, wo), dtype, g_)
+    coef = torch.randn((n, c, 4), generator=g_) * 0.5
+    wt = torch.randn((c, 3, 3, 3), generator=g_) * 0.3
+    ss = torch.stack([1 + 0.3 * torch.randn(c, generator=g_), 0.3 * torch.randn(c, generator=g_)], 1)
+    cd = coef.double()
+    dB = cd[:, :, 0, None, None, None] * dvd + cd[:, :, 1, None, None, None] * bd + cd[:, :, 2, None, None, None]
+    z = _affine(ad, ss.double())
+    act = F.relu(z).requires_grad_(True)
+    wref = wt.double().requires_grad_(True)
+    out = O.depthwise3x3x3(act, wref, stride)
+    dA, dWr = torch.autograd.grad((out * dB).sum(), [act, wref])
+    ga_ref = dA * (z > 0)
+    ga = torch.empty((n, c, t, h, w), dtype=dtype, device=gpu)
+    a_sums = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    dw = torch.full((c, 27), 0.25, dtype=torch.float32, device=gpu)
+    ops.dw3d_bwd(dv.to(gpu), braw.to(gpu), coef.to(gpu), araw.to(gpu), ss.to(gpu), wt.to(gpu).view(c, 27), ga,
+                 a_sums, dw, stride)
+    torch.cuda.synchronize()
+    rt, at = tol_for(dtype)
+    report("ga", ga, ga_ref, rt, at * ga_ref.abs().max().item())
+    report("dw", dw, dWr.view(c, 27) + 0.25, 2e-4, 2e-4 * dWr.abs().max().item())
+    gs = ga.float().cpu().double()
+    sref = torch.stack([gs.sum((0, 2, 3, 4)), (gs * ad).sum((0, 2, 3, 4))], 1)
+    report("a_sums", a_sums, sref, 1e-4, 1e-4 * max(1.0, sref.abs().max().item()))
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4, 16, 16, 24), (1, 3, 9, 11, 24), (1, 2, 20, 20, 32)])
+def test_stem(gpu, dtype, shape):
+    ops = _ops()
+    n, t, h, w, c1 = shape
+    g_ = _gen(6)
+    x, xd = rnd((n, 3, t, h, w), dtype, g_)
+    ws = torch.randn((c1, 3, 3, 3), generator=g_) * 0.3
+    wt = torch.randn((c1, 5), generator=g_) * 0.4
+    ref_s = F.conv3d(F.pad(xd, (1, 1, 1, 1, 0, 0)), ws.double().unsqueeze(2), stride=(1, 2, 2))
+    ys = ops.stem_s_fwd(x.to(gpu), ws.to(gpu))
+    torch.cuda.synchronize()
+    rt, at = tol_for(dtype)
+    report("conv_s", ys, ref_s, rt, at * ref_s.abs().max().item())
+    # conv_t on the stored conv_s output
+    ysd = ys.float().cpu().double()
+    ref_t = F.conv3d(F.pad(ysd, (0, 0, 0, 0, 2, 2)), wt.double().view(-1, 1, 5, 1, 1), groups=c1)
+    stats = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
+    yt = ops.dwt_fwd(ys, wt.to(gpu), stats=stats)
+    torch.cuda.synchronize()
+    report("conv_t", yt, ref_t, rt, at * ref_t.abs().max().item())
+    report("stats", stats, _stats_ref(yt.float().cpu(), dtype), 1e-5, 1e-4)
+    # backward of conv_t (+BN coefficients) and wgrad of conv_s
+    g, gd = rnd(tuple(yt.shape), dtype, g_)
+    coef = torch.randn((c1, 4), generator=g_) * 0.5
+    ytd = yt.float().cpu().double()
+    dY = (coef[:, 0].double().view(1, -1, 1, 1, 1) * gd + coef[:, 1].double().view(1, -1, 1, 1, 1) * ytd
+          + coef[:, 2].double().view(1, -1, 1, 1, 1))
+    xs = ysd.clone().requires_grad_(True)
+    wtr = wt.double().requires_grad_(True)
+    out = F.conv3d(F.pad(xs, (0, 0, 0, 0, 2, 2)), wtr.view(-1, 1, 5, 1, 1), groups=c1)
+    dxs, dwt_ref = torch.autograd.grad((out * dY).sum(), [xs, wtr])
+    dx = torch.empty_like(ys)
+    dwt = torch.zeros((c1, 5), dtype=torch.float32, device=gpu)
+    ops.dwt_bwd(g.to(gpu), yt, coef.to(gpu), ys, wt.to(gpu), dx, dwt)
+    torch.cuda.synchronize()
+    report("dwt_dx", dx, dxs, rt, at * dxs.abs().max().item())
+    report("dwt_dw", dwt, dwt_ref, 2e-4, 2e-4 * dwt_ref.abs().max().item())
+    dxsd = dx.float().cpu().double()
+    wsr = ws.double().requires_grad_(True)
+    out_s = F.conv3d(F.pad(xd, (1, 1, 1, 1, 0, 0)), wsr.unsqueeze(2), stride=(1, 2, 2))
+    (dws_ref,) = torch.autograd.grad((out_s * dxsd).sum(), [wsr])
+    dws = torch.zeros((c1, 3, 3, 3), dtype=torch.float32, device=gpu)
+    ops.stem_s_wgrad(x.to(gpu), dx, dws)
+    torch.cuda.synchronize()
+    report("stem_s_dw", dws, dws_ref, 2e-4, 2e-4 * dws_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P", [(2, 4, 8), (13, 5, 5)])
+def test_bn_tail_pool(gpu, dtype, P):
+    ops = _ops()
+    n, c = 3, 10
+    g_ = _gen(7)
+    shape = (n, c) + P
+    craw, cd = rnd(shape, dtype, g_)
+    rraw, rd = rnd(shape, dtype, g_)
+    M = n * P[0] * P[1] * P[2]
+    # finalize from exact statistics
+    stats = torch.stack([cd.sum((0, 2, 3, 4)), (cd * cd).sum((0, 2, 3, 4))], 1).to(gpu)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g_))
+    beta = 0.2 * torch.randn(c, generator=g_)
+    mm, mv = torch.zeros(c), torch.ones(c)
+    ss = torch.empty((c, 2), device=gpu)
+    mi = torch.empty((c, 2), device=gpu)
+    mmg, mvg = mm.to(gpu), mv.to(gpu)
+    ops.bn_finalize(stats, M, gamma.to(gpu), beta.to(gpu), mmg, mvg, 1e-5, 0.9, True, ss, mi)
+    mean = cd.mean((0, 2, 3, 4))
+    var = cd.var((0, 2, 3, 4), unbiased=False)
+    inv = 1 / torch.sqrt(var + 1e-5)
+    report("scale", ss[:, 0], gamma.double() * inv, 1e-5, 1e-6)
+    report("shift", ss[:, 1], beta.double() - mean * gamma.double() * inv, 1e-5, 1e-6)
+    report("moving_mean", mmg, 0.1 * mean, 1e-5, 1e-7)
+    report("moving_var", mvg, 0.9 + 0.1 * var * M / (M - 1), 1e-5, 1e-7)
+    ss2 = torch.empty((c, 2), device=gpu)
+    mi2 = torch.empty((c, 2), device=gpu)
+    ops.bn_eval_coef(gamma.to(gpu), beta.to(gpu), mmg, mvg, 1e-5, ss2, mi2)
+    inv2 = 1 / torch.sqrt(mvg.cpu().double() + 1e-5)
+    report("eval_scale", ss2[:, 0], gamma.double() * inv2, 1e-5, 1e-6)
+    # tail fwd (conv shortcut and identity)
+    ssr = torch.stack([1 + 0.3 * torch.randn(c, generator=g_), 0.3 * torch.randn(c, generator=g_)], 1)
+    ssc = ss.cpu().double()
+    rt, at = tol_for(dtype)
+    y = torch.empty(shape, dtype=dtype, device=gpu)
+    ops.tail_fwd(craw.to(gpu), ss, rraw.to(gpu), ssr.to(gpu), y)
+    ref = F.relu(_affine(cd, ssc) + _affine(rd, ssr.double()))
+    report("tail_conv", y, ref, rt, at * ref.abs().max().item())
+    y2 = torch.empty(shape, dtype=dtype, device=gpu)
+    ops.tail_fwd(craw.to(gpu), ss, rraw.to(gpu), None, y2)
+    ref2 = F.relu(_affine(cd, ssc) + rd)
+    report("tail_identity", y2, ref2, rt, at * ref2.abs().max().item())
+    # tail bwd
+    dy, dyd = rnd(shape, dtype, g_)
+    dyg = dy.to(gpu).clone()
+    sc = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    sr = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    ops.tail_bwd(dyg, y, craw.to(gpu), rraw.to(gpu), sc, sr)
+    yd = y.float().cpu().double()
+    gref = dyd * (yd > 0)
+    report("tail_bwd_g", dyg, gref, 0, 0)
+    report("sums_c", sc, torch.stack([gref.sum((0, 2, 3, 4)), (gref * cd).sum((0, 2, 3, 4))], 1), 1e-5, 1e-4)
+    report("sums_r", sr, torch.stack([gref.sum((0, 2, 3, 4)), (gref * rd).sum((0, 2, 3, 4))], 1), 1e-5, 1e-4)
+    # bn backward finalize: check the coefficients reproduce the BN gradient
+    coef = torch.empty((c, 4), device=gpu)
+    dgam = torch.zeros(c, device=gpu)
+    dbet = torch.zeros(c, device=gpu)
+    ops.bn_bwd_finalize(sc, M, mi, gamma.to(gpu), coef, dgam, dbet)
+    x_ = cd.clone().requires_grad_(True)
+    gm = gamma.double().requires_grad_(True)
+    bt = beta.double().requires_grad_(True)
+    mu = x_.mean((0, 2, 3, 4), keepdim=True)
+    vr = x_.var((0, 2, 3, 4), unbiased=False, keepdim=True)
+    bn = (x_ - mu) / torch.sqrt(vr + 1e-5) * gm.view(1, -1, 1, 1, 1) + bt.view(1, -1, 1, 1, 1)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad((bn * gref).sum(), [x_, gm, bt])
+    cf = coef.cpu().double()
+    dx_got = cf[:, 0].view(1, -1, 1, 1, 1) * gref + cf[:, 1].view(1, -1, 1, 1, 1) * cd + cf[:, 2].view(1, -1, 1, 1, 1)
+    report("bn_bwd_dx", dx_got, dx_ref, 1e-4, 1e-5)
+    report("bn_bwd_dgamma", dgam, dg_ref, 1e-4, 1e-4)
+    report("bn_bwd_dbeta", dbet, db_ref, 1e-4, 1e-4)
+    # relu+bn backward reduce (both sources) and pool
+    gbuf = torch.empty(shape, dtype=dtype, device=gpu)
+    s2 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    ops.relu_bn_bwd_reduce(dy.to(gpu), None, craw.to(gpu), ss, gbuf, s2)
+    z = _affine(cd, ssc)
+    gr = dyd * (z > 0)
+    report("rbr_g", gbuf, gr, 0, 0)
+    report("rbr_sums", s2, torch.stack([gr.sum((0, 2, 3, 4)), (gr * cd).sum((0, 2, 3, 4))], 1), 1e-5, 1e-4)
+    dpool = torch.randn((n, c), generator=g_)
+    s3 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    ops.relu_bn_bwd_reduce(None, dpool.to(gpu), craw.to(gpu), ss, gbuf, s3)
+    pp = P[0] * P[1] * P[2]
+    gr3 = (dpool.double() / pp)[:, :, None, None, None] * (z > 0)
+    report("rbr_pool_g", gbuf, gr3, rt, at * gr3.abs().max().item())
+    pooled = torch.empty((n, c), device=gpu)
+    ops.pool_fwd(craw.to(gpu), ss, pooled)
+    report("pool", pooled, F.relu(z).mean((2, 3, 4)), 1e-5, 1e-5)
+
+
+def test_se(gpu):
+    ops = _ops()
+    n, c, wd, P = 3, 54, 8, 640.0
+    g_ = _gen(8)
+    pool_sums = torch.randn((n, c), generator=g_, dtype=torch.float64) * 30
+    bss = torch.stack([1 + 0.3 * torch.randn(c, generator=g_), 0.3 * torch.randn(c, generator=g_)], 1)
+    w1 = torch.randn((wd, c), generator=g_) * 0.3
+    b1 = torch.randn(wd, generator=g_) * 0.1
+    w2 = torch.randn((c, wd), generator=g_) * 0.3
+    b2 = torch.randn(c, generator=g_) * 0.1
+    gate = torch.empty((n, c), device=gpu)
+    hidden = torch.empty((n, wd), device=gpu)
+    ops.se_fwd(pool_sums.to(gpu), P, bss.to(gpu), w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu), gate, hidden)
+    pooled = bss[:, 0].double() * pool_sums / P + bss[:, 1].double()
+    h = F.relu(pooled @ w1.double().t() + b1.double())
+    gr = torch.sigmoid(h @ w2.double().t() + b2.double())
+    report("hidden", hidden, h, 1e-5, 1e-5)
+    report("gate", gate, gr, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("has_se", [True, False])
+def test_se_bnb_bwd(gpu, has_se):
+    """Composite check: u = bn_b(braw) [train stats] -> (SE gate) -> v ; L = sum(dv * v).  The kernel sees only the
+    per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients."""
+    ops = _ops()
+    n, c, wd = 3, 12, 8
+    T, H, W = 2, 3, 4
+    P = T * H * W
+    g_ = _gen(9)
+    braw = torch.randn((n, c, T, H, W), generator=g_, dtype=torch.float64)
+    dv = torch.randn((n, c, T, H, W), generator=g_, dtype=torch.float64)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g_)).double().requires_grad_(True)
+    beta = (0.2 * torch.randn(c, generator=g_)).double().requires_grad_(True)
+    w1 = (torch.randn((wd, c), generator=g_) * 0.3).double().requires_grad_(True)
+    b1 = (torch.randn(wd, generator=g_) * 0.1).double().requires_grad_(True)
+    w2 = (torch.randn((c, wd), generator=g_) * 0.3).double().requires_grad_(True)
+    b2 = (torch.randn(c, generator=g_) * 0.1).double().requires_grad_(True)
+    x_ = braw.clone().requires_grad_(True)
+    mu = x_.mean((0, 2, 3, 4), keepdim=True)
+    vr = x_.var((0, 2, 3, 4), unbiased=False, keepdim=True)
+    inv = 1 / torch.sqrt(vr + 1e-5)
+    u = (x_ - mu) * inv * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)
+    if has_se:
+        pooled = u.mean((2, 3, 4))
+        h = F.relu(pooled @ w1.t() + b1)
+        gate = torch.sigmoid(h @ w2.t() + b2)
+        v = u * gate[:, :, None, None, None]
+    else:
+        v = u
+    params = [x_, gamma, beta] + ([w1, b1, w2, b2] if has_se else [])
+    grads = torch.autograd.grad((v * dv).sum(), params)
+    # kernel inputs
+    f32 = lambda t_: t_.detach().float().to(gpu).contiguous()
+    bss = torch.stack([(gamma * inv.view(-1)).detach(), (beta - mu.view(-1) * gamma * inv.view(-1)).detach()], 1)
+    bmi = torch.stack([mu.view(-1).detach(), inv.view(-1).detach()], 1)
+    nc_sums = torch.stack([dv.sum((2, 3, 4)), (dv * braw).sum((2, 3, 4))], -1).to(gpu)
+    pool_sums = braw.sum((2, 3, 4)).to(gpu)
+    coef_nc = torch.empty((n, c, 4), device=gpu)
+    dgam = torch.zeros(c, device=gpu)
+    dbet = torch.zeros(c, device=gpu)
+    kw = {}
+    if has_se:
+        kw = dict(w1=f32(w1), b1=f32(b1), w2=f32(w2), b2=f32(b2), gate=f32(gate), hidden=f32(h),
+                  dw1=torch.zeros((wd, c), device=gpu), db1=torch.zeros(wd, device=gpu),
+                  dw2=torch.zeros((c, wd), device=gpu), db2=torch.zeros(c, device=gpu),
+                  scratch=torch.empty((n, c), device=gpu))
+    ops.se_bnb_bwd(nc_sums, pool_sums if has_se else None, P, f32(bss), f32(bmi), f32(gamma), dgam, dbet, coef_nc,
+                   n, c, **kw)
+    torch.cuda.synchronize()
+    cf = coef_nc.cpu().double()
+    dB = cf[:, :, 0, None, None, None] * dv + cf[:, :, 1, None, None, None] * braw + cf[:, :, 2, None, None, None]
+    report("dbraw", dB, grads[0], 2e-4, 2e-5)
+    report("dgamma_b", dgam, grads[1], 2e-4, 2e-4)
+    report("dbeta_b", dbet, grads[2], 2e-4, 2e-4)
+    if has_se:
+        report("dw1", kw["dw1"], grads[3], 2e-4, 2e-5)
+        report("db1", kw["db1"], grads[4], 2e-4, 2e-5)
+        report("dw2", kw["dw2"], grads[5], 2e-4, 2e-5)
+        report("db2", kw["db2"], grads[6], 2e-4, 2e-5)
+
+
+def test_head(gpu):
+    ops = _ops()
+    n, k, m1, m2 = 5, 54, 96, 40
+    g_ = _gen(10)
+    x = torch.randn((n, k), generator=g_)
+    w1 = torch.randn((m1, k), generator=g_) * 0.2
+    w2 = torch.randn((m2, m1), generator=g_) * 0.2
+    b2 = torch.randn(m2, generator=g_) * 0.1
+    mask = (torch.rand((n, m1), generator=g_) > 0.5).float()
+    labels = torch.randint(0, m2, (n,), generator=g_, dtype=torch.int32)
+    O = _oracle()
+    xd = x.double().requires_grad_(True)
+    w1d, w2d, b2d = [t.double().requires_grad_(True) for t in (w1, w2, b2)]
+    h = F.relu(xd @ w1d.t())
+    hm = h * mask.double() * 2.0
+    logits = hm @ w2d.t() + b2d
+    probs = torch.softmax(logits, -1)
+    q = probs.clamp(1e-7, 1 - 1e-7)
+    loss_rows = -torch.log(q.gather(1, labels.long().view(-1, 1)).squeeze(1)) + torch.log(q.sum(1))
+    gx, gw1, gw2, gb2 = torch.autograd.grad(loss_rows.mean(), [xd, w1d, w2d, b2d])
+    dev = lambda t_: t_.to(gpu)
+    hg = torch.empty((n, m1), device=gpu)
+    ops.dense_fwd(dev(x), dev(w1), None, hg, act=1)
+    lg = torch.empty((n, m2), device=gpu)
+    ops.dense_fwd(hg, dev(w2), dev(b2), lg, act=0, mask=dev(mask), mask_scale=2.0)
+    pg = torch.empty((n, m2), device=gpu)
+    lr = torch.empty(n, device=gpu)
+    dl = torch.empty((n, m2), device=gpu)
+    ops.softmax_xent(lg, dev(labels), pg, lr, dl, 1.0 / n)
+    report("h", hg, h, 1e-5, 1e-5)
+    report("logits", lg, logits, 1e-5, 1e-5)
+    report("probs", pg, probs, 1e-5, 1e-7)
+    report("loss_rows", lr, loss_rows, 1e-5, 1e-5)
+    dh = torch.empty((n, m1), device=gpu)
+    dw2 = torch.zeros((m2, m1), device=gpu)
+    db2 = torch.zeros(m2, device=gpu)
+    ops.dense_bwd(dl, None, 0, hg, dev(w2), dh, dw2, db2, mask=dev(mask), mask_scale=2.0)
+    dx = torch.empty((n, k), device=gpu)
+    dw1 = torch.zeros((m1, k), device=gpu)
+    ops.dense_bwd(dh, hg, 1, dev(x), dev(w1), dx, dw1, None)
+    report("dw2", dw2, gw2, 1e-4, 1e-6)
+    report("db2", db2, gb2, 1e-4, 1e-6)
+    report("dw1", dw1, gw1, 1e-4, 1e-6)
+    report("dx", dx, gx, 1e-4, 1e-6)
+    # clipped regime: a dominant logit pushes p to the 1e-7 clip
+    big = torch.zeros((2, m2))
+    big[0, 3] = 40.0
+    big[1, 5] = 40.0
+    lab2 = torch.tensor([3, 7], dtype=torch.int32)
+    bd = big.double().requires_grad_(True)
+    pr = torch.softmax(bd, -1)
+    qq = pr.clamp(1e-7, 1 - 1e-7)
+    ll = -torch.log(qq.gather(1, lab2.long().view(-1, 1)).squeeze(1)) + torch.log(qq.sum(1))
+    (gbig,) = torch.autograd.grad(ll.sum(), [bd])
+    p2 = torch.empty((2, m2), device=gpu)
+    l2 = torch.empty(2, device=gpu)
+    d2 = torch.empty((2, m2), device=gpu)
+    ops.softmax_xent(dev(big), dev(lab2), p2, l2, d2, 1.0)
+    report("loss_clipped", l2, ll, 1e-4, 1e-4)
+    report("dlogits_clipped", d2, gbig, 1e-3, 1e-6)
+    # view mean
+    out = torch.empty((1, m2), device=gpu)
+    ops.view_mean(p2, out, 2)
+    report("view_mean", out, p2.cpu().double().mean(0, keepdim=True), 1e-6, 1e-8)
+
+
+def test_sgd_and_layout(gpu):
+    ops, O = _ops(), _oracle()
+    g_ = _gen(11)
+    nel = 1000
+    w = torch.randn(nel, generator=g_)
+    v = torch.randn(nel, generator=g_) * 0.1
+    g = torch.randn(nel, generator=g_)
+    mask = (torch.rand(nel, generator=g_) > 0.5).to(torch.uint8)
+    wg, vg = w.to(gpu), v.to(gpu)
+    ops.sgd_nesterov(wg, vg, g.to(gpu), mask.to(gpu), 0.1, 0.9, 5e-5, 0.5)
+    gg = g.double() * 0.5 + 2 * 5e-5 * w.double() * mask.double()
+    vref = 0.9 * v.double() - 0.1 * gg
+    wref = w.double() + 0.9 * vref - 0.1 * gg
+    report("v", vg, vref, 1e-6, 1e-7)
+    report("w", wg, wref, 1e-6, 1e-7)
+    acc = torch.zeros(1, dtype=torch.float64, device=gpu)
+    ops.l2_sumsq(w.to(gpu), mask.to(gpu), acc)
+    report("l2", acc, ((w.double() ** 2) * mask.double()).sum().view(1), 1e-6, 1e-6)
+    x = torch.randn((2, 3, 5, 7, 3), generator=g_)
+    for dt in DTYPES:
+        dst = torch.empty((2, 3, 3, 5, 7), dtype=dt, device=gpu)
+        ops.nthwc_to_ncthw(x.to(gpu), dst)
+        report("layout", dst, x.permute(0, 4, 1, 2, 3).to(dt), 0, 0)

@@ -1,0 +1,29 @@
+import torch
+
+
+def report(name, got, ref, rtol, atol):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        idx = torch.nonzero(bad | ~torch.isfinite(got))[0].tolist() if (bad | ~torch.isfinite(got)).any() else None
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} elements out of tolerance (rtol={rtol}, atol={atol}); "
+            f"max abs err {err.max().item():.3e}, max |ref| {ref.abs().max().item():.3e}; first bad index {idx}: "
+            f"got {got[tuple(idx)].item() if idx is not None else None} ref {ref[tuple(idx)].item() if idx is not None else None}")
+    return err.max().item()
+
+
+def tol_for(dtype):
+    # (rtol, atol) for outputs stored in `dtype`; inputs are pre-rounded so only output rounding and
+    # fp32 accumulation order differ from the fp64 reference
+    return (2e-5, 2e-5) if dtype == torch.float32 else (1.6e-2, 1.6e-2)
+
+
+def rnd(shape, dtype, gen, scale=1.0):
+    """random tensor representable in `dtype`, returned as (device-dtype tensor on cpu, fp64 copy)"""
+    t = (torch.randn(shape, generator=gen, dtype=torch.float32) * scale).to(dtype)
+    return t, t.double()

@@ -1,0 +1,189 @@
+// Shared device/host helpers for the X3D HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/x3d_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error reporting across the C ABI: status codes + a thread-local message (x3d_last_error()).
+// ---------------------------------------------------------------------------------------------
+void x3d_set_error(const char* fmt, ...);
+
+#define X3D_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      x3d_set_error(__VA_ARGS__);              \
+      return X3D_ERR_INVALID;                  \
+    }                                          \
+  } while (0)
+
+#define X3D_LAUNCH_CHECK(name)                                               \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      x3d_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return X3D_ERR_LAUNCH;                                                 \
+    }                                                                        \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// storage-type conversion.  Arithmetic is always fp32; T is only the HBM storage type.
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+// value as it will read back from HBM (used so batch statistics describe the stored tensor)
+template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f<T>(from_f<T>(v)); }
+
+// VEC contiguous elements -> fp32 registers (VEC in {1,2,4,8}; caller guarantees alignment)
+template <typename T, int VEC> struct VecIO;
+template <int VEC> struct VecIO<float, VEC> {
+  static __device__ __forceinline__ void load(const float* p, float (&o)[VEC]) {
+    if constexpr (VEC == 8) {
+      f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o[i] = a[i]; o[4 + i] = b[i]; }
+    } else if constexpr (VEC == 4) {
+      f32x4 a = *(const f32x4*)p;
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[i] = a[i];
+    } else if constexpr (VEC == 2) {
+      float2 a = *(const float2*)p; o[0] = a.x; o[1] = a.y;
+    } else { o[0] = *p; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+      f32x4 a, b;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
+      *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+    } else if constexpr (VEC == 4) {
+      f32x4 a;
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = v[i];
+      *(f32x4*)p = a;
+    } else if constexpr (VEC == 2) {
+      *(float2*)p = make_float2(v[0], v[1]);
+    } else { *p = v[0]; }
+  }
+};
+template <int VEC> struct VecIO<bf16, VEC> {
+  static __device__ __forceinline__ void load(const bf16* p, float (&o)[VEC]) {
+    if constexpr (VEC == 8) {
+      bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+      for (int i = 0; i < 8; i++) o[i] = (float)a[i];
+    } else if constexpr (VEC == 4) {
+      bf16x4 a = *(const bf16x4*)p;
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[i] = (float)a[i];
+    } else if constexpr (VEC == 2) {
+      bf16x2 a = *(const bf16x2*)p; o[0] = (float)a[0]; o[1] = (float)a[1];
+    } else { o[0] = (float)*p; }
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+      bf16x8 a;
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = (bf16)v[i];
+      *(bf16x8*)p = a;
+    } else if constexpr (VEC == 4) {
+      bf16x4 a;
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = (bf16)v[i];
+      *(bf16x4*)p = a;
+    } else if constexpr (VEC == 2) {
+      bf16x2 a; a[0] = (bf16)v[0]; a[1] = (bf16)v[1];
+      *(bf16x2*)p = a;
+    } else { *p = (bf16)v[0]; }
+  }
+};
+
+// largest power-of-two vector (<= cap elements, <= 16 bytes) dividing every extent given and
+// compatible with the pointer alignments
+static inline int pick_vec(int elem_bytes, long long extent, const void* p0, const void* p1 = nullptr,
+                           const void* p2 = nullptr, const void* p3 = nullptr) {
+  int v = 16 / elem_bytes;
+  const void* ps[4] = {p0, p1, p2, p3};
+  while (v > 1) {
+    bool ok = (extent % v) == 0;
+    for (int i = 0; i < 4 && ok; i++)
+      if (ps[i] && ((uintptr_t)ps[i] % (size_t)(v * elem_bytes)) != 0) ok = false;
+    if (ok) break;
+    v >>= 1;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float swishf_(float v) { return v * sigmoidf_(v); }
+__device__ __forceinline__ float swish_grad_(float v) {
+  float s = sigmoidf_(v);
+  return s * (1.0f + v * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions: 64-wide wavefront shuffles, then LDS across the waves of a block
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of NV floats per thread; result valid in thread 0.  scratch: >= NV * (blockDim/64) floats.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) scratch[wid * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      float s = 0.f;
+      for (int w = 0; w < nw; w++) s += scratch[w * NV + i];
+      v[i] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p, v); }

@@ -1,0 +1,509 @@
+// Channelwise 3x3x3 convolution (stride (1,s,s), TF-SAME padding): forward and fused backward.
+//
+// HBM-bound: 27 FMAs per output against 2-10 bytes, so the design goal is "read every input element
+// once, write every output once".  One workgroup owns one (n, c, H-tile) and streams the T planes of
+// that channel through LDS:
+//   global --(vector load, folded BN+ReLU applied once per element)--> LDS plane with zero halo
+// Each thread owns a strip of SW consecutive outputs of one row and keeps THREE partial output
+// planes (t-1, t, t+1) in registers: a staged input plane is read from LDS once and scattered into
+// the three temporal taps, so no plane is ever re-read and only one plane lives in LDS.
+// Per-channel BatchNorm statistics and the squeeze-excite pool are reduced in the epilogue
+// (wave shuffles -> LDS -> one fp64 atomic per workgroup).
+#include "common.h"
+
+struct DwGeom {
+  int N, C, T, H, W, Ho, Wo, S;
+  int ph, pw;        // TF-SAME pad_before along H, W
+  int TH;            // output rows per tile
+  int ntile_h;
+  int nstrips;       // strips of SW outputs per row
+  int RIN;           // staged input rows  = (TH-1)*S + 3
+  int LP;            // LDS pitch (floats) = (nstrips*SW-1)*S + 3
+  int vec;           // staging vector width along W
+};
+
+struct DwFwdArgs {
+  DwGeom g;
+  const void* x; const float* w; void* y;
+  const float* ss; int act;
+  double* stats; double* pool;
+};
+
+// stage rows [0, RIN) of image plane `src` (H x W, row-major) into lds[lr*LP + pw + col], applying
+// v = act(sc*x + sh) (identity when !affine).  Rows outside the image are left untouched (zero).
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void dw_stage_rows(const T* __restrict__ src, float* lds, int RIN, int LP,
+                                              int row0 /* image row of lds row 0 */, int H, int W,
+                                              int pw, F f) {
+  const int nvr = W / VEC;
+  const int total = RIN * nvr;
+  for (int v = threadIdx.x; v < total; v += blockDim.x) {
+    const int lr = v / nvr, jv = v - lr * nvr;
+    const int hi = row0 + lr;
+    if (hi >= 0 && hi < H) {
+      float val[VEC];
+      VecIO<T, VEC>::load(src + (long long)hi * W + jv * VEC, val);
+      float* d = lds + lr * LP + pw + jv * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) d[e] = f(val[e]);
+    }
+  }
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ void dw_stage_rows_v(int vec, const T* src, float* lds, int RIN, int LP,
+                                                int row0, int H, int W, int pw, F f) {
+  switch (vec) {
+    case 8: if constexpr (sizeof(T) == 2) { dw_stage_rows<T, 8>(src, lds, RIN, LP, row0, H, W, pw, f); break; }
+    case 4: dw_stage_rows<T, 4>(src, lds, RIN, LP, row0, H, W, pw, f); break;
+    case 2: dw_stage_rows<T, 2>(src, lds, RIN, LP, row0, H, W, pw, f); break;
+    default: dw_stage_rows<T, 1>(src, lds, RIN, LP, row0, H, W, pw, f); break;
+  }
+}
+
+// two-operand variant: f(a, b) -> value   (dB = A*dv + B*braw + C)
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void dw_stage_rows2(const T* __restrict__ s0, const T* __restrict__ s1,
+                                               float* lds, int RIN, int LP, int row0, int H, int W,
+                                               int pw, F f) {
+  const int nvr = W / VEC;
+  const int total = RIN * nvr;
+  for (int v = threadIdx.x; v < total; v += blockDim.x) {
+    const int lr = v / nvr, jv = v - lr * nvr;
+    const int hi = row0 + lr;
+    if (hi >= 0 && hi < H) {
+      float a[VEC], b[VEC];
+      VecIO<T, VEC>::load(s0 + (long long)hi * W + jv * VEC, a);
+      VecIO<T, VEC>::load(s1 + (long long)hi * W + jv * VEC, b);
+      float* d = lds + lr * LP + pw + jv * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) d[e] = f(a[e], b[e]);
+    }
+  }
+}
+template <typename T, typename F>
+__device__ __forceinline__ void dw_stage_rows2_v(int vec, const T* s0, const T* s1, float* lds, int RIN,
+                                                 int LP, int row0, int H, int W, int pw, F f) {
+  switch (vec) {
+    case 8: if constexpr (sizeof(T) == 2) { dw_stage_rows2<T, 8>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break; }
+    case 4: dw_stage_rows2<T, 4>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
+    case 2: dw_stage_rows2<T, 2>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
+    default: dw_stage_rows2<T, 1>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
+  }
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <typename T, int S, int SW>
+__global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwGeom& g = a.g;
+  constexpr int WIN = (SW - 1) * S + 3;
+  const int plane_sz = g.RIN * g.LP;
+  float* scratch = lds + plane_sz;
+
+  int b = blockIdx.x;
+  const int tile = b % g.ntile_h; b /= g.ntile_h;
+  const int c = b % g.C;
+  const int n = b / g.C;
+  const int h0 = tile * g.TH;
+  const int th_here = min(g.TH, g.Ho - h0);
+
+  const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
+  const bool active = r < th_here;
+  const int ho = h0 + r, wo0 = sidx * SW;
+
+  for (int i = threadIdx.x; i < plane_sz; i += blockDim.x) lds[i] = 0.f;
+
+  float wgt[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  const bool affine = a.ss != nullptr;
+  const float sc = affine ? a.ss[c * 2] : 1.f, sh = affine ? a.ss[c * 2 + 1] : 0.f;
+  const int act = a.act;
+  auto xf = [=](float v) {
+    float u = sc * v + sh;
+    return act == X3D_ACT_RELU ? fmaxf(u, 0.f) : u;
+  };
+
+  float acc0[SW], acc1[SW], acc2[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
+  float s1 = 0.f, s2 = 0.f;
+
+  const T* xin = (const T*)a.x + ((long long)n * g.C + c) * g.T * g.H * g.W;
+  T* yout = (T*)a.y + ((long long)n * g.C + c) * g.T * g.Ho * g.Wo;
+  const long long oplane = (long long)g.Ho * g.Wo;
+
+  auto store_plane = [&](int t, const float (&v)[SW]) {
+    if (!active) return;
+    T* dst = yout + t * oplane + (long long)ho * g.Wo + wo0;
+#pragma unroll
+    for (int i = 0; i < SW; i++) {
+      if (wo0 + i < g.Wo) {
+        dst[i] = from_f<T>(v[i]);
+        const float vr = round_to<T>(v[i]);
+        s1 += vr;
+        s2 += vr * vr;
+      }
+    }
+  };
+
+  for (int t = 0; t < g.T; ++t) {
+    __syncthreads();  // zero-fill / previous plane's readers done
+    dw_stage_rows_v<T>(g.vec, xin + (long long)t * g.H * g.W, lds, g.RIN, g.LP, h0 * S - g.ph, g.H,
+                       g.W, g.pw, xf);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) {
+        float win[WIN];
+        const float* row = lds + (r * S + kh) * g.LP + wo0 * S;
+#pragma unroll
+        for (int j = 0; j < WIN; j++) win[j] = row[j];
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+          for (int i = 0; i < SW; i++) {
+            const float v = win[i * S + kw];
+            acc0[i] += wgt[18 + kh * 3 + kw] * v;  // out[t-1] sees this plane through kt = 2
+            acc1[i] += wgt[9 + kh * 3 + kw] * v;   // out[t]   through kt = 1
+            acc2[i] += wgt[kh * 3 + kw] * v;       // out[t+1] through kt = 0
+          }
+        }
+      }
+    }
+    if (t >= 1) store_plane(t - 1, acc0);
+#pragma unroll
+    for (int i = 0; i < SW; i++) { acc0[i] = acc1[i]; acc1[i] = acc2[i]; acc2[i] = 0.f; }
+  }
+  store_plane(g.T - 1, acc0);
+
+  if (a.stats || a.pool) {
+    float red[2] = {s1, s2};
+    block_sum<2>(red, scratch);
+    if (threadIdx.x == 0) {
+      if (a.stats) {
+        atomic_add_d(&a.stats[c * 2], (double)red[0]);
+        atomic_add_d(&a.stats[c * 2 + 1], (double)red[1]);
+      }
+      if (a.pool) atomic_add_d(&a.pool[(long long)n * g.C + c], (double)red[0]);
+    }
+  }
+}
+
+// tile geometry shared by forward and backward
+static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int SW, int elem_bytes,
+                   const void* p0, const void* p1, const void* p2, int* block_dim, size_t* lds_floats,
+                   int max_items) {
+  g.N = N; g.C = C; g.T = T; g.H = H; g.W = W; g.S = stride;
+  g.Ho = ceil_div(H, stride); g.Wo = ceil_div(W, stride);
+  const int tot_h = (g.Ho - 1) * stride + 3 - H, tot_w = (g.Wo - 1) * stride + 3 - W;
+  g.ph = (tot_h > 0 ? tot_h : 0) / 2;
+  g.pw = (tot_w > 0 ? tot_w : 0) / 2;
+  g.nstrips = ceil_div(g.Wo, SW);
+  int bd = 256;
+  const int items = g.Ho * g.nstrips;
+  if (items <= 64) bd = 64;
+  else if (items <= 128) bd = 128;
+  if (bd > max_items) bd = max_items;
+  if (g.nstrips > bd) return -1;
+  int th = bd / g.nstrips;
+  if (th > g.Ho) th = g.Ho;
+  g.ntile_h = ceil_div(g.Ho, th);
+  g.TH = ceil_div(g.Ho, g.ntile_h);
+  g.RIN = (g.TH - 1) * stride + 3;
+  g.LP = (g.nstrips * SW - 1) * stride + 3;
+  g.vec = pick_vec(elem_bytes, W, p0, p1, p2);
+  *block_dim = bd;
+  *lds_floats = (size_t)g.RIN * g.LP;
+  return 0;
+}
+
+static int dw_pick_sw(int Wo) { return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1); }
+
+template <typename T, int S>
+static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
+  DwFwdArgs a;
+  a.x = f->x; a.w = f->w; a.y = f->y; a.ss = f->in_scale_shift; a.act = f->in_act;
+  a.stats = f->stats; a.pool = f->pool;
+  const int Wo = ceil_div(f->W, S);
+  const int SW = dw_pick_sw(Wo);
+  int bd; size_t ldsf;
+  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->x, nullptr, nullptr, &bd, &ldsf, 256)) {
+    x3d_set_error("dw3d_fwd: row of %d outputs does not fit one workgroup", Wo);
+    return X3D_ERR_INVALID;
+  }
+  const size_t lds = (ldsf + 2 * 4 + 8) * sizeof(float);
+  X3D_REQUIRE(lds <= 64 * 1024, "dw3d_fwd: tile needs %zu B of LDS", lds);
+  const long long grid = (long long)f->N * f->C * a.g.ntile_h;
+  X3D_REQUIRE(grid < (1ll << 31), "dw3d_fwd: grid too large");
+  switch (SW) {
+    case 4: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 4>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 2>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+    default: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 1>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+  }
+  X3D_LAUNCH_CHECK("dw3d_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {
+  X3D_REQUIRE(f && f->x && f->w && f->y, "dw3d_fwd: null pointer");
+  X3D_REQUIRE(f->stride == 1 || f->stride == 2, "dw3d_fwd: stride must be 1 or 2");
+  X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_fwd: bad extents");
+  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_fwd: bad dtype");
+  X3D_REQUIRE(f->in_act == X3D_ACT_NONE || f->in_act == X3D_ACT_RELU, "dw3d_fwd: prologue act must be none/relu");
+  hipStream_t st = (hipStream_t)stream;
+  if (f->dtype == X3D_F32)
+    return f->stride == 1 ? dw_fwd_launch<float, 1>(f, st) : dw_fwd_launch<float, 2>(f, st);
+  return f->stride == 1 ? dw_fwd_launch<bf16, 1>(f, st) : dw_fwd_launch<bf16, 2>(f, st);
+}
+
+// ================================================================================================
+// backward (data + weight fused).  Thread = output position strip, exactly as in the forward.
+//   dB = A*dv + B*braw + C            (BN_b / SE backward folded, per (n,c) coefficients)
+//   dW[kt][kh][kw] += sum dB[t][ho][wo] * act[t+kt-1][ho*S+kh-ph][wo*S+kw-pw]
+//   dA[t][h][w]     = sum w[kt][kh][kw] * dB[t+1-kt][(h+ph-kh)/S][(w+pw-kw)/S]
+//   ga = dA * [sc*araw + sh > 0];   a_sums += (sum ga, sum ga*araw)
+// Planes of act and dB are streamed through LDS once; the temporal taps are handled with rotating
+// register accumulators (dA) and a one-plane-old register window (dW).
+// ================================================================================================
+struct DwBwdArgs {
+  DwGeom g;
+  const void* dv; const void* braw; const float* coef_nc;
+  const void* araw; const float* ss_a; const float* w;
+  void* ga; double* a_sums; float* dw;
+  int LPB, RB;  // dB plane pitch / rows
+  int vecB;     // staging vector width for the dv / braw planes
+};
+
+template <typename T, int S, int SW>
+__global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwGeom& g = a.g;
+  constexpr int WIN = (SW - 1) * S + 3;          // act window columns
+  constexpr int BW = (S == 1) ? SW + 2 : SW + 1; // dB window columns
+  constexpr int BR = (S == 1) ? 3 : 2;           // dB window rows
+  constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
+  constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
+  const int aplane = g.RIN * g.LP;
+  const int bplane = a.RB * a.LPB;
+  float* Al = lds;
+  float* Bl = lds + aplane;
+  float* scratch = Bl + bplane;
+
+  int b = blockIdx.x;
+  const int tile = b % g.ntile_h; b /= g.ntile_h;
+  const int c = b % g.C;
+  const int n = b / g.C;
+  const int h0 = tile * g.TH;
+  const int th_here = min(g.TH, g.Ho - h0);
+  const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
+  const bool active = r < th_here;
+  const int ho = h0 + r, wo0 = sidx * SW;
+
+  for (int i = threadIdx.x; i < aplane + bplane; i += blockDim.x) lds[i] = 0.f;
+
+  float wgt[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
+  const float* cf = a.coef_nc + ((long long)n * g.C + c) * 4;
+  const float cA = cf[0], cB = cf[1], cC = cf[2];
+  auto af = [=](float v) { return fmaxf(sc * v + sh, 0.f); };
+  auto bf = [=](float dvv, float bv) { return cA * dvv + cB * bv + cC; };
+
+  const long long ipl = (long long)g.H * g.W, opl = (long long)g.Ho * g.Wo;
+  const T* araw = (const T*)a.araw + ((long long)n * g.C + c) * g.T * ipl;
+  const T* dvp = (const T*)a.dv + ((long long)n * g.C + c) * g.T * opl;
+  const T* brp = (const T*)a.braw + ((long long)n * g.C + c) * g.T * opl;
+  T* gap = (T*)a.ga + ((long long)n * g.C + c) * g.T * ipl;
+
+  float dA0[NR][NA], dA1[NR][NA], dA2[NR][NA];
+#pragma unroll
+  for (int q = 0; q < NR; q++)
+#pragma unroll
+    for (int i = 0; i < NA; i++) { dA0[q][i] = 0.f; dA1[q][i] = 0.f; dA2[q][i] = 0.f; }
+  float dW[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) dW[k] = 0.f;
+  float winA_prev[3][WIN], dB_prev[SW];
+#pragma unroll
+  for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+    for (int j = 0; j < WIN; j++) winA_prev[kh][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < SW; i++) dB_prev[i] = 0.f;
+  float s1 = 0.f, s2 = 0.f;
+
+  // image rows / cols owned for dA
+  const int hA = (S == 1) ? ho : ho * 2 - g.ph;
+  const int wA0 = (S == 1) ? wo0 : wo0 * 2 - g.pw;
+
+  auto emit = [&](int t, const float (&v)[NR][NA]) {
+    if (!active) return;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      const int h = hA + q;
+      if (h < 0 || h >= g.H) continue;
+      const long long base = t * ipl + (long long)h * g.W;
+#pragma unroll
+      for (int i = 0; i < NA; i++) {
+        const int w = wA0 + i;
+        if (w >= 0 && w < g.W) {
+          const float av = to_f<T>(araw[base + w]);
+          const float gv = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
+          gap[base + w] = from_f<T>(gv);
+          const float gr = round_to<T>(gv);
+          s1 += gr;
+          s2 += gr * av;
+        }
+      }
+    }
+  };
+
+  for (int t = 0; t < g.T; ++t) {
+    __syncthreads();
+    dw_stage_rows_v<T>(g.vec, araw + t * ipl, Al, g.RIN, g.LP, h0 * S - g.ph, g.H, g.W, g.pw, af);
+    // dB plane: lds row 0 <-> output row h0-1, col 0 <-> output col -1
+    dw_stage_rows2_v<T>(a.vecB, dvp + t * opl, brp + t * opl, Bl, a.RB, a.LPB, h0 - 1,
+                        g.Ho, g.Wo, 1, bf);
+    __syncthreads();
+    if (active) {
+      float winA[3][WIN], winB[BR][BW];
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) {
+        const float* row = Al + (r * S + kh) * g.LP + wo0 * S;
+#pragma unroll
+        for (int j = 0; j < WIN; j++) winA[kh][j] = row[j];
+      }
+#pragma unroll
+      for (int q = 0; q < BR; q++) {
+        const float* row = Bl + (r + q) * a.LPB + wo0;
+#pragma unroll
+        for (int j = 0; j < BW; j++) winB[q][j] = row[j];
+      }
+      // own dB strip: window row of output row `ho` is index 1 in both layouts; col wo0+i is index i+1
+      float dBo[SW];
+#pragma unroll
+      for (int i = 0; i < SW; i++) dBo[i] = winB[1][i + 1];
+
+      // ---- weight gradient
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < SW; i++) {
+            d1 += dBo[i] * winA[kh][i * S + kw];          // kt = 1: dB[t] * act[t]
+            d2 += dB_prev[i] * winA[kh][i * S + kw];      // kt = 2: dB[t-1] * act[t]
+            d0 += dBo[i] * winA_prev[kh][i * S + kw];     // kt = 0: dB[t] * act[t-1]
+          }
+          dW[kh * 3 + kw] += d0;
+          dW[9 + kh * 3 + kw] += d1;
+          dW[18 + kh * 3 + kw] += d2;
+        }
+
+      // ---- data gradient: plane dB[t] feeds dA[t-1] (kt=0), dA[t] (kt=1), dA[t+1] (kt=2)
+      if constexpr (S == 1) {
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+              const float v = winB[2 - kh][i + 2 - kw];   // dB[h+1-kh][w+1-kw]
+              dA0[0][i] += wgt[kh * 3 + kw] * v;
+              dA1[0][i] += wgt[9 + kh * 3 + kw] * v;
+              dA2[0][i] += wgt[18 + kh * 3 + kw] * v;
+            }
+      } else {
+        // rows: q=0 is image row 2ho-ph (taps kh=0 from ho, kh=2 from ho-1); q=1 is 2ho-ph+1 (kh=1 from ho)
+        // cols likewise.  winB[1][*] = dB row ho, winB[0][*] = row ho-1; col index i+1 = wo0+i.
+#pragma unroll
+        for (int i = 0; i < SW; i++) {
+          const float b11 = winB[1][i + 1], b10 = winB[1][i], b01 = winB[0][i + 1], b00 = winB[0][i];
+#pragma unroll
+          for (int kt = 0; kt < 3; kt++) {
+            const float* wk = &wgt[kt * 9];
+            const float eA = wk[0] * b11 + wk[2] * b10 + wk[6] * b01 + wk[8] * b00;  // (hA, wA)
+            const float eB = wk[1] * b11 + wk[7] * b01;                              // (hA, wB)
+            const float eC = wk[3] * b11 + wk[5] * b10;                              // (hB, wA)
+            const float eD = wk[4] * b11;                                            // (hB, wB)
+            if (kt == 0) { dA0[0][2 * i] += eA; dA0[0][2 * i + 1] += eB; dA0[1][2 * i] += eC; dA0[1][2 * i + 1] += eD; }
+            if (kt == 1) { dA1[0][2 * i] += eA; dA1[0][2 * i + 1] += eB; dA1[1][2 * i] += eC; dA1[1][2 * i + 1] += eD; }
+            if (kt == 2) { dA2[0][2 * i] += eA; dA2[0][2 * i + 1] += eB; dA2[1][2 * i] += eC; dA2[1][2 * i + 1] += eD; }
+          }
+        }
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int j = 0; j < WIN; j++) winA_prev[kh][j] = winA[kh][j];
+#pragma unroll
+      for (int i = 0; i < SW; i++) dB_prev[i] = dBo[i];
+    }
+    if (t >= 1) emit(t - 1, dA0);
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+#pragma unroll
+      for (int i = 0; i < NA; i++) { dA0[q][i] = dA1[q][i]; dA1[q][i] = dA2[q][i]; dA2[q][i] = 0.f; }
+  }
+  emit(g.T - 1, dA0);
+
+  float red[29];
+#pragma unroll
+  for (int k = 0; k < 27; k++) red[k] = dW[k];
+  red[27] = s1; red[28] = s2;
+  block_sum<29>(red, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
+    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
+    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
+  }
+}
+
+template <typename T, int S>
+static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
+  DwBwdArgs a;
+  a.dv = f->dv; a.braw = f->braw; a.coef_nc = f->coef_nc; a.araw = f->araw; a.ss_a = f->a_scale_shift;
+  a.w = f->w; a.ga = f->ga; a.a_sums = f->a_sums; a.dw = f->dw;
+  const int Wo = ceil_div(f->W, S);
+  int SW = dw_pick_sw(Wo);
+  if (S == 2 && SW > 2) SW = 2;  // 2x2 input quads per output: keep the register footprint bounded
+  int bd; size_t ldsf;
+  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->araw, f->ga, nullptr, &bd, &ldsf, 256)) {
+    x3d_set_error("dw3d_bwd: row of %d outputs does not fit one workgroup", Wo);
+    return X3D_ERR_INVALID;
+  }
+  a.RB = (S == 1) ? a.g.TH + 2 : a.g.TH + 1;
+  a.LPB = a.g.nstrips * SW + ((S == 1) ? 2 : 1);
+  a.vecB = pick_vec(sizeof(T), a.g.Wo, f->dv, f->braw);
+  const size_t lds = (ldsf + (size_t)a.RB * a.LPB + 29 * 4 + 8) * sizeof(float);
+  X3D_REQUIRE(lds <= 64 * 1024, "dw3d_bwd: tile needs %zu B of LDS", lds);
+  const long long grid = (long long)f->N * f->C * a.g.ntile_h;
+  X3D_REQUIRE(grid < (1ll << 31), "dw3d_bwd: grid too large");
+  switch (SW) {
+    case 4:
+      if constexpr (S == 1) { hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 4>), dim3((unsigned)grid), dim3(bd), lds, st, a); break; }
+    case 2: hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 2>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+    default: hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 1>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+  }
+  X3D_LAUNCH_CHECK("dw3d_bwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dw3d_bwd(const x3d_dw3d_bwd_args* f, void* stream) {
+  X3D_REQUIRE(f && f->dv && f->braw && f->coef_nc && f->araw && f->a_scale_shift && f->w && f->ga &&
+                  f->a_sums && f->dw, "dw3d_bwd: null pointer");
+  X3D_REQUIRE(f->stride == 1 || f->stride == 2, "dw3d_bwd: stride must be 1 or 2");
+  X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_bwd: bad extents");
+  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_bwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (f->dtype == X3D_F32)
+    return f->stride == 1 ? dw_bwd_launch<float, 1>(f, st) : dw_bwd_launch<float, 2>(f, st);
+  return f->stride == 1 ? dw_bwd_launch<bf16, 1>(f, st) : dw_bwd_launch<bf16, 2>(f, st);
+}

@@ -1,0 +1,366 @@
+// BatchNorm bookkeeping and the bandwidth-bound elementwise / reduction kernels around the convs:
+// BN finalize (train / eval / backward), residual tail (Add+ReLU) forward and backward, ReLU+BN
+// backward reduce (stem, conv5 after global pooling), pool5, NTHWC<->NCTHW at the module boundary.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// BN finalize kernels: one thread per channel (C <= a few hundred)
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* mmean, float* mvar, float eps, float momentum, int update,
+                                   float* ss, float* mi, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[c * 2] / count;
+  double var = stats[c * 2 + 1] / count - mean * mean;  // biased batch variance (Keras, training)
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  ss[c * 2] = sc;
+  ss[c * 2 + 1] = beta[c] - (float)mean * sc;
+  mi[c * 2] = (float)mean;
+  mi[c * 2 + 1] = invstd;
+  if (update) {
+    // Keras momentum convention: moving = moving*momentum + batch*(1-momentum); the moving variance
+    // receives the unbiased estimate (TF fused batch norm) [TF-3p]
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    mmean[c] = mmean[c] * momentum + (float)mean * (1.f - momentum);
+    mvar[c] = mvar[c] * momentum + (float)unb * (1.f - momentum);
+  }
+}
+
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ mmean, const float* __restrict__ mvar,
+                                    float eps, float* ss, float* mi, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(mvar[c] + eps);
+  const float sc = gamma[c] * invstd;
+  ss[c * 2] = sc;
+  ss[c * 2 + 1] = beta[c] - mmean[c] * sc;
+  mi[c * 2] = mmean[c];
+  mi[c * 2 + 1] = invstd;
+}
+
+// dY = k1*(g - dbeta/M - xhat*dgamma/M), k1 = gamma*invstd, xhat = (y-mean)*invstd
+//    = A*g + B*y + C with A = k1, B = -k1*invstd*dgamma/M, C = -k1*dbeta/M - B*mean
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
+                                       const float* __restrict__ mi, const float* __restrict__ gamma,
+                                       float* coef, float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = mi[c * 2], invstd = mi[c * 2 + 1];
+  const double dbe = sums[c * 2];
+  const double dga = (sums[c * 2 + 1] - mean * dbe) * invstd;
+  const double k1 = (double)gamma[c] * invstd;
+  const double B = -k1 * invstd * dga / count;
+  coef[c * 4] = (float)k1;
+  coef[c * 4 + 1] = (float)B;
+  coef[c * 4 + 2] = (float)(-k1 * dbe / count - B * mean);
+  coef[c * 4 + 3] = 0.f;
+  dgamma[c] += (float)dga;
+  dbeta[c] += (float)dbe;
+}
+
+extern "C" int x3d_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                               float* moving_mean, float* moving_var, float eps, float momentum,
+                               int update_moving, float* scale_shift, float* mean_invstd, int C,
+                               void* stream) {
+  X3D_REQUIRE(stats && gamma && beta && scale_shift && mean_invstd && C > 0 && count > 0, "bn_finalize: bad args");
+  X3D_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_finalize: moving stats required");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, count,
+                     gamma, beta, moving_mean, moving_var, eps, momentum, update_moving, scale_shift,
+                     mean_invstd, C);
+  X3D_LAUNCH_CHECK("bn_finalize");
+  return X3D_OK;
+}
+
+extern "C" int x3d_bn_eval_coef(const float* gamma, const float* beta, const float* moving_mean,
+                                const float* moving_var, float eps, float* scale_shift,
+                                float* mean_invstd, int C, void* stream) {
+  X3D_REQUIRE(gamma && beta && moving_mean && moving_var && scale_shift && mean_invstd && C > 0, "bn_eval_coef: bad args");
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, scale_shift, mean_invstd, C);
+  X3D_LAUNCH_CHECK("bn_eval_coef");
+  return X3D_OK;
+}
+
+extern "C" int x3d_bn_bwd_finalize(const double* sums, double count, const float* mean_invstd,
+                                   const float* gamma, float* coef, float* dgamma, float* dbeta, int C,
+                                   void* stream) {
+  X3D_REQUIRE(sums && mean_invstd && gamma && coef && dgamma && dbeta && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, count,
+                     mean_invstd, gamma, coef, dgamma, dbeta, C);
+  X3D_LAUNCH_CHECK("bn_bwd_finalize");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane-wise elementwise kernels.  grid = (chunks over P, N*C): the channel is uniform per block.
+// Each thread handles VEC contiguous elements per iteration.
+// ------------------------------------------------------------------------------------------------
+#define ELEM_BLOCK 256
+#define ELEM_ITERS 4
+
+static inline dim3 elem_grid(long long P, int vec, int NC) {
+  return dim3((unsigned)ceil_div_ll(P, (long long)ELEM_BLOCK * vec * ELEM_ITERS), (unsigned)NC);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(ELEM_BLOCK) void tail_fwd_kernel(const T* __restrict__ craw,
+                                                             const float* __restrict__ ssc,
+                                                             const T* __restrict__ sh,
+                                                             const float* __restrict__ ssr, T* __restrict__ y,
+                                                             int C, long long P) {
+  const int nc = blockIdx.y, c = nc % C;
+  const float sc = ssc[c * 2], tc = ssc[c * 2 + 1];
+  const float sr = ssr ? ssr[c * 2] : 1.f, tr = ssr ? ssr[c * 2 + 1] : 0.f;
+  const long long base = (long long)nc * P;
+  long long p = ((long long)blockIdx.x * ELEM_ITERS * ELEM_BLOCK + threadIdx.x) * VEC;
+#pragma unroll
+  for (int it = 0; it < ELEM_ITERS; it++, p += (long long)ELEM_BLOCK * VEC) {
+    if (p < P) {
+      float a[VEC], b[VEC], o[VEC];
+      VecIO<T, VEC>::load(craw + base + p, a);
+      if (sh) {
+        VecIO<T, VEC>::load(sh + base + p, b);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o[e] = fmaxf(sc * a[e] + tc + (sr * b[e] + tr), 0.f);
+      } else {  // plain BN + ReLU (stem output)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o[e] = fmaxf(sc * a[e] + tc, 0.f);
+      }
+      VecIO<T, VEC>::store(y + base + p, o);
+    }
+  }
+}
+
+// g = dy*[y>0] in place; sums_c += (sum g, sum g*craw); sums_r += (sum g, sum g*rraw)
+template <typename T, int VEC>
+__global__ __launch_bounds__(ELEM_BLOCK) void tail_bwd_kernel(T* __restrict__ dyg, const T* __restrict__ y,
+                                                             const T* __restrict__ craw,
+                                                             const T* __restrict__ rraw, double* sums_c,
+                                                             double* sums_r, int C, long long P) {
+  __shared__ float scratch[3 * (ELEM_BLOCK / 64)];
+  const int nc = blockIdx.y, c = nc % C;
+  const long long base = (long long)nc * P;
+  float red[3] = {0.f, 0.f, 0.f};
+  long long p = ((long long)blockIdx.x * ELEM_ITERS * ELEM_BLOCK + threadIdx.x) * VEC;
+#pragma unroll
+  for (int it = 0; it < ELEM_ITERS; it++, p += (long long)ELEM_BLOCK * VEC) {
+    if (p < P) {
+      float d[VEC], yy[VEC], cr[VEC], rr[VEC], g[VEC];
+      VecIO<T, VEC>::load(dyg + base + p, d);
+      VecIO<T, VEC>::load(y + base + p, yy);
+      VecIO<T, VEC>::load(craw + base + p, cr);
+      if (rraw) VecIO<T, VEC>::load(rraw + base + p, rr);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        g[e] = yy[e] > 0.f ? d[e] : 0.f;
+        red[0] += g[e];
+        red[1] += g[e] * cr[e];
+        if (rraw) red[2] += g[e] * rr[e];
+      }
+      VecIO<T, VEC>::store(dyg + base + p, g);
+    }
+  }
+  block_sum<3>(red, scratch);
+  if (threadIdx.x == 0) {
+    atomic_add_d(&sums_c[c * 2], (double)red[0]);
+    atomic_add_d(&sums_c[c * 2 + 1], (double)red[1]);
+    if (rraw) {
+      atomic_add_d(&sums_r[c * 2], (double)red[0]);
+      atomic_add_d(&sums_r[c * 2 + 1], (double)red[2]);
+    }
+  }
+}
+
+// z = s*yraw + t ; g = (dy ? dy : dpool[n][c]/P) * [z > 0]; sums += (sum g, sum g*yraw)
+template <typename T, int VEC>
+__global__ __launch_bounds__(ELEM_BLOCK) void relu_bn_bwd_reduce_kernel(const T* __restrict__ dy,
+                                                                       const float* __restrict__ dpool,
+                                                                       const T* __restrict__ yraw,
+                                                                       const float* __restrict__ ss, T* g,
+                                                                       double* sums, int C, long long P) {
+  __shared__ float scratch[2 * (ELEM_BLOCK / 64)];
+  const int nc = blockIdx.y, c = nc % C;
+  const float s = ss[c * 2], t = ss[c * 2 + 1];
+  const float dp = dpool ? dpool[nc] / (float)P : 0.f;
+  const long long base = (long long)nc * P;
+  float red[2] = {0.f, 0.f};
+  long long p = ((long long)blockIdx.x * ELEM_ITERS * ELEM_BLOCK + threadIdx.x) * VEC;
+#pragma unroll
+  for (int it = 0; it < ELEM_ITERS; it++, p += (long long)ELEM_BLOCK * VEC) {
+    if (p < P) {
+      float d[VEC], yr[VEC], o[VEC];
+      VecIO<T, VEC>::load(yraw + base + p, yr);
+      if (dy) {
+        VecIO<T, VEC>::load(dy + base + p, d);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) d[e] = dp;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        o[e] = (s * yr[e] + t > 0.f) ? d[e] : 0.f;
+        const float gr = round_to<T>(o[e]);
+        red[0] += gr;
+        red[1] += gr * yr[e];
+      }
+      VecIO<T, VEC>::store(g + base + p, o);
+    }
+  }
+  block_sum<2>(red, scratch);
+  if (threadIdx.x == 0) {
+    atomic_add_d(&sums[c * 2], (double)red[0]);
+    atomic_add_d(&sums[c * 2 + 1], (double)red[1]);
+  }
+}
+
+// pooled[n][c] = mean_p relu(s*x + t): one block per (n, c)
+template <typename T, int VEC>
+__global__ __launch_bounds__(ELEM_BLOCK) void pool_fwd_kernel(const T* __restrict__ x,
+                                                             const float* __restrict__ ss, float* pooled,
+                                                             int C, long long P) {
+  __shared__ float scratch[ELEM_BLOCK / 64];
+  const int nc = blockIdx.x, c = nc % C;
+  const float s = ss[c * 2], t = ss[c * 2 + 1];
+  const long long base = (long long)nc * P;
+  float red[1] = {0.f};
+  for (long long p = (long long)threadIdx.x * VEC; p < P; p += (long long)ELEM_BLOCK * VEC) {
+    float v[VEC];
+    VecIO<T, VEC>::load(x + base + p, v);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) red[0] += fmaxf(s * v[e] + t, 0.f);
+  }
+  block_sum<1>(red, scratch);
+  if (threadIdx.x == 0) pooled[nc] = red[0] / (float)P;
+}
+
+static inline int norm_vec(int dtype, int vec) {
+  const int full = dtype == X3D_F32 ? 4 : 8;
+  return vec >= full ? full : 1;
+}
+
+extern "C" int x3d_tail_fwd(const void* c_raw, const float* c_scale_shift, const void* shortcut,
+                            const float* r_scale_shift, void* y, int N, int C, long long P, int dtype,
+                            void* stream) {
+  X3D_REQUIRE(c_raw && c_scale_shift && y && N > 0 && C > 0 && P > 0, "tail_fwd: bad args");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_fwd: bad dtype");
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = norm_vec(dtype, pick_vec(eb, P, c_raw, shortcut, y));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid = elem_grid(P, vec, N * C);
+#define ARGS(T) (const T*)c_raw, c_scale_shift, (const T*)shortcut, r_scale_shift, (T*)y, C, P
+  if (dtype == X3D_F32) {
+    if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((tail_fwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+  }
+#undef ARGS
+  X3D_LAUNCH_CHECK("tail_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const void* r_raw, double* sums_c,
+                            double* sums_r, int N, int C, long long P, int dtype, void* stream) {
+  X3D_REQUIRE(dy_g && y && c_raw && sums_c && N > 0 && C > 0 && P > 0, "tail_bwd: bad args");
+  X3D_REQUIRE(!r_raw || sums_r, "tail_bwd: sums_r required with r_raw");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_bwd: bad dtype");
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = norm_vec(dtype, pick_vec(eb, P, dy_g, y, c_raw, r_raw));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid = elem_grid(P, vec, N * C);
+#define ARGS(T) (T*)dy_g, (const T*)y, (const T*)c_raw, (const T*)r_raw, sums_c, sums_r, C, P
+  if (dtype == X3D_F32) {
+    if (vec == 4) hipLaunchKernelGGL((tail_bwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((tail_bwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((tail_bwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+  }
+#undef ARGS
+  X3D_LAUNCH_CHECK("tail_bwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const void* yraw,
+                                      const float* scale_shift, void* g, double* sums, int N, int C,
+                                      long long P, int dtype, void* stream) {
+  X3D_REQUIRE((dy != nullptr) != (dpool != nullptr), "relu_bn_bwd_reduce: exactly one of dy / dpool");
+  X3D_REQUIRE(yraw && scale_shift && g && sums && N > 0 && C > 0 && P > 0, "relu_bn_bwd_reduce: bad args");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "relu_bn_bwd_reduce: bad dtype");
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = norm_vec(dtype, pick_vec(eb, P, dy, yraw, g));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid = elem_grid(P, vec, N * C);
+#define ARGS(T) (const T*)dy, dpool, (const T*)yraw, scale_shift, (T*)g, sums, C, P
+  if (dtype == X3D_F32) {
+    if (vec == 4) hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+  }
+#undef ARGS
+  X3D_LAUNCH_CHECK("relu_bn_bwd_reduce");
+  return X3D_OK;
+}
+
+extern "C" int x3d_pool_fwd(const void* x_raw, const float* scale_shift, float* pooled, int N, int C,
+                            long long P, int dtype, void* stream) {
+  X3D_REQUIRE(x_raw && scale_shift && pooled && N > 0 && C > 0 && P > 0, "pool_fwd: bad args");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "pool_fwd: bad dtype");
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = norm_vec(dtype, pick_vec(eb, P, x_raw));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(N * C));
+#define ARGS(T) (const T*)x_raw, scale_shift, pooled, C, P
+  if (dtype == X3D_F32) {
+    if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((pool_fwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((pool_fwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((pool_fwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+  }
+#undef ARGS
+  X3D_LAUNCH_CHECK("pool_fwd");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// module boundary: NTHWC (reference) -> NCTHW (internal).  C is tiny (3), P is huge: one thread per
+// point reads C contiguous values and writes C planes (coalesced along P).
+// ------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void nthwc_to_ncthw_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int C, long long P) {
+  const int n = blockIdx.y;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const TS* s = src + ((long long)n * P + p) * C;
+  for (int c = 0; c < C; c++) dst[((long long)n * C + c) * P + p] = from_f<TD>(to_f<TS>(s[c]));
+}
+
+extern "C" int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C,
+                                  long long P, void* stream) {
+  X3D_REQUIRE(src && dst && N > 0 && C > 0 && P > 0, "nthwc_to_ncthw: bad args");
+  dim3 grid((unsigned)ceil_div_ll(P, 256), (unsigned)N);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == X3D_F32 && dst_dtype == X3D_F32)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, C, P);
+  else if (src_dtype == X3D_F32 && dst_dtype == X3D_BF16)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, bf16>), grid, dim3(256), 0, st, (const float*)src, (bf16*)dst, C, P);
+  else if (src_dtype == X3D_BF16 && dst_dtype == X3D_BF16)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)src, (bf16*)dst, C, P);
+  else if (src_dtype == X3D_BF16 && dst_dtype == X3D_F32)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, st, (const bf16*)src, (float*)dst, C, P);
+  else {
+    x3d_set_error("nthwc_to_ncthw: bad dtype");
+    return X3D_ERR_INVALID;
+  }
+  X3D_LAUNCH_CHECK("nthwc_to_ncthw");
+  return X3D_OK;
+}

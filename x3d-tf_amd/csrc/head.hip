@@ -1,0 +1,237 @@
+// Classification head on pooled vectors (reference model.py:95-111,119-127; loss train.py:104) and
+// the optimizer (train.py:89-92).  All fp32; sizes are [N <= a few hundred] x [432..2048] x [400].
+#include "common.h"
+
+// y[n][m] = act(sum_k xm[n][k]*w[m][k] + b[m]), xm = x * (mask ? mask*mask_scale : 1).
+// One wave per output feature m and tile of NTILE samples: lanes split K, coalesced on w[m][:] and x[n][:].
+#define DENSE_NT 8
+__global__ __launch_bounds__(64) void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                       float mask_scale, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* y, int act, int N, int K,
+                                                       int M) {
+  const int m = blockIdx.x, n0 = blockIdx.y * DENSE_NT, lane = threadIdx.x;
+  float acc[DENSE_NT];
+#pragma unroll
+  for (int i = 0; i < DENSE_NT; i++) acc[i] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = w[(long long)m * K + k];
+#pragma unroll
+    for (int i = 0; i < DENSE_NT; i++) {
+      const int n = n0 + i;
+      if (n < N) {
+        float xv = x[(long long)n * K + k];
+        if (mask) xv *= mask[(long long)n * K + k] * mask_scale;
+        acc[i] += wv * xv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DENSE_NT; i++) {
+    const float s = wave_sum(acc[i]);
+    const int n = n0 + i;
+    if (lane == 0 && n < N) {
+      float v = s + (b ? b[m] : 0.f);
+      if (act == X3D_ACT_RELU) v = fmaxf(v, 0.f);
+      y[(long long)n * M + m] = v;
+    }
+  }
+}
+
+// dx[n][k] = (sum_m dz[n][m]*w[m][k]) * (mask ? mask*scale : 1); dz = dy*[y>0] for ReLU
+__global__ __launch_bounds__(256) void dense_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           int act, const float* __restrict__ mask, float mask_scale,
+                                                           const float* __restrict__ w, float* dx, int N, int K, int M) {
+  extern __shared__ float dz[];  // [M]
+  const int n = blockIdx.y;
+  for (int m = threadIdx.x; m < M; m += 256) {
+    float d = dy[(long long)n * M + m];
+    if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
+    dz[m] = d;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int m = 0; m < M; m++) acc += dz[m] * w[(long long)m * K + k];
+  if (mask) acc *= mask[(long long)n * K + k] * mask_scale;
+  dx[(long long)n * K + k] = acc;
+}
+
+// dw[m][k] += sum_n dz[n][m]*xm[n][k] ; db[m] += sum_n dz[n][m]
+__global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           int act, const float* __restrict__ x,
+                                                           const float* __restrict__ mask, float mask_scale, float* dw,
+                                                           float* db, int N, int K, int M) {
+  const int m = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f, accb = 0.f;
+  for (int n = 0; n < N; n++) {
+    float d = dy[(long long)n * M + m];
+    if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
+    accb += d;
+    if (k < K) {
+      float xv = x[(long long)n * K + k];
+      if (mask) xv *= mask[(long long)n * K + k] * mask_scale;
+      acc += d * xv;
+    }
+  }
+  if (k < K) dw[(long long)m * K + k] += acc;
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) db[m] += accb;
+}
+
+extern "C" int x3d_dense_fwd(const float* x, const float* mask, float mask_scale, const float* w, const float* b,
+                             float* y, int act, int N, int K, int M, void* stream) {
+  X3D_REQUIRE(x && w && y && N > 0 && K > 0 && M > 0, "dense_fwd: bad args");
+  X3D_REQUIRE(act == X3D_ACT_NONE || act == X3D_ACT_RELU, "dense_fwd: act must be none/relu");
+  hipLaunchKernelGGL(dense_fwd_kernel, dim3(M, ceil_div(N, DENSE_NT)), dim3(64), 0, (hipStream_t)stream, x, mask,
+                     mask_scale, w, b, y, act, N, K, M);
+  X3D_LAUNCH_CHECK("dense_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dense_bwd(const float* dy, const float* y, int act, const float* x, const float* mask,
+                             float mask_scale, const float* w, float* dx, float* dw, float* db, int N, int K, int M,
+                             void* stream) {
+  X3D_REQUIRE(dy && x && w && dw && N > 0 && K > 0 && M > 0, "dense_bwd: bad args");
+  X3D_REQUIRE(act == X3D_ACT_NONE || (act == X3D_ACT_RELU && y), "dense_bwd: relu needs y");
+  X3D_REQUIRE((size_t)M * sizeof(float) <= 48 * 1024, "dense_bwd: M too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(dense_bwd_dx_kernel, dim3(ceil_div(K, 256), N), dim3(256), M * sizeof(float), st, dy, y, act,
+                       mask, mask_scale, w, dx, N, K, M);
+    X3D_LAUNCH_CHECK("dense_bwd_dx");
+  }
+  hipLaunchKernelGGL(dense_bwd_dw_kernel, dim3(ceil_div(K, 256), M), dim3(256), 0, st, dy, y, act, x, mask,
+                     mask_scale, dw, db, N, K, M);
+  X3D_LAUNCH_CHECK("dense_bwd_dw");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax + Keras sparse categorical cross-entropy on probabilities.  One block per sample.
+//   p = softmax(z);  q = clip(p, 1e-7, 1-1e-7);  L = -log q_y + log sum_j q_j          [TF-3p]
+//   dL/dp_j = [1e-7 <= p_j <= 1-1e-7] * (-[j==y]/q_y + 1/sum q);   dz = p * (dL/dp - sum_k p_k dL/dp_k)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                           const int* __restrict__ labels, float* probs,
+                                                           float* loss_rows, float* dlogits, float grad_scale, int M) {
+  __shared__ float scratch[8];
+  __shared__ float bc[2];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* z = logits + (long long)n * M;
+  float mx = -INFINITY;
+  for (int j = tid; j < M; j += 256) mx = fmaxf(mx, z[j]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) scratch[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+  __syncthreads();
+  float red[1] = {0.f};
+  for (int j = tid; j < M; j += 256) red[0] += expf(z[j] - mx);
+  block_sum<1>(red, scratch);
+  if (tid == 0) bc[0] = red[0];
+  __syncthreads();
+  const float inv = 1.f / bc[0];
+  __syncthreads();
+  const int label = labels ? labels[n] : -1;
+  float r2[2] = {0.f, 0.f};  // sum q, sum_k p_k*[in range]  (for the dz formula)
+  for (int j = tid; j < M; j += 256) {
+    const float p = expf(z[j] - mx) * inv;
+    probs[(long long)n * M + j] = p;
+    const float q = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+    r2[0] += q;
+    r2[1] += (p >= 1e-7f && p <= 1.f - 1e-7f) ? p : 0.f;
+  }
+  if (!labels) return;
+  block_sum<2>(r2, scratch);
+  if (tid == 0) { bc[0] = r2[0]; bc[1] = r2[1]; }
+  __syncthreads();
+  const float sumq = bc[0], sum_p_in = bc[1];
+  const float py = expf(z[label] - mx) * inv;
+  const float qy = fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f);
+  const bool y_in = (py >= 1e-7f && py <= 1.f - 1e-7f);
+  if (tid == 0 && loss_rows) loss_rows[n] = -logf(qy) + logf(sumq);
+  if (dlogits) {
+    // inner = sum_k p_k * dL/dp_k = sum_p_in / sumq - [y in range] * p_y / q_y
+    const float inner = sum_p_in / sumq - (y_in ? py / qy : 0.f);
+    for (int j = tid; j < M; j += 256) {
+      const float p = expf(z[j] - mx) * inv;
+      const bool in = (p >= 1e-7f && p <= 1.f - 1e-7f);
+      float dldp = in ? 1.f / sumq : 0.f;
+      if (j == label && in) dldp -= 1.f / qy;
+      dlogits[(long long)n * M + j] = grad_scale * p * (dldp - inner);
+    }
+  }
+}
+
+extern "C" int x3d_softmax_xent(const float* logits, const int* labels, float* probs, float* loss_rows,
+                                float* dlogits, float grad_scale, int N, int M, void* stream) {
+  X3D_REQUIRE(logits && probs && N > 0 && M > 0, "softmax_xent: bad args");
+  X3D_REQUIRE(labels || (!loss_rows && !dlogits), "softmax_xent: loss/grad need labels");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, labels, probs,
+                     loss_rows, dlogits, grad_scale, M);
+  X3D_LAUNCH_CHECK("softmax_xent");
+  return X3D_OK;
+}
+
+__global__ void view_mean_kernel(const float* __restrict__ probs, float* out, int views, int M) {
+  const int v = blockIdx.y;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float acc = 0.f;
+  for (int i = 0; i < views; i++) acc += probs[((long long)v * views + i) * M + m];
+  out[(long long)v * M + m] = acc / (float)views;
+}
+
+extern "C" int x3d_view_mean(const float* probs, float* out, int videos, int views, int M, void* stream) {
+  X3D_REQUIRE(probs && out && videos > 0 && views > 0 && M > 0, "view_mean: bad args");
+  hipLaunchKernelGGL(view_mean_kernel, dim3(ceil_div(M, 128), videos), dim3(128), 0, (hipStream_t)stream, probs, out,
+                     views, M);
+  X3D_LAUNCH_CHECK("view_mean");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SGD + Nesterov momentum + L2 (flat arrays)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ w, float* __restrict__ v,
+                                                           const float* __restrict__ g,
+                                                           const unsigned char* __restrict__ l2, float lr, float mom,
+                                                           float wd, float gscale, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i] * gscale;
+  const float wi = w[i];
+  if (l2 && l2[i]) gi += 2.f * wd * wi;
+  const float vi = mom * v[i] - lr * gi;
+  v[i] = vi;
+  w[i] = wi + mom * vi - lr * gi;
+}
+
+extern "C" int x3d_sgd_nesterov(float* w, float* v, const float* g, const unsigned char* l2_mask, float lr,
+                                float momentum, float weight_decay, float grad_scale, long long n, void* stream) {
+  X3D_REQUIRE(w && v && g && n > 0, "sgd_nesterov: bad args");
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     v, g, l2_mask, lr, momentum, weight_decay, grad_scale, n);
+  X3D_LAUNCH_CHECK("sgd_nesterov");
+  return X3D_OK;
+}
+
+__global__ __launch_bounds__(256) void l2_sumsq_kernel(const float* __restrict__ w,
+                                                       const unsigned char* __restrict__ l2, double* out, long long n) {
+  __shared__ float scratch[4];
+  float red[1] = {0.f};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    if (!l2 || l2[i]) red[0] += w[i] * w[i];
+  block_sum<1>(red, scratch);
+  if (threadIdx.x == 0) atomic_add_d(out, (double)red[0]);
+}
+
+extern "C" int x3d_l2_sumsq(const float* w, const unsigned char* l2_mask, double* out, long long n, void* stream) {
+  X3D_REQUIRE(w && out && n > 0, "l2_sumsq: bad args");
+  long long blocks = ceil_div_ll(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(l2_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, l2_mask, out, n);
+  X3D_LAUNCH_CHECK("l2_sumsq");
+  return X3D_OK;
+}

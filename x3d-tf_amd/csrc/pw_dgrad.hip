@@ -1,0 +1,41 @@
+// x3d_pw_dgrad: pointwise convolution data gradient (see pw_gemm.h)
+#include "pw_gemm.h"
+
+template <typename T>
+static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
+  switch (epi) {
+    case X3D_EPI_STORE: return pw_launch_vec<T, PRO_BNBWD, X3D_EPI_STORE>(a, vec, st);
+    case X3D_EPI_ADD: return pw_launch_vec<T, PRO_BNBWD, X3D_EPI_ADD>(a, vec, st);
+    case X3D_EPI_ADD_STRIDED: return pw_launch_vec<T, PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, vec, st);
+    case X3D_EPI_SWISH_BWD: return pw_launch_vec<T, PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, vec, st);
+  }
+  x3d_set_error("pw_dgrad: unknown epilogue %d", epi);
+  return X3D_ERR_INVALID;
+}
+
+extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
+  X3D_REQUIRE(d && d->g && d->w && d->dx, "pw_dgrad: null pointer");
+  X3D_REQUIRE(d->coef && d->yraw, "pw_dgrad: coef/yraw required (every conv on the path feeds a BN)");
+  X3D_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0 && d->H > 0 && d->W > 0,
+              "pw_dgrad: bad extents");
+  X3D_REQUIRE(d->dtype == X3D_F32 || d->dtype == X3D_BF16, "pw_dgrad: bad dtype");
+  if (d->epi == X3D_EPI_ADD || d->epi == X3D_EPI_ADD_STRIDED)
+    X3D_REQUIRE(d->add, "pw_dgrad: epilogue needs `add`");
+  if (d->epi == X3D_EPI_SWISH_BWD)
+    X3D_REQUIRE(d->braw && d->b_scale_shift && d->nc_sums, "pw_dgrad: SWISH_BWD needs braw/b_scale_shift/nc_sums");
+  PwGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = d->g; a.x2 = d->yraw; a.coef = d->coef;
+  a.w = d->w; a.wsk = d->Cin; a.wsm = 1;  // (k = co, m = ci) -> w[co*Cin + ci]
+  a.N = d->N; a.K = d->Cout; a.M = d->Cin;
+  a.stride = 1;
+  a.P = a.Pin = (long long)d->T * d->H * d->W;
+  a.y = d->dx; a.add = d->add; a.braw = d->braw; a.b_ss = d->b_scale_shift; a.egate = d->gate;
+  a.nc_sums = d->nc_sums; a.eH = d->H; a.eW = d->W;
+  const int eb = d->dtype == X3D_F32 ? 4 : 2;
+  const int vec = pick_vec(eb, a.P, d->g, d->yraw);
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == X3D_F32 ? pw_dgrad_dispatch<float>(a, d->epi, vec, st)
+                             : pw_dgrad_dispatch<bf16>(a, d->epi, vec, st);
+}
+

@@ -1,0 +1,32 @@
+// x3d_pw_fwd: pointwise convolution forward (see pw_gemm.h)
+#include "pw_gemm.h"
+
+extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
+  X3D_REQUIRE(f && f->x && f->w && f->y, "pw_fwd: null pointer");
+  X3D_REQUIRE(f->stride == 1 || f->stride == 2, "pw_fwd: stride must be 1 or 2");
+  X3D_REQUIRE(f->N > 0 && f->Cin > 0 && f->Cout > 0 && f->T > 0 && f->H > 0 && f->W > 0,
+              "pw_fwd: bad extents");
+  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "pw_fwd: bad dtype");
+  X3D_REQUIRE(!(f->stride > 1 && f->in_scale_shift), "pw_fwd: strided input takes no prologue");
+  PwGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = f->x; a.coef = f->in_scale_shift; a.gate = f->in_gate; a.act = f->in_act;
+  a.w = f->w; a.wsk = 1; a.wsm = f->Cin;  // (k = ci, m = co) -> w[co*Cin + ci]
+  a.N = f->N; a.K = f->Cin; a.M = f->Cout;
+  a.stride = f->stride; a.H = f->H; a.W = f->W;
+  a.Ho = ceil_div(f->H, f->stride); a.Wo = ceil_div(f->W, f->stride);
+  a.Pin = (long long)f->T * f->H * f->W;
+  a.P = (long long)f->T * a.Ho * a.Wo;
+  a.y = f->y; a.stats = f->stats;
+  hipStream_t st = (hipStream_t)stream;
+  const int eb = f->dtype == X3D_F32 ? 4 : 2;
+  const int vec = pick_vec(eb, a.P, f->x);
+  const bool pro = f->in_scale_shift != nullptr || f->in_gate != nullptr || f->in_act != X3D_ACT_NONE;
+  X3D_REQUIRE(!pro || f->in_scale_shift, "pw_fwd: gate/activation prologue needs in_scale_shift");
+  if (f->dtype == X3D_F32)
+    return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
+               : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
+  return pro ? pw_launch_vec<bf16, PRO_AFFINE, EPI_STATS>(a, vec, st)
+             : pw_launch_vec<bf16, PRO_NONE, EPI_STATS>(a, vec, st);
+}
+

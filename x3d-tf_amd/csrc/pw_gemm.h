@@ -1,0 +1,309 @@
+// Pointwise (1x1x1) convolutions as GEMMs over points on the MI355X matrix cores.
+//
+// NCTHW makes every sample a [C][P] row-major matrix with the P = T*H*W points contiguous, so
+//   forward  Y[n] = W   * f(X[n])        M = Cout, K = Cin , N = points
+//   dgrad    dX[n] = W^T * dYraw[n]      M = Cin , K = Cout, N = points
+//   wgrad    dW   += dYraw[n] * f(X[n])^T M = Cout, N = Cin , K = points
+// are im2col-free.  This file is the exact-fp32 path: v_mfma_f32_32x32x2_f32 takes ONE f32 per lane
+// per operand with lane = (k = lane>>5, row/col = lane&31), so the [k][32 points] operand is read
+// from an LDS tile whose rows are points-contiguous without any transpose, and the 32x32 result has
+// the point index on the lane (stores/loads in the epilogue touch 32 consecutive points per
+// half-wave).  Tiles are staged global -> registers -> (prologue transform) -> LDS once per element,
+// so the folded BN / SE gate / activation / BN-backward arithmetic runs once per element, not once
+// per MFMA operand read.
+#pragma once
+#include "common.h"
+
+enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_BNBWD = 2 };
+enum { EPI_STATS = 100 };  // forward epilogue: store raw + per-channel statistics
+
+struct PwGemmArgs {
+  // streamed operand  [N][K][Pin]
+  const void* x;
+  const void* x2;      // PRO_BNBWD: raw conv output
+  const float* coef;   // PRO_AFFINE: [K][2] ; PRO_BNBWD: [K][4]
+  const float* gate;   // PRO_AFFINE: [N][K] or null
+  int act;
+  // weights, element (k, m) at w[k*wsk + m*wsm]
+  const float* w;
+  int wsk, wsm;
+  int N, K, M;
+  long long P, Pin;
+  int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
+  int KC, nchunks, tiles_per_block;
+  // epilogue
+  void* y;
+  double* stats;       // EPI_STATS: [M][2]
+  const void* add;
+  const void* braw;
+  const float* b_ss;
+  const float* egate;
+  double* nc_sums;
+  int eH, eW;          // EPI_ADD_STRIDED: geometry of dx (H, W); add is at ceil(H/2) x ceil(W/2)
+};
+
+template <typename T, int VEC, int PRO, bool STRIDED>
+__device__ __forceinline__ void pw_load_vec(const PwGemmArgs& a, int n, int gk, long long p,
+                                            float (&v)[VEC]) {
+  const T* x = (const T*)a.x;
+  if constexpr (STRIDED) {
+    static_assert(VEC == 1, "strided gather is scalar");
+    long long hw = (long long)a.Ho * a.Wo;
+    long long t = p / hw;
+    int rem = (int)(p - t * hw);
+    int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+    v[0] = to_f<T>(x[((long long)n * a.K + gk) * a.Pin + src]);
+  } else {
+    VecIO<T, VEC>::load(x + ((long long)n * a.K + gk) * a.Pin + p, v);
+  }
+  if constexpr (PRO == PRO_AFFINE) {
+    float s = a.coef[gk * 2], t = a.coef[gk * 2 + 1];
+    float g = a.gate ? a.gate[(long long)n * a.K + gk] : 1.0f;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float u = (s * v[e] + t) * g;
+      if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
+      else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
+      v[e] = u;
+    }
+  } else if constexpr (PRO == PRO_BNBWD) {
+    float y2[VEC];
+    VecIO<T, VEC>::load((const T*)a.x2 + ((long long)n * a.K + gk) * a.Pin + p, y2);
+    float A = a.coef[gk * 4], B = a.coef[gk * 4 + 1], C = a.coef[gk * 4 + 2];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) v[e] = A * v[e] + B * y2[e] + C;
+  }
+}
+
+template <typename T, int VEC, int MT, int NT, int PRO, int EPI, bool STRIDED>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = MT * 32, BN = NT * 32;
+  constexpr int TPW = (MT * NT + 3) / 4;
+  constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
+  constexpr int BMP = BM + 1;      // odd W pitch: staging along k (stride BMP) is bank-conflict-free
+  float* Xs = smem;                // [KC][BN]   (16-B aligned for the vector stores)
+  float* Ws = smem + a.KC * BN;    // [KC][BMP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.y * BM;
+  const int tiles_per_n = (int)((a.P + BN - 1) / BN);
+  const int chunks_per_n = (tiles_per_n + a.tiles_per_block - 1) / a.tiles_per_block;
+  const int n = blockIdx.x / chunks_per_n;
+  const int chunk = blockIdx.x - n * chunks_per_n;
+  const int tile_begin = chunk * a.tiles_per_block;
+  const int tile_end = min(tile_begin + a.tiles_per_block, tiles_per_n);
+
+  f32x16 acc[TPW];
+  float st1[HAS_SUMS ? TPW : 1][16], st2[HAS_SUMS ? TPW : 1][16];
+  if constexpr (HAS_SUMS) {
+#pragma unroll
+    for (int s = 0; s < TPW; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) { st1[s][j] = 0.f; st2[s][j] = 0.f; }
+  }
+
+  auto stage_w = [&](int k0) {
+    // walk the weight matrix along its contiguous axis so the global reads coalesce
+    for (int i = tid; i < a.KC * BM; i += 256) {
+      int k, m;
+      if (a.wsk == 1) { m = i / a.KC; k = i - m * a.KC; }
+      else { k = i / BM; m = i - k * BM; }
+      int gk = k0 + k, gm = m0 + m;
+      Ws[k * BMP + m] = (gk < a.K && gm < a.M) ? a.w[(long long)gk * a.wsk + (long long)gm * a.wsm] : 0.f;
+    }
+  };
+  auto stage_x = [&](int k0, long long p0) {
+    constexpr int VPR = BN / VEC;  // vectors per row
+    for (int v = tid; v < a.KC * VPR; v += 256) {
+      int k = v / VPR, pv = v - k * VPR;
+      int gk = k0 + k;
+      long long p = p0 + (long long)pv * VEC;
+      float val[VEC];
+      if (gk < a.K && p < a.P) {
+        pw_load_vec<T, VEC, PRO, STRIDED>(a, n, gk, p, val);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = 0.f;
+      }
+      VecIO<float, VEC>::store(&Xs[k * BN + pv * VEC], val);
+    }
+  };
+
+  if (a.nchunks == 1) stage_w(0);
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const long long p0 = (long long)tile * BN;
+#pragma unroll
+    for (int s = 0; s < TPW; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+      const int k0 = kc * a.KC;
+      __syncthreads();  // every wave is done reading the previous tiles
+      if (a.nchunks > 1) stage_w(k0);
+      stage_x(k0, p0);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < TPW; s++) {
+        const int id = wid + 4 * s;
+        if (id < MT * NT) {
+          const int mt = id / NT, nt = id - mt * NT;
+          const float* wp = Ws + half * BMP + mt * 32 + r;
+          const float* xp = Xs + half * BN + nt * 32 + r;
+          for (int kk = 0; kk < a.KC; kk += 2) {
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[kk * BMP], xp[kk * BN], acc[s], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: D[row][col]: col = lane&31 (point), row = (j&3) + 8*(j>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      const int id = wid + 4 * s;
+      if (id < MT * NT) {
+        const int mt = id / NT, nt = id - mt * NT;
+        const long long p = p0 + nt * 32 + r;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+          const bool ok = (m < a.M) && (p < a.P);
+          float val = acc[s][j];
+          const long long o = ((long long)n * a.M + m) * a.P + p;
+          if constexpr (EPI == EPI_STATS) {
+            if (ok) {
+              ((T*)a.y)[o] = from_f<T>(val);
+              float vr = round_to<T>(val);
+              st1[s][j] += vr;
+              st2[s][j] += vr * vr;
+            }
+          } else if constexpr (EPI == X3D_EPI_STORE) {
+            if (ok) ((T*)a.y)[o] = from_f<T>(val);
+          } else if constexpr (EPI == X3D_EPI_ADD) {
+            if (ok) ((T*)a.y)[o] = from_f<T>(val + to_f<T>(((const T*)a.add)[o]));
+          } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
+            if (ok) {
+              const long long hw = (long long)a.eH * a.eW;
+              const long long t = p / hw;
+              const int rem = (int)(p - t * hw);
+              const int h = rem / a.eW, w = rem - h * a.eW;
+              if (((h | w) & 1) == 0) {
+                const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+                const long long T_ = a.P / hw;
+                const long long oa =
+                    ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
+                val += to_f<T>(((const T*)a.add)[oa]);
+              }
+              ((T*)a.y)[o] = from_f<T>(val);
+            }
+          } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+            if (ok) {
+              const float b = to_f<T>(((const T*)a.braw)[o]);
+              const float u = a.b_ss[m * 2] * b + a.b_ss[m * 2 + 1];
+              const float g = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+              const float dv = val * swish_grad_(u * g);
+              ((T*)a.y)[o] = from_f<T>(dv);
+              const float dvr = round_to<T>(dv);
+              st1[s][j] += dvr;
+              st2[s][j] += dvr * b;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (HAS_SUMS) {
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      const int id = wid + 4 * s;
+      if (id < MT * NT) {
+        const int mt = id / NT;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float s1 = half_wave_sum(st1[s][j]);
+          const float s2 = half_wave_sum(st2[s][j]);
+          const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+          if (r == 0 && m < a.M) {
+            if constexpr (EPI == EPI_STATS) {
+              if (a.stats) {
+                atomic_add_d(&a.stats[m * 2], (double)s1);
+                atomic_add_d(&a.stats[m * 2 + 1], (double)s2);
+              }
+            } else {
+              double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
+              atomic_add_d(d, (double)s1);
+              atomic_add_d(d + 1, (double)s2);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int MT, int NT, int PRO, int EPI, bool STRIDED>
+static int pw_launch_cfg(PwGemmArgs& a, hipStream_t st) {
+  constexpr int BM = MT * 32, BN = NT * 32;
+  const int Kpad = (a.K + 1) & ~1;
+  const size_t resident = (size_t)Kpad * (BM + 1 + BN) * sizeof(float);
+  if (resident <= 80 * 1024) {
+    a.KC = Kpad;
+    a.nchunks = 1;
+  } else {
+    a.KC = 64;
+    a.nchunks = ceil_div(a.K, 64);
+  }
+  const size_t lds = (size_t)a.KC * (BM + 1 + BN) * sizeof(float);
+  const int gy = ceil_div(a.M, BM);
+  const long long tiles_per_n = ceil_div_ll(a.P, BN);
+  const long long total = tiles_per_n * a.N * gy;
+  int tpb = (int)(total / 2048);
+  if (tpb < 1) tpb = 1;
+  if (tpb > 16) tpb = 16;
+  if (tpb > tiles_per_n) tpb = (int)tiles_per_n;
+  a.tiles_per_block = tpb;
+  const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
+  auto kern = pw_gemm_kernel<T, VEC, MT, NT, PRO, EPI, STRIDED>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_gemm");
+  return X3D_OK;
+}
+
+template <typename T, int VEC, int PRO, int EPI, bool STRIDED>
+static int pw_launch_tile(PwGemmArgs& a, hipStream_t st) {
+  if (a.M <= 32) return pw_launch_cfg<T, VEC, 1, 4, PRO, EPI, STRIDED>(a, st);
+  if (a.M <= 64) return pw_launch_cfg<T, VEC, 2, 2, PRO, EPI, STRIDED>(a, st);
+  if (a.M <= 96) return pw_launch_cfg<T, VEC, 3, 2, PRO, EPI, STRIDED>(a, st);
+  return pw_launch_cfg<T, VEC, 4, 2, PRO, EPI, STRIDED>(a, st);
+}
+
+template <typename T, int PRO, int EPI>
+static int pw_launch_vec(PwGemmArgs& a, int vec, hipStream_t st) {
+  constexpr int FULL = 16 / sizeof(T);
+  if (a.stride > 1) {
+    if constexpr (PRO == PRO_NONE && EPI == EPI_STATS)
+      return pw_launch_tile<T, 1, PRO, EPI, true>(a, st);
+    else {
+      x3d_set_error("pw: strided gather only in forward");
+      return X3D_ERR_INVALID;
+    }
+  }
+  if (vec >= FULL) return pw_launch_tile<T, FULL, PRO, EPI, false>(a, st);
+  return pw_launch_tile<T, 1, PRO, EPI, false>(a, st);
+}
+

@@ -1,0 +1,210 @@
+// x3d_pw_wgrad: pointwise convolution weight gradient on fp32-input MFMA
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: split over points, fp32 atomics into dw
+// ------------------------------------------------------------------------------------------------
+struct PwWgradArgs {
+  const void* g; const void* yraw; const float* coef;                 // dY operand (rows = Cout)
+  const void* x; const float* xcoef; const float* xgate; int xact;   // X operand (rows = Cin)
+  float* dw;
+  int N, Cout, Cin;
+  long long P, Pin;
+  int stride, H, W, Ho, Wo;
+  int mt_per_group;     // 32-row tiles of Cout handled by one blockIdx.y
+  int nt_total;         // 32-col tiles of Cin
+  int steps_per_block;  // 32-point steps per block
+};
+
+template <typename T, int VEC, int TPW, bool XPRO, bool STRIDED>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BP = 32, LP = 33;  // points per step, LDS pitch (odd: conflict-free row-strided reads)
+  const int rowsA = a.mt_per_group * 32, rowsB = a.nt_total * 32;
+  float* As = smem;                // [rowsA][LP]
+  float* Bs = smem + rowsA * LP;   // [rowsB][LP]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int co0 = blockIdx.y * rowsA;
+  const int steps_per_n = (int)((a.P + BP - 1) / BP);
+  const int chunks_per_n = (steps_per_n + a.steps_per_block - 1) / a.steps_per_block;
+  const int n = blockIdx.x / chunks_per_n;
+  const int chunk = blockIdx.x - n * chunks_per_n;
+  const int s_begin = chunk * a.steps_per_block;
+  const int s_end = min(s_begin + a.steps_per_block, steps_per_n);
+  const int mt_here = min(a.mt_per_group, (a.Cout - co0 + 31) / 32);
+  const int ntiles = mt_here * a.nt_total;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+
+  constexpr int VPR = BP / VEC;
+  for (int step = s_begin; step < s_end; ++step) {
+    const long long p0 = (long long)step * BP;
+    __syncthreads();
+    for (int v = tid; v < rowsA * VPR; v += 256) {
+      const int row = v / VPR, pv = v - row * VPR;
+      const int co = co0 + row;
+      const long long p = p0 + (long long)pv * VEC;
+      float val[VEC];
+      if (co < a.Cout && p < a.P) {
+        const long long o = ((long long)n * a.Cout + co) * a.P + p;
+        VecIO<T, VEC>::load((const T*)a.g + o, val);
+        if (a.coef) {
+          float y2[VEC];
+          VecIO<T, VEC>::load((const T*)a.yraw + o, y2);
+          const float A = a.coef[co * 4], B = a.coef[co * 4 + 1], C = a.coef[co * 4 + 2];
+#pragma unroll
+          for (int e = 0; e < VEC; e++) val[e] = A * val[e] + B * y2[e] + C;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) As[row * LP + pv * VEC + e] = val[e];
+    }
+    for (int v = tid; v < rowsB * VPR; v += 256) {
+      const int row = v / VPR, pv = v - row * VPR;
+      const long long p = p0 + (long long)pv * VEC;
+      float val[VEC];
+      if (row < a.Cin && p < a.P) {
+        if constexpr (STRIDED) {
+          const long long hw = (long long)a.Ho * a.Wo;
+          const long long t = p / hw;
+          const int rem = (int)(p - t * hw);
+          const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+          const long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+          val[0] = to_f<T>(((const T*)a.x)[((long long)n * a.Cin + row) * a.Pin + src]);
+        } else {
+          VecIO<T, VEC>::load((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p, val);
+        }
+        if constexpr (XPRO) {
+          const float s = a.xcoef[row * 2], t = a.xcoef[row * 2 + 1];
+          const float g = a.xgate ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) {
+            float u = (s * val[e] + t) * g;
+            if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
+            else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
+            val[e] = u;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) Bs[row * LP + pv * VEC + e] = val[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      const int id = wid + 4 * s;
+      if (id < ntiles) {
+        const int mt = id / a.nt_total, nt = id - mt * a.nt_total;
+        const float* ap = As + (mt * 32 + r) * LP + half;
+        const float* bp = Bs + (nt * 32 + r) * LP + half;
+#pragma unroll
+        for (int kk = 0; kk < BP; kk += 2)
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc[s], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    const int id = wid + 4 * s;
+    if (id < ntiles) {
+      const int mt = id / a.nt_total, nt = id - mt * a.nt_total;
+      const int ci = nt * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int co = co0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+      }
+    }
+  }
+}
+
+template <typename T, int VEC, int TPW, bool XPRO, bool STRIDED>
+static int pw_wgrad_launch(PwWgradArgs& a, hipStream_t st) {
+  const int mt_total = ceil_div(a.Cout, 32);
+  a.nt_total = ceil_div(a.Cin, 32);
+  int g = (4 * TPW) / a.nt_total;
+  if (g < 1) g = 1;
+  if (g > mt_total) g = mt_total;
+  a.mt_per_group = g;
+  const int gy = ceil_div(mt_total, g);
+  const long long steps_per_n = ceil_div_ll(a.P, 32);
+  long long total = steps_per_n * a.N;
+  int spb = (int)(total / 1024);
+  if (spb < 4) spb = 4;
+  if (spb > 64) spb = 64;
+  if (spb > steps_per_n) spb = (int)steps_per_n;
+  a.steps_per_block = spb;
+  const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
+  const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * 33 * sizeof(float);
+  auto kern = pw_wgrad_kernel<T, VEC, TPW, XPRO, STRIDED>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_wgrad");
+  return X3D_OK;
+}
+
+template <typename T, int VEC, bool XPRO, bool STRIDED>
+static int pw_wgrad_tpw(PwWgradArgs& a, hipStream_t st) {
+  const int nt = ceil_div(a.Cin, 32), mt = ceil_div(a.Cout, 32);
+  const int tiles = nt * mt;
+  if (tiles <= 4) return pw_wgrad_launch<T, VEC, 1, XPRO, STRIDED>(a, st);
+  if (tiles <= 8) return pw_wgrad_launch<T, VEC, 2, XPRO, STRIDED>(a, st);
+  if (tiles <= 16) return pw_wgrad_launch<T, VEC, 4, XPRO, STRIDED>(a, st);
+  return pw_wgrad_launch<T, VEC, 8, XPRO, STRIDED>(a, st);  // nt <= 32 checked by the caller
+}
+
+template <typename T>
+static int pw_wgrad_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
+  constexpr int FULL = 16 / sizeof(T);
+  if (a.stride > 1) {
+    if (xpro) { x3d_set_error("pw_wgrad: strided input takes no prologue"); return X3D_ERR_INVALID; }
+    return pw_wgrad_tpw<T, 1, false, true>(a, st);
+  }
+  if (vec >= FULL)
+    return xpro ? pw_wgrad_tpw<T, FULL, true, false>(a, st) : pw_wgrad_tpw<T, FULL, false, false>(a, st);
+  return xpro ? pw_wgrad_tpw<T, 1, true, false>(a, st) : pw_wgrad_tpw<T, 1, false, false>(a, st);
+}
+
+extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
+  X3D_REQUIRE(w && w->g && w->x && w->dw, "pw_wgrad: null pointer");
+  X3D_REQUIRE((w->coef == nullptr) == (w->yraw == nullptr), "pw_wgrad: coef and yraw go together");
+  X3D_REQUIRE(w->stride == 1 || w->stride == 2, "pw_wgrad: stride must be 1 or 2");
+  X3D_REQUIRE(w->N > 0 && w->Cin > 0 && w->Cout > 0 && w->T > 0 && w->H > 0 && w->W > 0,
+              "pw_wgrad: bad extents");
+  X3D_REQUIRE(w->dtype == X3D_F32 || w->dtype == X3D_BF16, "pw_wgrad: bad dtype");
+  X3D_REQUIRE(w->Cin <= 32 * 32, "pw_wgrad: Cin too large");
+  PwWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = w->g; a.yraw = w->yraw; a.coef = w->coef;
+  a.x = w->x; a.xcoef = w->in_scale_shift; a.xgate = w->in_gate; a.xact = w->in_act;
+  a.dw = w->dw; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
+  a.stride = w->stride; a.H = w->H; a.W = w->W;
+  a.Ho = ceil_div(w->H, w->stride); a.Wo = ceil_div(w->W, w->stride);
+  a.Pin = (long long)w->T * w->H * w->W;
+  a.P = (long long)w->T * a.Ho * a.Wo;
+  const bool xpro = w->in_scale_shift != nullptr;
+  X3D_REQUIRE(xpro || (!w->in_gate && w->in_act == X3D_ACT_NONE), "pw_wgrad: prologue needs in_scale_shift");
+  const int eb = w->dtype == X3D_F32 ? 4 : 2;
+  const int vec = pick_vec(eb, a.P, w->g, w->yraw, w->x);
+  hipStream_t st = (hipStream_t)stream;
+  return w->dtype == X3D_F32 ? pw_wgrad_dispatch<float>(a, vec, xpro, st)
+                             : pw_wgrad_dispatch<bf16>(a, vec, xpro, st);
+}

@@ -1,0 +1,140 @@
+// Squeeze-excite MLP (reference model.py:274-290,311-315) forward, and its backward fused with the
+// BatchNorm_b backward finalize.  These are per-sample GEMVs on [C] vectors (C <= 630): a handful of
+// microseconds; what matters is that they need NO extra pass over the activations -- the squeeze
+// comes out of the depthwise epilogue and the backward sums out of the pointwise dgrad epilogue.
+#include "common.h"
+
+#define SE_MAXC 1024
+#define SE_MAXW 64
+
+__global__ __launch_bounds__(256) void se_fwd_kernel(const double* __restrict__ pool_sums, double P,
+                                                     const float* __restrict__ ssb, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* gate, float* hidden,
+                                                     int C, int Wd) {
+  __shared__ float pooled[SE_MAXC];
+  __shared__ float hid[SE_MAXW];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int c = tid; c < C; c += 256)
+    pooled[c] = ssb[c * 2] * (float)(pool_sums[(long long)n * C + c] / P) + ssb[c * 2 + 1];
+  __syncthreads();
+  for (int j = wid; j < Wd; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w1[j * C + c] * pooled[c];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float h = fmaxf(acc + b1[j], 0.f);
+      hid[j] = h;
+      hidden[(long long)n * Wd + j] = h;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = b2[c];
+    for (int j = 0; j < Wd; j++) acc += w2[c * Wd + j] * hid[j];
+    gate[(long long)n * C + c] = sigmoidf_(acc);
+  }
+}
+
+extern "C" int x3d_se_fwd(const double* pool_sums, double P, const float* b_scale_shift, const float* w1,
+                          const float* b1, const float* w2, const float* b2, float* gate, float* hidden, int N,
+                          int C, int Wd, void* stream) {
+  X3D_REQUIRE(pool_sums && b_scale_shift && w1 && b1 && w2 && b2 && gate && hidden, "se_fwd: null pointer");
+  X3D_REQUIRE(N > 0 && C > 0 && C <= SE_MAXC && Wd > 0 && Wd <= SE_MAXW && P > 0, "se_fwd: bad extents");
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, pool_sums, P, b_scale_shift, w1,
+                     b1, w2, b2, gate, hidden, C, Wd);
+  X3D_LAUNCH_CHECK("se_fwd");
+  return X3D_OK;
+}
+
+// stage 1 (one block per sample): gradient through gate -> fc2 -> ReLU -> fc1 -> pooled
+__global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a) {
+  __shared__ float pooled[SE_MAXC];
+  __shared__ float dz2[SE_MAXC];
+  __shared__ float dz1[SE_MAXW];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int C = a.C, Wd = a.Wd;
+  for (int c = tid; c < C; c += 256) {
+    const float sb = a.b_scale_shift[c * 2], tb = a.b_scale_shift[c * 2 + 1];
+    const long long i = (long long)n * C + c;
+    pooled[c] = sb * (float)(a.pool_sums[i] / a.P) + tb;
+    // dgate = sum_p dv*u, u = sb*braw + tb
+    const float dgate = (float)((double)sb * a.nc_sums[i * 2 + 1] + (double)tb * a.nc_sums[i * 2]);
+    const float g = a.gate[i];
+    const float d = dgate * g * (1.f - g);
+    dz2[c] = d;
+    atomicAdd(&a.db2[c], d);
+    for (int j = 0; j < Wd; j++) atomicAdd(&a.dw2[c * Wd + j], d * a.hidden[(long long)n * Wd + j]);
+  }
+  __syncthreads();
+  for (int j = wid; j < Wd; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += a.w2[c * Wd + j] * dz2[c];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float d = a.hidden[(long long)n * Wd + j] > 0.f ? acc : 0.f;
+      dz1[j] = d;
+      atomicAdd(&a.db1[j], d);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float dp = 0.f;
+    for (int j = 0; j < Wd; j++) {
+      dp += a.w1[j * C + c] * dz1[j];
+      atomicAdd(&a.dw1[j * C + c], dz1[j] * pooled[c]);
+    }
+    a.scratch[(long long)n * C + c] = dp;  // d loss / d pooled[n][c]
+  }
+}
+
+// stage 2 (one thread per channel): BN_b backward over du = dv*gate + dpool/P, then per-(n,c) coefficients
+__global__ void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  const int C = a.C, N = a.N;
+  double sdu = 0.0, sdub = 0.0;
+  for (int n = 0; n < N; n++) {
+    const long long i = (long long)n * C + c;
+    const double g = has_se ? (double)a.gate[i] : 1.0;
+    const double dp = has_se ? (double)a.scratch[i] : 0.0;
+    sdu += g * a.nc_sums[i * 2] + dp;
+    sdub += g * a.nc_sums[i * 2 + 1] + (has_se ? dp / a.P * a.pool_sums[i] : 0.0);
+  }
+  const double count = (double)N * a.P;
+  const double mean = a.b_mean_invstd[c * 2], invstd = a.b_mean_invstd[c * 2 + 1];
+  const double dga = (sdub - mean * sdu) * invstd;
+  const double k1 = (double)a.gamma_b[c] * invstd;
+  const double B = -k1 * invstd * dga / count;
+  const double Cc = -k1 * sdu / count - B * mean;
+  a.dgamma_b[c] += (float)dga;
+  a.dbeta_b[c] += (float)sdu;
+  for (int n = 0; n < N; n++) {
+    const long long i = (long long)n * C + c;
+    const double g = has_se ? (double)a.gate[i] : 1.0;
+    const double dp = has_se ? (double)a.scratch[i] : 0.0;
+    float* o = a.coef_nc + i * 4;
+    o[0] = (float)(k1 * g);
+    o[1] = (float)B;
+    o[2] = (float)(Cc + k1 * dp / a.P);
+    o[3] = 0.f;
+  }
+}
+
+extern "C" int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream) {
+  X3D_REQUIRE(a && a->nc_sums && a->b_scale_shift && a->b_mean_invstd && a->gamma_b && a->dgamma_b &&
+                  a->dbeta_b && a->coef_nc, "se_bnb_bwd: null pointer");
+  X3D_REQUIRE(a->N > 0 && a->C > 0 && a->C <= SE_MAXC && a->P > 0, "se_bnb_bwd: bad extents");
+  const int has_se = a->w1 != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (has_se) {
+    X3D_REQUIRE(a->w2 && a->b1 && a->b2 && a->gate && a->hidden && a->pool_sums && a->dw1 && a->db1 && a->dw2 &&
+                    a->db2 && a->scratch, "se_bnb_bwd: SE pointers missing");
+    X3D_REQUIRE(a->Wd > 0 && a->Wd <= SE_MAXW, "se_bnb_bwd: bad SE width");
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(a->N), dim3(256), 0, st, *a);
+    X3D_LAUNCH_CHECK("se_bwd");
+  }
+  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(ceil_div(a->C, 64)), dim3(64), 0, st, *a, has_se);
+  X3D_LAUNCH_CHECK("bnb_bwd");
+  return X3D_OK;
+}

@@ -1,0 +1,347 @@
+// X3D stem (reference model.py:134-210): conv_s = 1x3x3 stride (1,2,2) conv with symmetric pad
+// (0,1,1), Cin=3 -> C1; conv_t = KTx1x1 temporal depthwise conv with pad (KT/2,0,0).  Cin = 3 and
+// K = 27 are not MFMA shapes in the forward direction; both are HBM-bound direct kernels.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// conv_s forward: one thread = one output position (t, ho, wo), all COUT channels in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         T* __restrict__ y, int Tn, int H, int W, int Ho, int Wo) {
+  const int n = blockIdx.z, t = blockIdx.y;
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= Ho * Wo) return;
+  const int ho = pos / Wo, wo = pos - ho * Wo;
+  float in[CIN][3][3];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ci++) {
+    const T* xp = x + (((long long)n * CIN + ci) * Tn + t) * H * W;
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++) {
+      const int hi = ho * 2 + kh - 1;
+#pragma unroll
+      for (int kw = 0; kw < 3; kw++) {
+        const int wi = wo * 2 + kw - 1;
+        in[ci][kh][kw] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? to_f<T>(xp[(long long)hi * W + wi]) : 0.f;
+      }
+    }
+  }
+  const long long oplane = (long long)Ho * Wo;
+  T* yp = y + (((long long)n * COUT) * Tn + t) * oplane + pos;
+#pragma unroll 4
+  for (int co = 0; co < COUT; co++) {
+    const float* wc = w + co * CIN * 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) acc += wc[ci * 9 + kh * 3 + kw] * in[ci][kh][kw];
+    yp[(long long)co * Tn * oplane] = from_f<T>(acc);
+  }
+}
+
+extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int Cin, int T, int H, int W,
+                              int Cout, int dtype, void* stream) {
+  X3D_REQUIRE(x && w && y && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_fwd: bad args");
+  X3D_REQUIRE(Cin == 3, "stem_s_fwd: Cin must be 3 (DATA.NUM_INPUT_CHANNELS)");
+  X3D_REQUIRE(Cout == 24 || Cout == 32 || Cout == 8 || Cout == 16, "stem_s_fwd: unsupported Cout %d", Cout);
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "stem_s_fwd: bad dtype");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  dim3 grid(ceil_div(Ho * Wo, 256), T, N);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(TT, CO) \
+  hipLaunchKernelGGL((stem_s_fwd_kernel<TT, 3, CO>), grid, dim3(256), 0, st, (const TT*)x, w, (TT*)y, T, H, W, Ho, Wo)
+#define BY_CO(TT)                      \
+  switch (Cout) {                      \
+    case 8: LAUNCH(TT, 8); break;      \
+    case 16: LAUNCH(TT, 16); break;    \
+    case 24: LAUNCH(TT, 24); break;    \
+    default: LAUNCH(TT, 32); break;    \
+  }
+  if (dtype == X3D_F32) { BY_CO(float) } else { BY_CO(bf16) }
+#undef BY_CO
+#undef LAUNCH
+  X3D_LAUNCH_CHECK("stem_s_fwd");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_s weight gradient on the matrix cores:  dW[co][tap] = sum_p dY[co][p] * im2col(x)[tap][p],
+// tap = (ci, kh, kw) -> 27 rows padded to 32, co <= 32 rows: ONE 32x32 fp32 MFMA tile with the
+// points as the K dimension.  The four waves of a workgroup split each 64-point step between them
+// and the partial tiles meet in the fp32 atomics on dw.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_s_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           float* dw, int Cin, int Cout, int Tn, int H, int W,
+                                                           int Ho, int Wo, int steps_per_block) {
+  constexpr int BP = 64, LP = 65;
+  __shared__ float As[32 * LP];  // dY  [co][p]
+  __shared__ float Bs[32 * LP];  // im2col [tap][p]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const long long P = (long long)Tn * Ho * Wo;
+  const int steps_per_n = (int)((P + BP - 1) / BP);
+  const int chunks_per_n = (steps_per_n + steps_per_block - 1) / steps_per_block;
+  const int n = blockIdx.x / chunks_per_n;
+  const int chunk = blockIdx.x - n * chunks_per_n;
+  const int s_begin = chunk * steps_per_block, s_end = min(s_begin + steps_per_block, steps_per_n);
+  const int ntap = Cin * 9;
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc[j] = 0.f;
+
+  for (int step = s_begin; step < s_end; ++step) {
+    const long long p0 = (long long)step * BP;
+    __syncthreads();
+    for (int v = tid; v < 32 * BP; v += 256) {
+      const int row = v / BP, pp = v - row * BP;
+      const long long p = p0 + pp;
+      float a = 0.f, b = 0.f;
+      if (p < P) {
+        if (row < Cout) a = to_f<T>(dy[((long long)n * Cout + row) * P + p]);
+        if (row < ntap) {
+          const int ci = row / 9, k = row - ci * 9, kh = k / 3, kw = k - kh * 3;
+          const long long hw = (long long)Ho * Wo;
+          const long long t = p / hw;
+          const int rem = (int)(p - t * hw);
+          const int ho = rem / Wo, wo = rem - ho * Wo;
+          const int hi = ho * 2 + kh - 1, wi = wo * 2 + kw - 1;
+          if (hi >= 0 && hi < H && wi >= 0 && wi < W)
+            b = to_f<T>(x[((((long long)n * Cin + ci) * Tn + t) * H + hi) * W + wi]);
+        }
+      }
+      As[row * LP + pp] = a;
+      Bs[row * LP + pp] = b;
+    }
+    __syncthreads();
+    const float* ap = As + r * LP + wid * 16 + half;
+    const float* bp = Bs + r * LP + wid * 16 + half;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+  }
+  // D[row = co][col = tap]
+  if (r < ntap) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int co = (j & 3) + 8 * (j >> 2) + 4 * half;
+      if (co < Cout) atomicAdd(&dw[co * ntap + r], acc[j]);
+    }
+  }
+}
+
+extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, int T, int H, int W,
+                                int Cout, int dtype, void* stream) {
+  X3D_REQUIRE(x && dy && dw && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_wgrad: bad args");
+  X3D_REQUIRE(Cin * 9 <= 32 && Cout <= 32, "stem_s_wgrad: needs Cin*9 <= 32 and Cout <= 32");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "stem_s_wgrad: bad dtype");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long P = (long long)T * Ho * Wo;
+  const long long steps_per_n = ceil_div_ll(P, 64);
+  int spb = (int)(steps_per_n * N / 2048);
+  if (spb < 2) spb = 2;
+  if (spb > 64) spb = 64;
+  if (spb > steps_per_n) spb = (int)steps_per_n;
+  const long long gx = ceil_div_ll(steps_per_n, spb) * N;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == X3D_F32)
+    hipLaunchKernelGGL((stem_s_wgrad_kernel<float>), dim3((unsigned)gx), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, spb);
+  else
+    hipLaunchKernelGGL((stem_s_wgrad_kernel<bf16>), dim3((unsigned)gx), dim3(256), 0, st, (const bf16*)x,
+                       (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, spb);
+  X3D_LAUNCH_CHECK("stem_s_wgrad");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_t: temporal depthwise conv, KT taps (KT odd, <= 7).  A thread owns VEC consecutive spatial
+// positions of one (n, c) plane stack and walks T with a rolling register window, so each element
+// is read once and written once.
+// ------------------------------------------------------------------------------------------------
+#define DWT_MAXK 7
+
+template <typename T, int VEC, int KT>
+__global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                      T* __restrict__ y, double* stats, int C, int Tn, long long HW) {
+  __shared__ float scratch[2 * 4];
+  const int nc = blockIdx.y, c = nc % C;
+  const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  constexpr int R = KT / 2;
+  float wk[KT];
+#pragma unroll
+  for (int k = 0; k < KT; k++) wk[k] = w[c * KT + k];
+  float red[2] = {0.f, 0.f};
+  if (q < HW) {
+    const T* xp = x + (long long)nc * Tn * HW + q;
+    T* yp = y + (long long)nc * Tn * HW + q;
+    float win[KT][VEC];  // win[k] = x[t + k - R]
+#pragma unroll
+    for (int k = 0; k < KT; k++)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) win[k][e] = 0.f;
+    // preload x[0 .. R-1] into win[R+1 .. KT-1] (they become win[R..] after the first shift)
+#pragma unroll
+    for (int k = 0; k < R; k++)
+      if (k < Tn) VecIO<T, VEC>::load(xp + (long long)k * HW, win[R + 1 + k]);
+    for (int t = 0; t < Tn; t++) {
+#pragma unroll
+      for (int k = 0; k < KT - 1; k++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) win[k][e] = win[k + 1][e];
+      if (t + R < Tn) {
+        VecIO<T, VEC>::load(xp + (long long)(t + R) * HW, win[KT - 1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) win[KT - 1][e] = 0.f;
+      }
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; k++) acc += wk[k] * win[k][e];
+        o[e] = acc;
+        const float vr = round_to<T>(acc);
+        red[0] += vr;
+        red[1] += vr * vr;
+      }
+      VecIO<T, VEC>::store(yp + (long long)t * HW, o);
+    }
+  }
+  if (stats) {
+    block_sum<2>(red, scratch);
+    if (threadIdx.x == 0) {
+      atomic_add_d(&stats[c * 2], (double)red[0]);
+      atomic_add_d(&stats[c * 2 + 1], (double)red[1]);
+    }
+  }
+}
+
+// backward: dY[t] = A*g[t] + B*yraw[t] + C ; dx[t] = sum_k w[k]*dY[t + R - k] ; dw[k] += sum dY[t]*x[t+k-R]
+template <typename T, int VEC, int KT>
+__global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ yraw,
+                                                      const float* __restrict__ coef, const T* __restrict__ x,
+                                                      const float* __restrict__ w, T* __restrict__ dx, float* dw,
+                                                      int C, int Tn, long long HW) {
+  __shared__ float scratch[KT * 4];
+  const int nc = blockIdx.y, c = nc % C;
+  const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  constexpr int R = KT / 2;
+  float wk[KT], dwk[KT];
+#pragma unroll
+  for (int k = 0; k < KT; k++) { wk[k] = w[c * KT + k]; dwk[k] = 0.f; }
+  const float A = coef[c * 4], B = coef[c * 4 + 1], Cc = coef[c * 4 + 2];
+  if (q < HW) {
+    const long long base = (long long)nc * Tn * HW + q;
+    // step tau brings in dY[tau] and x[tau]; then dx[tau-R] = sum_k w[k]*dY[tau-k] is complete and
+    // dY[tau-R] meets its whole x window x[tau-2R .. tau].
+    float dwin[KT][VEC], xwin[KT][VEC];  // dwin[k] = dY[tau - (KT-1) + k], same for xwin
+#pragma unroll
+    for (int k = 0; k < KT; k++)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { dwin[k][e] = 0.f; xwin[k][e] = 0.f; }
+    for (int tau = 0; tau < Tn + R; tau++) {
+#pragma unroll
+      for (int k = 0; k < KT - 1; k++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { dwin[k][e] = dwin[k + 1][e]; xwin[k][e] = xwin[k + 1][e]; }
+      if (tau < Tn) {
+        float gg[VEC], yy[VEC];
+        VecIO<T, VEC>::load(g + base + (long long)tau * HW, gg);
+        VecIO<T, VEC>::load(yraw + base + (long long)tau * HW, yy);
+        VecIO<T, VEC>::load(x + base + (long long)tau * HW, xwin[KT - 1]);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) dwin[KT - 1][e] = A * gg[e] + B * yy[e] + Cc;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { dwin[KT - 1][e] = 0.f; xwin[KT - 1][e] = 0.f; }
+      }
+      const int t = tau - R;
+      if (t >= 0) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          float acc = 0.f;
+          // dx[t] = sum_k w[k]*dY[t+R-k] = sum_k w[k]*dwin[KT-1-k]
+#pragma unroll
+          for (int k = 0; k < KT; k++) acc += wk[k] * dwin[KT - 1 - k][e];
+          o[e] = acc;
+          // dY[t] = dwin[KT-1-R]; x[t+k-R] = xwin[KT-1-2R+k] = xwin[k]
+#pragma unroll
+          for (int k = 0; k < KT; k++) dwk[k] += dwin[KT - 1 - R][e] * xwin[k][e];
+        }
+        VecIO<T, VEC>::store(dx + base + (long long)t * HW, o);
+      }
+    }
+  }
+  block_sum<KT>(dwk, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < KT; k++) atomicAdd(&dw[c * KT + k], dwk[k]);
+  }
+}
+
+template <typename T, int VEC>
+static int dwt_fwd_kt(const void* x, const float* w, void* y, double* stats, int NC, int C, int T_, long long HW,
+                      int KT, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div_ll(HW, 256ll * VEC), (unsigned)NC);
+  switch (KT) {
+    case 1: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 1>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
+    case 3: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 3>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
+    case 5: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 5>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
+    case 7: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 7>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
+    default: x3d_set_error("dwt_fwd: KT must be 1,3,5 or 7"); return X3D_ERR_INVALID;
+  }
+  X3D_LAUNCH_CHECK("dwt_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
+                           int KT, int dtype, void* stream) {
+  X3D_REQUIRE(x && w && y && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_fwd: bad args");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "dwt_fwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = pick_vec(eb, HW, x, y);
+  if (dtype == X3D_F32)
+    return vec >= 4 ? dwt_fwd_kt<float, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
+                    : dwt_fwd_kt<float, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
+  return vec >= 4 ? dwt_fwd_kt<bf16, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
+                  : dwt_fwd_kt<bf16, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
+}
+
+template <typename T, int VEC>
+static int dwt_bwd_kt(const void* g, const void* yraw, const float* coef, const void* x, const float* w, void* dx,
+                      float* dw, int NC, int C, int T_, long long HW, int KT, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div_ll(HW, 256ll * VEC), (unsigned)NC);
+#define L(K) hipLaunchKernelGGL((dwt_bwd_kernel<T, VEC, K>), grid, dim3(256), 0, st, (const T*)g, (const T*)yraw, coef, (const T*)x, w, (T*)dx, dw, C, T_, HW)
+  switch (KT) {
+    case 1: L(1); break;
+    case 3: L(3); break;
+    case 5: L(5); break;
+    case 7: L(7); break;
+    default: x3d_set_error("dwt_bwd: KT must be 1,3,5 or 7"); return X3D_ERR_INVALID;
+  }
+#undef L
+  X3D_LAUNCH_CHECK("dwt_bwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, const void* x, const float* w,
+                           void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream) {
+  X3D_REQUIRE(g && yraw && coef && x && w && dx && dw && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_bwd: bad args");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "dwt_bwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = pick_vec(eb, HW, g, yraw, x, dx);
+  if (dtype == X3D_F32)
+    return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                    : dwt_bwd_kt<float, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  return vec >= 2 ? dwt_bwd_kt<bf16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                  : dwt_bwd_kt<bf16, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+}

@@ -1,0 +1,154 @@
+"""ctypes binding of libx3d_hip.so (C ABI in include/x3d_hip.h).
+
+There is no fallback: if the library is missing or a call fails this raises.  torch is used only for
+device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx3d_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
+EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
+
+_vp, _i, _f, _d, _ll = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong
+
+
+class X3DHipError(RuntimeError):
+    pass
+
+
+class PwFwdArgs(C.Structure):
+    _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("stats", _vp), ("in_scale_shift", _vp),
+                ("in_gate", _vp), ("in_act", _i), ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i),
+                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
+
+
+class PwDgradArgs(C.Structure):
+    _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("w", _vp), ("dx", _vp), ("epi", _i),
+                ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
+                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+
+
+class PwWgradArgs(C.Structure):
+    _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("x", _vp), ("in_scale_shift", _vp),
+                ("in_gate", _vp), ("in_act", _i), ("dw", _vp), ("N", _i), ("Cin", _i), ("Cout", _i),
+                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
+
+
+class Dw3dFwdArgs(C.Structure):
+    _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("in_scale_shift", _vp), ("in_act", _i),
+                ("stats", _vp), ("pool", _vp), ("N", _i), ("C", _i), ("T", _i), ("H", _i), ("W", _i),
+                ("stride", _i), ("dtype", _i)]
+
+
+class Dw3dBwdArgs(C.Structure):
+    _fields_ = [("dv", _vp), ("braw", _vp), ("coef_nc", _vp), ("araw", _vp), ("a_scale_shift", _vp),
+                ("w", _vp), ("ga", _vp), ("a_sums", _vp), ("dw", _vp), ("N", _i), ("C", _i), ("T", _i),
+                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
+
+
+class SeBnbBwdArgs(C.Structure):
+    _fields_ = [("nc_sums", _vp), ("pool_sums", _vp), ("P", _d), ("b_scale_shift", _vp),
+                ("b_mean_invstd", _vp), ("gamma_b", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp),
+                ("b2", _vp), ("gate", _vp), ("hidden", _vp), ("dw1", _vp), ("db1", _vp), ("dw2", _vp),
+                ("db2", _vp), ("dgamma_b", _vp), ("dbeta_b", _vp), ("coef_nc", _vp), ("scratch", _vp),
+                ("N", _i), ("C", _i), ("Wd", _i)]
+
+
+_SIGS = {
+    "x3d_version": ([], _i),
+    "x3d_last_error": ([], C.c_char_p),
+    "x3d_stem_s_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_stem_s_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_dwt_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_bn_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
+    "x3d_bn_eval_coef": ([_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], _i),
+    "x3d_bn_bwd_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
+    "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),
+    "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
+    "x3d_dw3d_fwd": ([C.POINTER(Dw3dFwdArgs), _vp], _i),
+    "x3d_dw3d_bwd": ([C.POINTER(Dw3dBwdArgs), _vp], _i),
+    "x3d_se_fwd": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "x3d_se_bnb_bwd": ([C.POINTER(SeBnbBwdArgs), _vp], _i),
+    "x3d_tail_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_tail_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_relu_bn_bwd_reduce": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_pool_fwd": ([_vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_dense_fwd": ([_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "x3d_dense_bwd": ([_vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "x3d_softmax_xent": ([_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp], _i),
+    "x3d_view_mean": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "x3d_sgd_nesterov": ([_vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp], _i),
+    "x3d_l2_sumsq": ([_vp, _vp, _vp, _ll, _vp], _i),
+    "x3d_nthwc_to_ncthw": ([_vp, _i, _vp, _i, _i, _i, _ll, _vp], _i),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/x3d_hip.h declares (and this binding expects)."""
+    return sorted(_SIGS)
+
+
+def load(path=None):
+    """dlopen libx3d_hip.so and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise X3DHipError(
+            f"{p} not found: build it with `python x3d-tf_amd/build.py` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the X3D hot path.")
+    lib = C.CDLL(p)
+    for name, (argtypes, restype) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise X3DHipError(f"unsupported activation dtype {dt}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().x3d_last_error()
+        raise X3DHipError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    """Call a plain-argument entry point on the current stream."""
+    lib = load()
+    check(getattr(lib, name)(*args, stream_ptr()), name)
+
+
+def call_struct(name, struct):
+    lib = load()
+    check(getattr(lib, name)(C.byref(struct), stream_ptr()), name)

@@ -1,0 +1,767 @@
+"""``X3D(cfg)``: the reference's model surface (reference model.py:8-132) over hand-written HIP kernels.
+
+Same constructor argument (the config tree), same call signature (``model(input, training=False)``
+with a channels-last ``[N, T, H, W, 3]`` clip batch, fp32 probabilities out, views averaged at
+inference -- model.py:113-127), same attribute tree (``conv1.conv_s``, ``stages[i].stage[j].bottleneck.a``
+... -- the names the released checkpoints are keyed by), ``summary(input_shape)`` and
+``load_weights(path)``.  What is different is everything underneath: activations live in NCTHW, every
+op is a kernel from libx3d_hip.so, BatchNorm / ReLU / swish / SE scale never touch HBM as separate
+passes (they are folded into the prologue of the consuming conv and the epilogue of the producing
+one), and the backward pass is written out explicitly instead of taped.
+
+Execution model: for one (batch, clip shape, mode) a ``_Plan`` allocates every buffer once and records
+the kernel launches as pre-bound C calls; a step replays the list on the current HIP stream (and can
+be captured into a hipGraph with torch.cuda.CUDAGraph, since nothing allocates or synchronises).
+"""
+import ctypes as C
+import math
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip
+from .arch import Arch, BlockSpec, ParamSpec, block_prefix, build_arch, param_specs, same_pad, summary_rows
+from .hip import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_ADD, EPI_ADD_STRIDED, EPI_STORE, EPI_SWISH_BWD)
+from .params import init_params
+
+
+# ------------------------------------------------------------------------------------------------
+# thin layer objects: they own views of the flat parameter buffers and give the reference's
+# attribute paths something to resolve to.  No compute happens here.
+# ------------------------------------------------------------------------------------------------
+class _Layer:
+    def __init__(self, name):
+        self.name = name
+
+    def variables(self):
+        return {k: v for k, v in vars(self).items() if isinstance(v, torch.Tensor)}
+
+
+class Conv3D(_Layer):
+    def __init__(self, name, kernel, bias=None, **attrs):
+        super().__init__(name)
+        self.kernel = kernel
+        if bias is not None:
+            self.bias = bias
+        self.__dict__.update(attrs)
+
+
+class Dense(Conv3D):
+    pass
+
+
+class BatchNormalization(_Layer):
+    def __init__(self, name, gamma, beta, moving_mean, moving_variance, epsilon, momentum):
+        super().__init__(name)
+        self.gamma, self.beta = gamma, beta
+        self.moving_mean, self.moving_variance = moving_mean, moving_variance
+        self.epsilon, self.momentum = epsilon, momentum
+        self.axis = -1
+
+
+class Activation(_Layer):
+    def __init__(self, kind):
+        super().__init__(kind)
+        self.activation = kind
+
+
+class AdaptiveAvgPool3D(_Layer):
+    def __init__(self, name="pool"):
+        super().__init__(name)
+        self.out_shape = (1, 1, 1)
+
+
+class Dropout(_Layer):
+    def __init__(self, rate):
+        super().__init__("dropout")
+        self.rate = rate
+
+
+class X3D_Stem(_Layer):
+    pass
+
+
+class Bottleneck(_Layer):
+    pass
+
+
+class ResBlock(_Layer):
+    pass
+
+
+class ResStage(_Layer):
+    pass
+
+
+class _Sequential(list):
+    """K.Sequential stand-in: an indexable list of layers (``layer_with_weights-i`` order)."""
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+class _Plan:
+    """Buffers + recorded launches for one (N, T, H, W, training) configuration."""
+
+    def __init__(self, model, n, t, h, w, training):
+        self.model = model
+        self.key = (n, t, h, w, bool(training))
+        self.n, self.t, self.h, self.w, self.training = n, t, h, w, bool(training)
+        self.fwd: List = []
+        self.bwd: List = []
+        self.keep: List = []           # ctypes structs / tensors that must outlive the recording
+        self.lib = hip.load()
+        self._zero_chunks: List = []   # (numel) fp64 accumulators carved from one flat buffer
+        self._zero_views: List = []
+        self.bwd_stage_marks: Dict[int, int] = {}
+
+    # -- allocation ------------------------------------------------------------------------------
+    def act(self, *shape):
+        return torch.empty(shape, dtype=self.model.dtype, device=self.model.device)
+
+    def f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.model.device)
+
+    def acc64(self, *shape):
+        """fp64 accumulator zeroed at the start of every step (carved later from one flat buffer)."""
+        numel = 1
+        for s in shape:
+            numel *= s
+        self._zero_chunks.append((numel, shape))
+        return len(self._zero_chunks) - 1
+
+    def finalize_acc(self):
+        total = sum(c[0] for c in self._zero_chunks)
+        self.zero_buf = torch.zeros(max(total, 1), dtype=torch.float64, device=self.model.device)
+        off = 0
+        for numel, shape in self._zero_chunks:
+            self._zero_views.append(self.zero_buf[off:off + numel].view(shape))
+            off += numel
+
+    # -- recording -------------------------------------------------------------------------------
+    def rec(self, lst, name, *args):
+        fn = getattr(self.lib, name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                self.keep.append(a)
+                conv.append(a.data_ptr())
+            elif isinstance(a, C.Structure):
+                self.keep.append(a)
+                conv.append(C.byref(a))
+            else:
+                conv.append(a)
+        lst.append((name, fn, tuple(conv)))
+
+    def run(self, lst, start=0, stop=None):
+        s = torch.cuda.current_stream().cuda_stream
+        for name, fn, args in lst[start:stop]:
+            st = fn(*args, s)
+            if st != 0:
+                hip.check(st, name)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class X3D:
+    """Constructs the X3D model from the model configurations (reference model.py:8-111).
+
+    Args:
+        cfg: config tree (x3d_tf_amd.config.CfgNode or anything exposing the same attributes).
+        dtype: activation storage type on the GPU: torch.float32 or torch.bfloat16 (weights,
+            statistics and accumulation stay fp32).  The reference's only reduced-precision mode is
+            Keras mixed_float16 (utils.py:176-192); bf16 is this build's equivalent.
+        device: a CUDA/HIP device.  There is no CPU path.
+        seed: seed of the Glorot-uniform initialisation.
+    """
+
+    def __init__(self, cfg, dtype=torch.float32, device="cuda", seed: int = 0, in_channels: int = 3):
+        self.cfg = cfg
+        self.arch: Arch = build_arch(cfg)
+        self.num_classes = self.arch.num_classes
+        self._num_preds = self.arch.num_preds
+        self._bn_cfg = cfg.NETWORK.BN
+        self.dtype = dtype
+        self.in_channels = in_channels
+        hip.dtype_code(dtype)
+        if not torch.cuda.is_available():
+            raise hip.X3DHipError("X3D needs an MI355X: the HIP path has no CPU fallback")
+        self.device = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        hip.load()
+        self._plans: Dict = {}
+        self._build_params(seed)
+        self._build_layers()
+        self._dropout_mask_override = None
+        self.last_loss = None
+
+    # ---------------------------------------------------------------------------------------------
+    # parameters: one flat fp32 buffer (trainable first, then BN moving statistics), one flat
+    # gradient buffer and one flat momentum buffer -- a single optimizer launch and contiguous
+    # all-reduce buckets.
+    # ---------------------------------------------------------------------------------------------
+    def _build_params(self, seed):
+        specs = param_specs(self.arch, self.in_channels)
+        self.specs: Dict[str, ParamSpec] = {s.name: s for s in specs}
+        order = [s for s in specs if s.trainable] + [s for s in specs if not s.trainable]
+        init = init_params(self.arch, seed, self.in_channels)
+
+        def numel(s):
+            n = 1
+            for d in s.shape:
+                n *= d
+            return n
+
+        # pad every tensor to a multiple of 4 floats so views stay 16-byte aligned
+        self._offsets = {}
+        off = 0
+        for s in order:
+            self._offsets[s.name] = off
+            off += (numel(s) + 3) // 4 * 4
+            if s.trainable:
+                self.n_trainable_flat = off
+        self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(self.n_trainable_flat, dtype=torch.float32, device=self.device)
+        self.flat_velocity = torch.zeros(self.n_trainable_flat, dtype=torch.float32, device=self.device)
+        l2 = torch.zeros(self.n_trainable_flat, dtype=torch.uint8)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        for s in order:
+            o, n = self._offsets[s.name], numel(s)
+            self.params[s.name] = self.flat_params[o:o + n].view(s.shape)
+            self.params[s.name].copy_(init[s.name])
+            if s.trainable:
+                self.grads[s.name] = self.flat_grads[o:o + n].view(s.shape)
+                if s.l2:
+                    l2[o:o + n] = 1
+        self.l2_mask = l2.to(self.device)
+        self.param_order = [s.name for s in order]
+        self.n_params = sum(numel(s) for s in order)
+        self.n_trainable = sum(numel(s) for s in order if s.trainable)
+
+    def _bn(self, prefix):
+        p = self.params
+        return BatchNormalization(prefix, p[f"{prefix}/gamma"], p[f"{prefix}/beta"],
+                                  p[f"{prefix}/moving_mean"], p[f"{prefix}/moving_variance"],
+                                  self.arch.bn_eps, self.arch.bn_momentum)
+
+    def _build_layers(self):
+        p, a = self.params, self.arch
+        self.conv1 = X3D_Stem("conv_1")
+        self.conv1.conv_s = Conv3D("conv_s", p["conv1/conv_s/kernel"], kernel_size=(1, 3, 3), strides=(1, 2, 2))
+        self.conv1.conv_t = Conv3D("conv_t", p["conv1/conv_t/kernel"], kernel_size=(a.c1_temp_filter, 1, 1),
+                                   strides=(1, 1, 1), groups=a.c1)
+        self.conv1.bn = self._bn("conv1/bn")
+        self.conv1.relu = Activation("relu")
+        self.stages = []
+        for si, st in enumerate(a.stages):
+            stage = ResStage(f"res_stage_{si + 2}")
+            stage._inner_channels = st.inner
+            stage.stage = _Sequential()
+            for b in st.blocks:
+                pre = block_prefix(b)
+                q = f"{pre}/bottleneck"
+                rb = ResBlock(f"ResBlock_{b.global_index - 1}")
+                rb.in_channels, rb.inner_channels, rb.out_channels = b.cin, b.inner, b.cout
+                if b.has_shortcut_conv:
+                    rb.residual = Conv3D("residual", p[f"{pre}/residual/kernel"], kernel_size=(1, 1, 1),
+                                         strides=(1, b.stride, b.stride))
+                    rb.bn_r = self._bn(f"{pre}/bn_r")
+                bt = Bottleneck("bottleneck")
+                bt.block_index = b.global_index
+                bt.a = Conv3D("a", p[f"{q}/a/kernel"], kernel_size=(1, 1, 1), strides=(1, 1, 1))
+                bt.bn_a = self._bn(f"{q}/bn_a")
+                bt.relu = Activation("relu")
+                bt.b = Conv3D("b", p[f"{q}/b/kernel"], kernel_size=(3, 3, 3), strides=(1, b.stride, b.stride),
+                              groups=b.inner)
+                bt.bn_b = self._bn(f"{q}/bn_b")
+                bt.swish = Activation("swish")
+                if b.has_se:
+                    bt.se_pool = AdaptiveAvgPool3D("se_pool")
+                    bt.se_fc1 = Conv3D("se_fc1", p[f"{q}/se_fc1/kernel"], p[f"{q}/se_fc1/bias"])
+                    bt.se_fc2 = Conv3D("se_fc2", p[f"{q}/se_fc2/kernel"], p[f"{q}/se_fc2/bias"])
+                bt.c = Conv3D("c", p[f"{q}/c/kernel"], kernel_size=(1, 1, 1), strides=(1, 1, 1))
+                bt.bn_c = self._bn(f"{q}/bn_c")
+                rb.bottleneck = bt
+                rb.add_op = Activation("add")
+                rb.relu = Activation("relu")
+                stage.stage.append(rb)
+            self.stages.append(stage)
+        self.conv5 = _Sequential([
+            Conv3D("conv_5", p["conv5/layer_with_weights-0/kernel"], kernel_size=(1, 1, 1)),
+            self._bn("conv5/layer_with_weights-1"), Activation("relu")])
+        self.pool5 = AdaptiveAvgPool3D("pool_5")
+        self.fc1 = Conv3D("fc_1", p["fc1/kernel"], kernel_size=(1, 1, 1))
+        self.dropout = Dropout(a.dropout_rate)
+        self.fc2 = Dense("fc_2", p["fc2/kernel"], p["fc2/bias"])
+        self.softmax = Activation("softmax")
+
+    # ---------------------------------------------------------------------------------------------
+    def summary(self, input_shape, print_fn=print):
+        """Same table as the reference's ``X3D.summary`` (model.py:129-132, models/X3D-*/X3D_*.txt)."""
+        t, h, w, c = input_shape
+        rows = summary_rows(self.arch, t, h, w, c)
+        lines = ['Model: "X3D"', "_" * 65, f"{'Layer (type)':<29}{'Output Shape':<26}{'Param #':<10}", "=" * 65,
+                 f"{'input_1 (InputLayer)':<29}{str([(None, t, h, w, c)]):<26}{0:<10}", "_" * 65]
+        kinds = {"conv_1": "X3D_Stem", "conv_5": "Sequential", "pool_5": "AdaptiveAvgPool3D", "fc_1": "Conv3D",
+                 "dropout": "Dropout", "fc_2": "Dense"}
+        for name, shp, n in rows:
+            kind = kinds.get(name, "ResStage")
+            lines += [f"{name + ' (' + kind + ')':<29}{str((None,) + tuple(shp)):<26}{n:<10}", "_" * 65]
+        lines[-1] = "=" * 65
+        lines += [f"Total params: {self.n_params:,}", f"Trainable params: {self.n_trainable:,}",
+                  f"Non-trainable params: {self.n_params - self.n_trainable:,}", "_" * 65]
+        text = "\n".join(lines)
+        if print_fn:
+            print_fn(text)
+        return text
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.params if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for k, v in sd.items():
+            if k in self.params:
+                if tuple(v.shape) != tuple(self.params[k].shape):
+                    raise ValueError(f"{k}: shape {tuple(v.shape)} vs {tuple(self.params[k].shape)}")
+                self.params[k].copy_(v)
+            elif strict:
+                raise KeyError(f"unexpected parameter {k}")
+
+    def load_weights(self, path, expect_partial=True):
+        """Keras-style ``load_weights`` on a TF tensor-bundle checkpoint prefix or directory
+        (reference train.py:131-143, eval.py:78-81)."""
+        from .checkpoint import load_tf_checkpoint
+        return load_tf_checkpoint(self, path, expect_partial=expect_partial)
+
+    def save_weights(self, prefix):
+        from .checkpoint import save_tf_checkpoint
+        return save_tf_checkpoint(self, prefix)
+
+    # ---------------------------------------------------------------------------------------------
+    # plan construction
+    # ---------------------------------------------------------------------------------------------
+    def _plan(self, n, t, h, w, training) -> _Plan:
+        key = (n, t, h, w, bool(training))
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = self._make_plan(n, t, h, w, bool(training))
+            self._plans[key] = pl
+        return pl
+
+    def _make_plan(self, n, t, h, w, training) -> _Plan:
+        a, p = self.arch, self.params
+        pl = _Plan(self, n, t, h, w, training)
+        dt = hip.dtype_code(self.dtype)
+        eps, mom = a.bn_eps, a.bn_momentum
+        F = pl.fwd
+
+        class BNBuf:
+            pass
+
+        def bn_bufs(prefix, c):
+            b = BNBuf()
+            b.prefix, b.c = prefix, c
+            b.ss = pl.f32(c, 2)
+            b.mi = pl.f32(c, 2)
+            b.stats = pl.acc64(c, 2) if training else None
+            b.bsums = pl.acc64(c, 2) if training else None
+            b.coef = pl.f32(c, 4) if training else None
+            return b
+
+        def bn_finish(b, count):
+            """after the producer kernel: turn statistics (training) or moving stats (inference) into scale/shift"""
+            g, be = p[f"{b.prefix}/gamma"], p[f"{b.prefix}/beta"]
+            mm, mv = p[f"{b.prefix}/moving_mean"], p[f"{b.prefix}/moving_variance"]
+            if training:
+                pl.rec(F, "x3d_bn_finalize", ("acc", b.stats), float(count), g, be, mm, mv, float(eps), float(mom), 1,
+                       b.ss, b.mi, b.c)
+            else:
+                pl.rec(F, "x3d_bn_eval_coef", g, be, mm, mv, float(eps), b.ss, b.mi, b.c)
+
+        # ---- input + stem --------------------------------------------------------------------
+        pl.x_in = None  # bound at run time (NTHWC user tensor)
+        pl.x = pl.act(n, self.in_channels, t, h, w)
+        h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        pl.s_raw = pl.act(n, a.c1, t, h1, w1)
+        pl.t_raw = pl.act(n, a.c1, t, h1, w1)
+        pl.y0 = pl.act(n, a.c1, t, h1, w1)
+        pl.bn1 = bn_bufs("conv1/bn", a.c1)
+        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt)
+        pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.t_raw,
+               ("acc", pl.bn1.stats) if training else None, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
+        bn_finish(pl.bn1, n * t * h1 * w1)
+        pl.rec(F, "x3d_tail_fwd", pl.t_raw, pl.bn1.ss, None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
+
+        # ---- residual stages -------------------------------------------------------------------
+        x_cur, hh, ww = pl.y0, h1, w1
+        pl.blocks = []
+        for b in a.blocks:
+            pre = block_prefix(b)
+            q = f"{pre}/bottleneck"
+            ho, wo = same_pad(hh, 3, b.stride)[0], same_pad(ww, 3, b.stride)[0]
+            P_in, P_out = t * hh * ww, t * ho * wo
+
+            class B:
+                pass
+
+            B.spec, B.x, B.hh, B.ww, B.ho, B.wo = b, x_cur, hh, ww, ho, wo
+            B.a_raw = pl.act(n, b.inner, t, hh, ww)
+            B.b_raw = pl.act(n, b.inner, t, ho, wo)
+            B.c_raw = pl.act(n, b.cout, t, ho, wo)
+            B.y = pl.act(n, b.cout, t, ho, wo)
+            B.bn_a, B.bn_b, B.bn_c = bn_bufs(f"{q}/bn_a", b.inner), bn_bufs(f"{q}/bn_b", b.inner), bn_bufs(f"{q}/bn_c", b.cout)
+            B.pool = pl.acc64(n, b.inner) if b.has_se else None
+            B.gate = pl.f32(n, b.inner) if b.has_se else None
+            B.hidden = pl.f32(n, b.se_width) if b.has_se else None
+            # a: 1x1x1 on the (materialised, already activated) block input
+            sa = hip.PwFwdArgs(_p(x_cur), _p(p[f"{q}/a/kernel"]), _p(B.a_raw), None, None, None, ACT_NONE, n, b.cin,
+                               b.inner, t, hh, ww, 1, dt)
+            B.sa = sa
+            pl.rec(F, "x3d_pw_fwd", ("stats", sa, B.bn_a.stats))
+            bn_finish(B.bn_a, n * P_in)
+            # b: channelwise 3x3x3, BN_a + ReLU folded into the load, BN_b statistics + SE squeeze in the epilogue
+            sb = hip.Dw3dFwdArgs(_p(B.a_raw), _p(p[f"{q}/b/kernel"]), _p(B.b_raw), _p(B.bn_a.ss), ACT_RELU, None, None,
+                                 n, b.inner, t, hh, ww, b.stride, dt)
+            B.sb = sb
+            pl.rec(F, "x3d_dw3d_fwd", ("dwstats", sb, B.bn_b.stats, B.pool))
+            bn_finish(B.bn_b, n * P_out)
+            if b.has_se:
+                pl.rec(F, "x3d_se_fwd", ("acc", B.pool), float(P_out), B.bn_b.ss, p[f"{q}/se_fc1/kernel"],
+                       p[f"{q}/se_fc1/bias"], p[f"{q}/se_fc2/kernel"], p[f"{q}/se_fc2/bias"], B.gate, B.hidden, n,
+                       b.inner, b.se_width)
+            # c: 1x1x1 with BN_b * SE gate -> swish folded into the load
+            sc = hip.PwFwdArgs(_p(B.b_raw), _p(p[f"{q}/c/kernel"]), _p(B.c_raw), None, _p(B.bn_b.ss), _p(B.gate),
+                               ACT_SWISH, n, b.inner, b.cout, t, ho, wo, 1, dt)
+            B.sc = sc
+            pl.rec(F, "x3d_pw_fwd", ("stats", sc, B.bn_c.stats))
+            bn_finish(B.bn_c, n * P_out)
+            if b.has_shortcut_conv:
+                B.r_raw = pl.act(n, b.cout, t, ho, wo)
+                B.bn_r = bn_bufs(f"{pre}/bn_r", b.cout)
+                sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                   n, b.cin, b.cout, t, hh, ww, b.stride, dt)
+                B.sr = sr
+                pl.rec(F, "x3d_pw_fwd", ("stats", sr, B.bn_r.stats))
+                bn_finish(B.bn_r, n * P_out)
+                pl.rec(F, "x3d_tail_fwd", B.c_raw, B.bn_c.ss, B.r_raw, B.bn_r.ss, B.y, n, b.cout, P_out, dt)
+            else:
+                B.r_raw, B.bn_r = None, None
+                pl.rec(F, "x3d_tail_fwd", B.c_raw, B.bn_c.ss, x_cur, None, B.y, n, b.cout, P_out, dt)
+            pl.blocks.append(B)
+            x_cur, hh, ww = B.y, ho, wo
+
+        # ---- head ------------------------------------------------------------------------------
+        c_last, c5 = a.stages[-1].cout, a.conv5_out
+        P5 = t * hh * ww
+        pl.P5, pl.h5, pl.w5 = P5, hh, ww
+        pl.y_last = x_cur
+        pl.c5_raw = pl.act(n, c5, t, hh, ww)
+        pl.bn5 = bn_bufs("conv5/layer_with_weights-1", c5)
+        s5 = hip.PwFwdArgs(_p(x_cur), _p(p["conv5/layer_with_weights-0/kernel"]), _p(pl.c5_raw), None, None, None,
+                           ACT_NONE, n, c_last, c5, t, hh, ww, 1, dt)
+        pl.s5 = s5
+        pl.rec(F, "x3d_pw_fwd", ("stats", s5, pl.bn5.stats))
+        bn_finish(pl.bn5, n * P5)
+        pl.pooled = pl.f32(n, c5)
+        pl.h1 = pl.f32(n, a.fc1_out)
+        pl.logits = pl.f32(n, a.num_classes)
+        pl.probs = pl.f32(n, a.num_classes)
+        pl.rec(F, "x3d_pool_fwd", pl.c5_raw, pl.bn5.ss, pl.pooled, n, c5, P5, dt)
+        pl.rec(F, "x3d_dense_fwd", pl.pooled, None, 1.0, p["fc1/kernel"], None, pl.h1, ACT_RELU, n, c5, a.fc1_out)
+        use_drop = training and a.dropout_rate > 0
+        pl.drop_mask = pl.f32(n, a.fc1_out) if use_drop else None
+        pl.drop_scale = 1.0 / (1.0 - a.dropout_rate) if use_drop else 1.0
+        pl.rec(F, "x3d_dense_fwd", pl.h1, pl.drop_mask, float(pl.drop_scale), p["fc2/kernel"], p["fc2/bias"],
+               pl.logits, ACT_NONE, n, a.fc1_out, a.num_classes)
+        if training:
+            pl.labels = torch.zeros(n, dtype=torch.int32, device=self.device)
+            pl.loss_rows = pl.f32(n)
+            pl.dlogits = pl.f32(n, a.num_classes)
+            pl.grad_scale_slot = len(F)
+            pl.rec(F, "x3d_softmax_xent", pl.logits, pl.labels, pl.probs, pl.loss_rows, pl.dlogits, 1.0 / n, n,
+                   a.num_classes)
+            self._record_backward(pl)
+        else:
+            pl.rec(F, "x3d_softmax_xent", pl.logits, None, pl.probs, None, None, 1.0, n, a.num_classes)
+            if n % a.num_preds:
+                raise ValueError(f"inference batch {n} is not a multiple of views*crops={a.num_preds} "
+                                 "(reference model.py:125)")
+            pl.out = pl.f32(n // a.num_preds, a.num_classes)
+            pl.rec(F, "x3d_view_mean", pl.probs, pl.out, n // a.num_preds, a.num_preds, a.num_classes)
+
+        # resolve fp64 accumulator handles into pointers
+        pl.finalize_acc()
+        self._resolve(pl, pl.fwd)
+        self._resolve(pl, pl.bwd)
+        return pl
+
+    @staticmethod
+    def _resolve(pl: _Plan, lst):
+        """Replace ('acc', handle) / ('stats', struct, handle) placeholders with device pointers."""
+        for i, (name, fn, args) in enumerate(lst):
+            new = []
+            for a_ in args:
+                if isinstance(a_, tuple) and a_ and a_[0] == "acc":
+                    new.append(None if a_[1] is None else pl._zero_views[a_[1]].data_ptr())
+                elif isinstance(a_, tuple) and a_ and a_[0] == "stats":
+                    st = a_[1]
+                    st.stats = None if a_[2] is None else pl._zero_views[a_[2]].data_ptr()
+                    pl.keep.append(st)
+                    new.append(C.byref(st))
+                elif isinstance(a_, tuple) and a_ and a_[0] == "dwstats":
+                    st = a_[1]
+                    st.stats = None if a_[2] is None else pl._zero_views[a_[2]].data_ptr()
+                    st.pool = None if a_[3] is None else pl._zero_views[a_[3]].data_ptr()
+                    pl.keep.append(st)
+                    new.append(C.byref(st))
+                elif isinstance(a_, tuple) and a_ and a_[0] == "field":
+                    st = a_[1]
+                    for fname, handle in a_[2].items():
+                        setattr(st, fname, None if handle is None else pl._zero_views[handle].data_ptr())
+                    pl.keep.append(st)
+                    new.append(C.byref(st))
+                else:
+                    new.append(a_)
+            lst[i] = (name, fn, tuple(new))
+
+    # ---------------------------------------------------------------------------------------------
+    # backward: written out explicitly (the reference relies on Keras autodiff)
+    # ---------------------------------------------------------------------------------------------
+    def _record_backward(self, pl: _Plan):
+        a, p, g = self.arch, self.params, self.grads
+        n, t = pl.n, pl.t
+        dt = hip.dtype_code(self.dtype)
+        Bk = pl.bwd
+        c5 = a.conv5_out
+        # scratch shared by all blocks (sized for the largest user)
+        max_out = max([pl.y0.numel()] + [B.y.numel() for B in pl.blocks])
+        max_inner_out = max(B.b_raw.numel() for B in pl.blocks)
+        max_inner_in = max(B.a_raw.numel() for B in pl.blocks)
+        max_r = max([1] + [n * B.spec.cin * t * B.ho * B.wo for B in pl.blocks if B.spec.has_shortcut_conv])
+        max_nc = max(n * B.spec.inner for B in pl.blocks)
+        flat = lambda numel: torch.empty(numel, dtype=self.dtype, device=self.device)
+        pl.gbuf = [flat(max_out), flat(max_out)]
+        pl.dv = flat(max_inner_out)
+        pl.ga = flat(max_inner_in)
+        pl.rtmp = flat(max_r)
+        pl.coef_nc = pl.f32(max_nc * 4)
+        pl.se_scratch = pl.f32(max_nc)
+        pl.g5 = pl.act(*pl.c5_raw.shape)
+        pl.dh1 = pl.f32(n, a.fc1_out)
+        pl.dpooled = pl.f32(n, c5)
+        pl.ds = pl.act(*pl.s_raw.shape)
+
+        # ---- head ------------------------------------------------------------------------------
+        pl.rec(Bk, "x3d_dense_bwd", pl.dlogits, None, ACT_NONE, pl.h1, pl.drop_mask, float(pl.drop_scale),
+               p["fc2/kernel"], pl.dh1, g["fc2/kernel"], g["fc2/bias"], n, a.fc1_out, a.num_classes)
+        pl.rec(Bk, "x3d_dense_bwd", pl.dh1, pl.h1, ACT_RELU, pl.pooled, None, 1.0, p["fc1/kernel"], pl.dpooled,
+               g["fc1/kernel"], None, n, c5, a.fc1_out)
+        b5 = pl.bn5
+        pl.rec(Bk, "x3d_relu_bn_bwd_reduce", None, pl.dpooled, pl.c5_raw, b5.ss, pl.g5, ("acc", b5.bsums), n, c5,
+               pl.P5, dt)
+        pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b5.bsums), float(n * pl.P5), b5.mi, p[f"{b5.prefix}/gamma"],
+               b5.coef, g[f"{b5.prefix}/gamma"], g[f"{b5.prefix}/beta"], c5)
+        c_last = a.stages[-1].cout
+        w5 = hip.PwWgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(pl.y_last), None, None, ACT_NONE,
+                             _p(g["conv5/layer_with_weights-0/kernel"]), n, c_last, c5, t, pl.h5, pl.w5, 1, dt)
+        pl.rec(Bk, "x3d_pw_wgrad", w5)
+        cur = 0
+        dy = pl.gbuf[cur][:pl.y_last.numel()]
+        d5 = hip.PwDgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(p["conv5/layer_with_weights-0/kernel"]),
+                             _p(dy), EPI_STORE, None, None, None, None, None, n, c_last, c5, t, pl.h5, pl.w5, dt)
+        pl.rec(Bk, "x3d_pw_dgrad", d5)
+        pl.bwd_stage_marks[len(a.stages)] = len(Bk)   # head finished
+
+        # ---- residual blocks, last to first ----------------------------------------------------
+        for B in reversed(pl.blocks):
+            b: BlockSpec = B.spec
+            pre = block_prefix(b)
+            q = f"{pre}/bottleneck"
+            P_in, P_out = t * B.hh * B.ww, t * B.ho * B.wo
+            # dy -> g = dy*[y>0] in place, with the BN_c (and BN_r) backward sums
+            pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
+                   ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
+            gten = dy
+            pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_c.bsums), float(n * P_out), B.bn_c.mi, p[f"{q}/bn_c/gamma"],
+                   B.bn_c.coef, g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout)
+            # c
+            wc = hip.PwWgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate),
+                                 ACT_SWISH, _p(g[f"{q}/c/kernel"]), n, b.inner, b.cout, t, B.ho, B.wo, 1, dt)
+            pl.rec(Bk, "x3d_pw_wgrad", wc)
+            B.nc_sums = pl.acc64(n, b.inner, 2)
+            dvv = pl.dv[:B.b_raw.numel()]
+            dc = hip.PwDgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(p[f"{q}/c/kernel"]), _p(dvv),
+                                 EPI_SWISH_BWD, None, _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, n, b.inner,
+                                 b.cout, t, B.ho, B.wo, dt)
+            pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
+            # SE + BN_b backward from the per-(n,c) sums
+            se = hip.SeBnbBwdArgs(
+                None, None, float(P_out), _p(B.bn_b.ss), _p(B.bn_b.mi), _p(p[f"{q}/bn_b/gamma"]),
+                _p(p.get(f"{q}/se_fc1/kernel")), _p(p.get(f"{q}/se_fc1/bias")), _p(p.get(f"{q}/se_fc2/kernel")),
+                _p(p.get(f"{q}/se_fc2/bias")), _p(B.gate), _p(B.hidden), _p(g.get(f"{q}/se_fc1/kernel")),
+                _p(g.get(f"{q}/se_fc1/bias")), _p(g.get(f"{q}/se_fc2/kernel")), _p(g.get(f"{q}/se_fc2/bias")),
+                _p(g[f"{q}/bn_b/gamma"]), _p(g[f"{q}/bn_b/beta"]), _p(pl.coef_nc), _p(pl.se_scratch), n, b.inner,
+                b.se_width)
+            pl.rec(Bk, "x3d_se_bnb_bwd", ("field", se, {"nc_sums": B.nc_sums, "pool_sums": B.pool}))
+            # b (fused data + weight gradient), emits grad wrt BN_a output with the ReLU mask applied
+            gaa = pl.ga[:B.a_raw.numel()]
+            db = hip.Dw3dBwdArgs(_p(dvv), _p(B.b_raw), _p(pl.coef_nc), _p(B.a_raw), _p(B.bn_a.ss),
+                                 _p(p[f"{q}/b/kernel"]), _p(gaa), None, _p(g[f"{q}/b/kernel"]), n, b.inner, t, B.hh,
+                                 B.ww, b.stride, dt)
+            pl.rec(Bk, "x3d_dw3d_bwd", ("field", db, {"a_sums": B.bn_a.bsums}))
+            pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_a.bsums), float(n * P_in), B.bn_a.mi, p[f"{q}/bn_a/gamma"],
+                   B.bn_a.coef, g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
+            # a
+            wa = hip.PwWgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(B.x), None, None, ACT_NONE,
+                                 _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, 1, dt)
+            pl.rec(Bk, "x3d_pw_wgrad", wa)
+            nxt = pl.gbuf[1 - cur][:B.x.numel()]
+            if b.has_shortcut_conv:
+                pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_r.bsums), float(n * P_out), B.bn_r.mi,
+                       p[f"{pre}/bn_r/gamma"], B.bn_r.coef, g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
+                wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
+                                     _p(g[f"{pre}/residual/kernel"]), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
+                pl.rec(Bk, "x3d_pw_wgrad", wr)
+                rt = pl.rtmp[:n * b.cin * P_out]
+                dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(p[f"{pre}/residual/kernel"]), _p(rt),
+                                     EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
+                pl.rec(Bk, "x3d_pw_dgrad", dr)
+                da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt),
+                                     EPI_ADD_STRIDED if b.stride == 2 else EPI_ADD, _p(rt), None, None, None, None, n,
+                                     b.cin, b.inner, t, B.hh, B.ww, dt)
+            else:
+                da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt), EPI_ADD,
+                                     _p(gten), None, None, None, None, n, b.cin, b.inner, t, B.hh, B.ww, dt)
+            pl.rec(Bk, "x3d_pw_dgrad", da)
+            cur = 1 - cur
+            dy = nxt
+            if b.index == 0:
+                pl.bwd_stage_marks[b.stage] = len(Bk)   # every gradient of stages >= b.stage is final
+
+        # ---- stem ------------------------------------------------------------------------------
+        b1 = pl.bn1
+        P1 = t * pl.y0.shape[3] * pl.y0.shape[4]
+        pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, dy, ("acc", b1.bsums), n, a.c1, P1, dt)
+        pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b1.bsums), float(n * P1), b1.mi, p["conv1/bn/gamma"], b1.coef,
+               g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
+        pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
+               g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
+        pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
+               a.c1, dt)
+        pl.bwd_stage_marks[-1] = len(Bk)
+
+    # ---------------------------------------------------------------------------------------------
+    # execution
+    # ---------------------------------------------------------------------------------------------
+    def _bind_input(self, pl: _Plan, x):
+        if x.dim() != 5 or x.shape[-1] != self.in_channels:
+            raise ValueError(f"expected a channels-last clip batch [N, T, H, W, {self.in_channels}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            x = x.to(self.device, non_blocking=True)
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        n, t, h, w, c = x.shape
+        hip.call("x3d_nthwc_to_ncthw", x.data_ptr(), hip.dtype_code(x.dtype), pl.x.data_ptr(),
+                 hip.dtype_code(self.dtype), n, c, t * h * w)
+        pl._x_keepalive = x
+
+    def _draw_dropout(self, pl: _Plan):
+        if pl.drop_mask is None:
+            return
+        if self._dropout_mask_override is not None:
+            pl.drop_mask.copy_(self._dropout_mask_override.to(self.device, torch.float32))
+        else:
+            pl.drop_mask.bernoulli_(1.0 - self.arch.dropout_rate)
+
+    def set_dropout_mask(self, mask: Optional[torch.Tensor]):
+        """Fix the dropout keep-mask ([N, 2048] of 0/1) for reproducible parity tests; None = random."""
+        self._dropout_mask_override = mask
+
+    def __call__(self, input, training=False):
+        return self.call(input, training)
+
+    def call(self, input, training=False):
+        """Forward pass (reference model.py:113-127).  Returns fp32 probabilities: ``[N, classes]`` when
+        training, ``[N / (views*crops), classes]`` (view-averaged) otherwise."""
+        n, t, h, w, _ = input.shape
+        pl = self._plan(n, t, h, w, training)
+        self._bind_input(pl, input)
+        if training:
+            pl.zero_buf.zero_()
+            self._draw_dropout(pl)
+            # forward only: stop before the loss kernel (labels unknown); softmax without labels
+            pl.run(pl.fwd, 0, pl.grad_scale_slot)
+            hip.call("x3d_softmax_xent", pl.logits.data_ptr(), None, pl.probs.data_ptr(), None, None, 1.0, n,
+                     self.num_classes)
+            return pl.probs
+        pl.zero_buf.zero_()
+        pl.run(pl.fwd)
+        return pl.out
+
+    def forward_backward(self, input, labels, global_batch=None, on_stage_done=None):
+        """One training forward + backward.  Fills ``self.grads`` (data gradients only; the L2 term is
+        applied by the optimizer), updates BN moving statistics, returns the plan (loss_rows, probs).
+
+        global_batch: divisor of the loss mean (defaults to the local batch; data-parallel callers pass
+            world_size * local batch so that summing gradients over ranks gives the global mean).
+        on_stage_done(stage): called as soon as every gradient of ``stage`` (4 = head, 3..0 = stages,
+            -1 = stem) is final on the stream -- the hook gradient all-reduce buckets attach to.
+        """
+        n, t, h, w, _ = input.shape
+        pl = self._plan(n, t, h, w, True)
+        self._bind_input(pl, input)
+        pl.labels.copy_(labels.to(self.device, non_blocking=True).to(torch.int32))
+        pl.zero_buf.zero_()
+        self.flat_grads.zero_()
+        self._draw_dropout(pl)
+        gb = float(global_batch or n)
+        pl.run(pl.fwd, 0, pl.grad_scale_slot)
+        hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
+                 pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), 1.0 / gb, n, self.num_classes)
+        if on_stage_done is None:
+            pl.run(pl.bwd)
+        else:
+            marks = sorted(pl.bwd_stage_marks.items(), key=lambda kv: kv[1])
+            start = 0
+            for stage, stop in marks:
+                pl.run(pl.bwd, start, stop)
+                on_stage_done(stage)
+                start = stop
+        return pl
+
+    def regularization_loss(self):
+        """weight_decay * sum(w^2) over the L2-regularised kernels (reference model.py:47)."""
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        hip.call("x3d_l2_sumsq", self.flat_params.data_ptr(), self.l2_mask.data_ptr(), acc.data_ptr(),
+                 self.n_trainable_flat)
+        return acc * self.arch.weight_decay
+
+    def apply_sgd(self, lr, momentum=0.9, grad_scale=1.0):
+        """SGD(momentum, nesterov=True) + L2 (reference train.py:89-92, model.py:47), one launch."""
+        hip.call("x3d_sgd_nesterov", self.flat_params.data_ptr(), self.flat_velocity.data_ptr(),
+                 self.flat_grads.data_ptr(), self.l2_mask.data_ptr(), float(lr), float(momentum),
+                 float(self.arch.weight_decay), float(grad_scale), self.n_trainable_flat)
+
+    def grad_bucket(self, stage):
+        """Contiguous slice of the flat gradient buffer holding the gradients of one stage
+        (4 = conv5 + head, 0..3 = residual stages, -1 = stem)."""
+        names = [k for k in self.param_order if k in self.grads]
+        if stage == -1:
+            sel = [k for k in names if k.startswith("conv1/")]
+        elif stage == len(self.arch.stages):
+            sel = [k for k in names if k.startswith(("conv5/", "fc1/", "fc2/"))]
+        else:
+            sel = [k for k in names if k.startswith(f"stages/{stage}/")]
+        lo = self._offsets[sel[0]]
+        last = sel[-1]
+        hi = self._offsets[last] + (self.params[last].numel() + 3) // 4 * 4
+        return self.flat_grads[lo:hi]
+
+    def moving_stats_flat(self):
+        return self.flat_params[self.n_trainable_flat:]

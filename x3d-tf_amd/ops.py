@@ -1,0 +1,237 @@
+"""Tensor-level wrappers over the C ABI: shape inference + pointer plumbing, nothing else.
+
+Every function launches hand-written HIP kernels from libx3d_hip.so on the current stream.  Tensors
+are NCTHW activations (fp32 or bf16) and fp32 parameters / coefficient vectors, all on the GPU.
+"""
+import torch
+
+from . import hip
+from .hip import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_ADD, EPI_ADD_STRIDED, EPI_STORE,  # noqa: F401
+                  EPI_SWISH_BWD, ptr)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise hip.X3DHipError("x3d ops need GPU tensors (no CPU fallback)")
+            if not t.is_contiguous():
+                raise hip.X3DHipError("x3d ops need contiguous tensors")
+
+
+def _out_hw(h, w, stride):
+    return -(-h // stride), -(-w // stride)
+
+
+# ---- stem ---------------------------------------------------------------------------------------
+def stem_s_fwd(x, w, y=None):
+    _chk(x, w, y)
+    n, cin, t, h, ww = x.shape
+    cout = w.shape[0]
+    ho, wo = (h - 1) // 2 + 1, (ww - 1) // 2 + 1
+    if y is None:
+        y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
+    hip.call("x3d_stem_s_fwd", ptr(x), ptr(w), ptr(y), n, cin, t, h, ww, cout, hip.dtype_code(x.dtype))
+    return y
+
+
+def stem_s_wgrad(x, dy, dw):
+    _chk(x, dy, dw)
+    n, cin, t, h, ww = x.shape
+    hip.call("x3d_stem_s_wgrad", ptr(x), ptr(dy), ptr(dw), n, cin, t, h, ww, dy.shape[1],
+             hip.dtype_code(x.dtype))
+
+
+def dwt_fwd(x, w, y=None, stats=None):
+    _chk(x, w, y, stats)
+    n, c, t, h, ww = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    hip.call("x3d_dwt_fwd", ptr(x), ptr(w), ptr(y), ptr(stats), n, c, t, h * ww, w.shape[1],
+             hip.dtype_code(x.dtype))
+    return y
+
+
+def dwt_bwd(g, yraw, coef, x, w, dx, dw):
+    _chk(g, yraw, coef, x, w, dx, dw)
+    n, c, t, h, ww = x.shape
+    hip.call("x3d_dwt_bwd", ptr(g), ptr(yraw), ptr(coef), ptr(x), ptr(w), ptr(dx), ptr(dw), n, c, t,
+             h * ww, w.shape[1], hip.dtype_code(x.dtype))
+
+
+# ---- batch norm ---------------------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, ss, mi):
+    _chk(stats, gamma, beta, mmean, mvar, ss, mi)
+    hip.call("x3d_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar),
+             float(eps), float(momentum), int(update), ptr(ss), ptr(mi), gamma.numel())
+
+
+def bn_eval_coef(gamma, beta, mmean, mvar, eps, ss, mi):
+    _chk(gamma, beta, mmean, mvar, ss, mi)
+    hip.call("x3d_bn_eval_coef", ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar), float(eps), ptr(ss),
+             ptr(mi), gamma.numel())
+
+
+def bn_bwd_finalize(sums, count, mi, gamma, coef, dgamma, dbeta):
+    _chk(sums, mi, gamma, coef, dgamma, dbeta)
+    hip.call("x3d_bn_bwd_finalize", ptr(sums), float(count), ptr(mi), ptr(gamma), ptr(coef),
+             ptr(dgamma), ptr(dbeta), gamma.numel())
+
+
+# ---- pointwise ----------------------------------------------------------------------------------
+def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
+    _chk(x, w, y, stats, in_ss, in_gate)
+    n, cin, t, h, ww = x.shape
+    cout = w.shape[0]
+    ho, wo = _out_hw(h, ww, stride)
+    if y is None:
+        y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
+    a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(stats), ptr(in_ss), ptr(in_gate), in_act, n, cin,
+                      cout, t, h, ww, stride, hip.dtype_code(x.dtype))
+    hip.call_struct("x3d_pw_fwd", a)
+    return y
+
+
+def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None, gate=None,
+             nc_sums=None):
+    """g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]."""
+    _chk(g, yraw, coef, w, dx, add, braw, b_ss, gate, nc_sums)
+    n, cout, t, h, ww = g.shape
+    cin = w.shape[1]
+    a = hip.PwDgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w), ptr(dx), epi, ptr(add), ptr(braw),
+                        ptr(b_ss), ptr(gate), ptr(nc_sums), n, cin, cout, t, h, ww,
+                        hip.dtype_code(g.dtype))
+    hip.call_struct("x3d_pw_dgrad", a)
+    return dx
+
+
+def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
+    """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points."""
+    _chk(g, yraw, coef, x, dw, in_ss, in_gate)
+    n, cin, t, h, ww = x.shape
+    cout = g.shape[1]
+    a = hip.PwWgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(x), ptr(in_ss), ptr(in_gate), in_act, ptr(dw),
+                        n, cin, cout, t, h, ww, stride, hip.dtype_code(x.dtype))
+    hip.call_struct("x3d_pw_wgrad", a)
+
+
+# ---- depthwise ----------------------------------------------------------------------------------
+def dw3d_fwd(x, w, stride, y=None, in_ss=None, in_act=ACT_NONE, stats=None, pool=None):
+    _chk(x, w, y, in_ss, stats, pool)
+    n, c, t, h, ww = x.shape
+    ho, wo = _out_hw(h, ww, stride)
+    if y is None:
+        y = torch.empty((n, c, t, ho, wo), dtype=x.dtype, device=x.device)
+    a = hip.Dw3dFwdArgs(ptr(x), ptr(w), ptr(y), ptr(in_ss), in_act, ptr(stats), ptr(pool), n, c, t, h,
+                        ww, stride, hip.dtype_code(x.dtype))
+    hip.call_struct("x3d_dw3d_fwd", a)
+    return y
+
+
+def dw3d_bwd(dv, braw, coef_nc, araw, a_ss, w, ga, a_sums, dw, stride):
+    _chk(dv, braw, coef_nc, araw, a_ss, w, ga, a_sums, dw)
+    n, c, t, h, ww = araw.shape
+    a = hip.Dw3dBwdArgs(ptr(dv), ptr(braw), ptr(coef_nc), ptr(araw), ptr(a_ss), ptr(w), ptr(ga),
+                        ptr(a_sums), ptr(dw), n, c, t, h, ww, stride, hip.dtype_code(araw.dtype))
+    hip.call_struct("x3d_dw3d_bwd", a)
+
+
+# ---- squeeze-excite -----------------------------------------------------------------------------
+def se_fwd(pool_sums, P, b_ss, w1, b1, w2, b2, gate, hidden):
+    _chk(pool_sums, b_ss, w1, b1, w2, b2, gate, hidden)
+    n, c = gate.shape
+    hip.call("x3d_se_fwd", ptr(pool_sums), float(P), ptr(b_ss), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+             ptr(gate), ptr(hidden), n, c, w1.shape[0])
+
+
+def se_bnb_bwd(nc_sums, pool_sums, P, b_ss, b_mi, gamma_b, dgamma_b, dbeta_b, coef_nc, N, C,
+               w1=None, b1=None, w2=None, b2=None, gate=None, hidden=None, dw1=None, db1=None,
+               dw2=None, db2=None, scratch=None):
+    _chk(nc_sums, pool_sums, b_ss, b_mi, gamma_b, dgamma_b, dbeta_b, coef_nc, w1, b1, w2, b2, gate,
+         hidden, dw1, db1, dw2, db2, scratch)
+    a = hip.SeBnbBwdArgs(ptr(nc_sums), ptr(pool_sums), float(P), ptr(b_ss), ptr(b_mi), ptr(gamma_b),
+                         ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), ptr(hidden), ptr(dw1),
+                         ptr(db1), ptr(dw2), ptr(db2), ptr(dgamma_b), ptr(dbeta_b), ptr(coef_nc),
+                         ptr(scratch), N, C, 0 if w1 is None else w1.shape[0])
+    hip.call_struct("x3d_se_bnb_bwd", a)
+
+
+# ---- residual tail / reductions -----------------------------------------------------------------
+def tail_fwd(c_raw, c_ss, shortcut, r_ss, y):
+    _chk(c_raw, c_ss, shortcut, r_ss, y)
+    n, c = c_raw.shape[:2]
+    hip.call("x3d_tail_fwd", ptr(c_raw), ptr(c_ss), ptr(shortcut), ptr(r_ss), ptr(y), n, c,
+             c_raw[0, 0].numel(), hip.dtype_code(c_raw.dtype))
+    return y
+
+
+def tail_bwd(dy_g, y, c_raw, r_raw, sums_c, sums_r):
+    _chk(dy_g, y, c_raw, r_raw, sums_c, sums_r)
+    n, c = y.shape[:2]
+    hip.call("x3d_tail_bwd", ptr(dy_g), ptr(y), ptr(c_raw), ptr(r_raw), ptr(sums_c), ptr(sums_r), n, c,
+             y[0, 0].numel(), hip.dtype_code(y.dtype))
+
+
+def relu_bn_bwd_reduce(dy, dpool, yraw, ss, g, sums):
+    _chk(dy, dpool, yraw, ss, g, sums)
+    n, c = yraw.shape[:2]
+    hip.call("x3d_relu_bn_bwd_reduce", ptr(dy), ptr(dpool), ptr(yraw), ptr(ss), ptr(g), ptr(sums), n, c,
+             yraw[0, 0].numel(), hip.dtype_code(yraw.dtype))
+
+
+def pool_fwd(x_raw, ss, pooled):
+    _chk(x_raw, ss, pooled)
+    n, c = x_raw.shape[:2]
+    hip.call("x3d_pool_fwd", ptr(x_raw), ptr(ss), ptr(pooled), n, c, x_raw[0, 0].numel(),
+             hip.dtype_code(x_raw.dtype))
+    return pooled
+
+
+# ---- head ---------------------------------------------------------------------------------------
+def dense_fwd(x, w, b, y, act=ACT_NONE, mask=None, mask_scale=1.0):
+    _chk(x, w, b, y, mask)
+    n, k = x.shape
+    hip.call("x3d_dense_fwd", ptr(x), ptr(mask), float(mask_scale), ptr(w), ptr(b), ptr(y), act, n, k,
+             w.shape[0])
+    return y
+
+
+def dense_bwd(dy, y, act, x, w, dx, dw, db, mask=None, mask_scale=1.0):
+    _chk(dy, y, x, w, dx, dw, db, mask)
+    n, k = x.shape
+    hip.call("x3d_dense_bwd", ptr(dy), ptr(y), act, ptr(x), ptr(mask), float(mask_scale), ptr(w),
+             ptr(dx), ptr(dw), ptr(db), n, k, w.shape[0])
+
+
+def softmax_xent(logits, labels, probs, loss_rows=None, dlogits=None, grad_scale=1.0):
+    _chk(logits, labels, probs, loss_rows, dlogits)
+    n, m = logits.shape
+    hip.call("x3d_softmax_xent", ptr(logits), ptr(labels), ptr(probs), ptr(loss_rows), ptr(dlogits),
+             float(grad_scale), n, m)
+    return probs
+
+
+def view_mean(probs, out, views):
+    _chk(probs, out)
+    hip.call("x3d_view_mean", ptr(probs), ptr(out), out.shape[0], views, probs.shape[1])
+    return out
+
+
+def sgd_nesterov(w, v, g, l2_mask, lr, momentum, weight_decay, grad_scale=1.0):
+    _chk(w, v, g, l2_mask)
+    hip.call("x3d_sgd_nesterov", ptr(w), ptr(v), ptr(g), ptr(l2_mask), float(lr), float(momentum),
+             float(weight_decay), float(grad_scale), w.numel())
+
+
+def l2_sumsq(w, l2_mask, out):
+    _chk(w, l2_mask, out)
+    hip.call("x3d_l2_sumsq", ptr(w), ptr(l2_mask), ptr(out), w.numel())
+
+
+def nthwc_to_ncthw(src, dst):
+    """src [N,T,H,W,C] -> dst [N,C,T,H,W] (with dtype conversion)."""
+    _chk(src, dst)
+    n, t, h, w, c = src.shape
+    hip.call("x3d_nthwc_to_ncthw", ptr(src), hip.dtype_code(src.dtype), ptr(dst),
+             hip.dtype_code(dst.dtype), n, c, t * h * w)
+    return dst
