@@ -1,0 +1,237 @@
+"""Benchmark of the X3D hot path on MI355X: clips/sec of the fwd + bwd (+ SGD) train step.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched by
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``, one rank per GPU over
+RCCL).  W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides,
+max over ranks; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): X3D-M, clips of 16x224x224, batch
+64 per GPU, bf16 activation storage with fp32 arithmetic, synthetic N(0,1) clips (NTHWC at the module
+boundary, already resident in HBM), random-init weights; weak scaling (per-GPU batch fixed).
+
+Extra objects on the JSON line:
+  roofline      dominant depthwise kernel instantiation: algorithmic bytes per launch (SURVEY 8d:
+                fwd e*(X + Y), fused bwd e*(X + dY + dX)) / average launch duration measured with HIP
+                events on the launch stream inside the timed region; peak 8 TB/s.
+  kernels       the same figure for every depthwise instantiation launched.
+  roofline_model  BASELINE.md's whole-step figure: clips/s * 1.262 GB / 8 TB/s.
+  cpu_baseline  the CPU oracle (a PyTorch-CPU restatement of the reference graph; TensorFlow is not
+                available) timed on the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import x3d_tf_amd as x3d  # noqa: E402
+from x3d_tf_amd import arch as A  # noqa: E402
+from x3d_tf_amd import dist as xdist  # noqa: E402
+
+CLIP = {"XS": (4, 160), "S": (13, 160), "M": (16, 224), "L": (16, 312), "XL": (16, 312)}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 measured copy ceiling
+
+
+def dw_key(name, stride, w):
+    wo = -(-w // stride)
+    sw = 4 if wo >= 20 else (2 if wo >= 10 else 1)
+    if name == "x3d_dw3d_bwd" and stride == 2 and sw > 2:
+        sw = 2
+    kind = "dw3d_fwd_kernel" if name == "x3d_dw3d_fwd" else "dw3d_bwd_kernel"
+    return f"{kind}<bf16|f32, S={stride}, SW={sw}>"
+
+
+class KernelTimer:
+    """HIP events around selected launches of a plan (the launches run on torch's current stream, so
+    torch.cuda.Event records on the stream the kernels are launched on)."""
+
+    def __init__(self, model, pl, elem_bytes):
+        self.slots = []   # (list_name, index, key, algorithmic bytes)
+        for lname, lst, field in (("fwd", pl.fwd, "sb"), ("bwd", pl.bwd, None)):
+            for i, (name, fn, args) in enumerate(lst):
+                if name in ("x3d_dw3d_fwd", "x3d_dw3d_bwd"):
+                    self.slots.append([lname, i, name, None, None])
+        # shapes in launch order: forward walks blocks first->last, backward last->first
+        fwd_slots = [s for s in self.slots if s[0] == "fwd"]
+        bwd_slots = [s for s in self.slots if s[0] == "bwd"]
+        for s, B in zip(fwd_slots, pl.blocks):
+            b = B.spec
+            x_el = pl.n * b.inner * pl.t * B.hh * B.ww
+            y_el = pl.n * b.inner * pl.t * B.ho * B.wo
+            s[3], s[4] = dw_key(s[2], b.stride, B.ww), elem_bytes * (x_el + y_el)
+        for s, B in zip(bwd_slots, reversed(pl.blocks)):
+            b = B.spec
+            x_el = pl.n * b.inner * pl.t * B.hh * B.ww
+            y_el = pl.n * b.inner * pl.t * B.ho * B.wo
+            s[3], s[4] = dw_key(s[2], b.stride, B.ww), elem_bytes * (2 * x_el + y_el)
+        self.events = []
+
+    def wrap(self, pl):
+        """Monkey-patch the plan's run() so the selected launches are bracketed by events."""
+        marks = {(s[0], s[1]): s for s in self.slots}
+        timer = self
+        orig_fwd, orig_bwd = pl.fwd, pl.bwd
+
+        def run(lst, start=0, stop=None):
+            lname = "fwd" if lst is orig_fwd else "bwd"
+            stream = torch.cuda.current_stream().cuda_stream
+            stop_ = len(lst) if stop is None else stop
+            for i in range(start, stop_):
+                name, fn, args = lst[i]
+                slot = marks.get((lname, i)) if timer.enabled else None
+                if slot is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    st = fn(*args, stream)
+                    e1.record()
+                    timer.events.append((slot, e0, e1))
+                else:
+                    st = fn(*args, stream)
+                if st != 0:
+                    from x3d_tf_amd import hip
+                    hip.check(st, name)
+        self.enabled = False
+        pl.run = run
+
+    def summary(self):
+        agg = {}
+        for slot, e0, e1 in self.events:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(slot[3], dict(launches=0, ms=0.0, bytes=0))
+            a["launches"] += 1
+            a["ms"] += ms
+            a["bytes"] += slot[4]
+        out = []
+        for k, a in agg.items():
+            out.append(dict(kernel=k, launches=a["launches"], avg_us=1e3 * a["ms"] / a["launches"],
+                            total_ms=a["ms"], algorithmic_bytes_per_launch=a["bytes"] / a["launches"],
+                            achieved_GBs=a["bytes"] / (a["ms"] * 1e-3) / 1e9))
+        out.sort(key=lambda d: -d["total_ms"])
+        return out
+
+
+def cpu_baseline(variant, seconds_budget=25.0, batch=2):
+    """fwd + bwd of the CPU oracle on `batch` clips of the benchmark shape, all host cores."""
+    from oracle import x3d_oracle as O
+    from x3d_tf_amd.params import init_params
+    cfg = x3d.get_config(variant)
+    arch = x3d.build_arch(cfg)
+    t, s = CLIP[variant]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = init_params(arch, seed=0)
+    torch.manual_seed(0)
+    xin = torch.randn(batch, t, s, s, 3)
+    labels = torch.randint(0, arch.num_classes, (batch,))
+    O.train_step(p, xin, labels, arch, lr=0.01, apply_update=True)        # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(p, xin, labels, arch, lr=0.01, apply_update=True)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or done >= 10:
+            break
+    return dict(value=done * batch / el, unit="clips/s", cores=cores, kind="port",
+                sample=f"CPU restatement of the reference graph (PyTorch-CPU fp32 oracle; TensorFlow unavailable): "
+                       f"X3D-{variant} fwd+bwd+SGD, batch {batch} of {t}x{s}x{s}, 1 warm-up + {done} timed steps, "
+                       f"{cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variant", default="M")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    args = ap.parse_args()
+
+    rank, local_rank, world = xdist.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.train import Trainer
+    cfg = x3d.get_config(args.variant)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = X3D(cfg, dtype=dtype, device=device, seed=0)
+    trainer = Trainer(model, cfg)
+    t, s = CLIP[args.variant]
+    B = args.batch
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)
+    clips = torch.randn((B, t, s, s, 3), generator=g, device=device, dtype=torch.float32).to(dtype)
+    labels = torch.randint(0, model.num_classes, (B,), generator=g, device=device)
+    lr = cfg.TRAIN.WARMUP_LR
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        pl = trainer.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    timer = KernelTimer(model, pl, 2 if dtype == torch.bfloat16 else 4)
+    timer.wrap(pl)
+    timer.enabled = True
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pl = trainer.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = xdist.max_over_ranks(elapsed, device)
+    loss = float(trainer.loss(pl).item())
+
+    if rank == 0:
+        clips_s = args.steps * B * world / elapsed
+        kernels = timer.summary()
+        dom = kernels[0] if kernels else None
+        w = A.workload(model.arch, t, s, s)
+        eb = 2 if dtype == torch.bfloat16 else 4
+        step_bytes_per_clip = 3 * w["total_elements"] * eb
+        out = {
+            "metric": "clips/sec (fwd+bwd) X3D-%s %dx%d^2; depthwise HBM GB/s" % (args.variant, t, s),
+            "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"X3D-{args.variant} train step (fwd + bwd + Nesterov SGD), clips {t}x{s}x{s}x3, "
+                                   f"{args.dtype} activation storage / fp32 arithmetic, random-init weights",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "loss": loss,
+            "roofline": None if dom is None else {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "launches": dom["launches"], "avg_us": dom["avg_us"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+            "kernels": kernels,
+            "roofline_model": {"bound": "hbm", "achieved": clips_s / world * step_bytes_per_clip / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": clips_s / world * step_bytes_per_clip / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_clip": step_bytes_per_clip},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.variant, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

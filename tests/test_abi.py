@@ -1,0 +1,53 @@
+"""The C-ABI library loads on a CPU-only host and exports exactly what include/x3d_hip.h declares.
+(No compute calls here: there is no GPU in the build container.)"""
+import os
+import re
+
+from x3d_tf_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "x3d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(x3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == hip.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load()
+    for name in _declared():
+        assert getattr(lib, name) is not None
+    assert lib.x3d_version() >= 100
+    assert lib.x3d_last_error() is not None
+
+
+def test_struct_layouts_match_header():
+    """field order of the ctypes mirrors == field order of the C structs"""
+    text = open(os.path.join(ROOT, "include", "x3d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    pairs = {"x3d_pw_fwd_args": hip.PwFwdArgs, "x3d_pw_dgrad_args": hip.PwDgradArgs,
+             "x3d_pw_wgrad_args": hip.PwWgradArgs, "x3d_dw3d_fwd_args": hip.Dw3dFwdArgs,
+             "x3d_dw3d_bwd_args": hip.Dw3dBwdArgs, "x3d_se_bnb_bwd_args": hip.SeBnbBwdArgs}
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct \{([^{}]*)\} " + cname + ";", text).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = names[0].split()[-1].lstrip("*")
+            fields.append(first)
+            fields += [n.strip().lstrip("*") for n in names[1:]]
+        assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+    with pytest.raises(hip.X3DHipError):
+        hip.load(str(tmp_path / "libx3d_hip.so"))

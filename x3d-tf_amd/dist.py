@@ -1,0 +1,93 @@
+"""Data parallelism for the X3D train step: one process per GPU, RCCL over xGMI.
+
+The reference's only parallelism is tf.distribute.MirroredStrategy (reference utils.py:144-174): the
+global batch is split across in-process replicas, BatchNorm statistics stay per replica, gradients
+are all-reduced once per step and mirrored variables (BN moving statistics) are mean-aggregated.
+Here: rank r owns clips [r*B, (r+1)*B) of the global batch; there is no data-path collective in the
+forward or backward kernels; the flat gradient buffer is all-reduced in per-stage buckets, each
+launched as soon as the backward pass has finished that stage (deepest stage first), so the ring
+traffic (15 MB total for X3D-M; ~0.2 ms on a 153 GB/s xGMI link) hides under the remaining backward
+depthwise/pointwise kernels.  ``backend="nccl"`` is RCCL on ROCm; the same code runs on gloo/CPU
+tensors for the multi-process tests.
+"""
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE if WORLD_SIZE > 1."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Clips [lo, hi) of the global batch owned by `rank` (equal shards, as MirroredStrategy splits)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by {world} replicas")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class BucketReducer:
+    """Asynchronous sum all-reduce of a fixed list of buckets (contiguous slices of a flat buffer).
+
+    ``launch(i)`` enqueues bucket i behind everything already on the current stream and returns at
+    once (RCCL runs it on its own stream); ``finish()`` makes the current stream wait for all of them.
+    With world_size 1 both are no-ops.
+    """
+
+    def __init__(self, buckets: Sequence[torch.Tensor], group=None):
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._work: List = []
+
+    def launch(self, i: int):
+        if self.world == 1:
+            return
+        self._work.append(dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+
+def broadcast_(tensors: Sequence[torch.Tensor], src: int = 0, group=None):
+    """Make every replica start from rank `src`'s values (mirrored-variable initialisation)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=group)
+
+
+def mean_(t: torch.Tensor, group=None):
+    """In-place mean over replicas (mirrored-variable MEAN aggregation of BN moving statistics) [TF-3p]."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -583,6 +583,7 @@ class X3D:
             pre = block_prefix(b)
             q = f"{pre}/bottleneck"
             P_in, P_out = t * B.hh * B.ww, t * B.ho * B.wo
+            B.bwd_start, B.dy_view = len(Bk), dy.view(B.y.shape)
             # dy -> g = dy*[y>0] in place, with the BN_c (and BN_r) backward sums
             pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
                    ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
@@ -639,6 +640,7 @@ class X3D:
                                      _p(gten), None, None, None, None, n, b.cin, b.inner, t, B.hh, B.ww, dt)
             pl.rec(Bk, "x3d_pw_dgrad", da)
             cur = 1 - cur
+            B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt
             if b.index == 0:
                 pl.bwd_stage_marks[b.stage] = len(Bk)   # every gradient of stages >= b.stage is final

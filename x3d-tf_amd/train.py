@@ -1,0 +1,63 @@
+"""The train step the reference compiles with Keras (reference train.py:85-125): SGD with Nesterov
+momentum, SparseCategoricalCrossentropy on the model's probabilities + L2 regularisation, per-epoch
+warm-up/cosine learning-rate schedule -- as an explicit step loop over the HIP model, data-parallel
+over RCCL when launched with torchrun.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import dist as xdist
+
+
+def lr_schedule(epoch, cfg):
+    """reference train.py:114-125: linear warm-up while epoch <= WARMUP_EPOCHS, then half-cosine."""
+    tr = cfg.TRAIN
+    if epoch > tr.WARMUP_EPOCHS:
+        return tr.BASE_LR * (0.5 * (math.cos(math.pi * (epoch / tr.EPOCHS)) + 1))
+    return tr.WARMUP_LR + epoch * (tr.BASE_LR - tr.WARMUP_LR) / tr.WARMUP_EPOCHS
+
+
+class Trainer:
+    """fwd + bwd + gradient all-reduce + optimizer for one replica.
+
+    model: x3d_tf_amd.model.X3D.  The process group (if any) must already be initialised; every
+    replica is given rank 0's initial variables, as variables created under MirroredStrategy are.
+    """
+
+    def __init__(self, model, cfg, momentum: Optional[float] = None, sync_moving_stats: bool = True, group=None):
+        if cfg.TRAIN.OPTIMIZER.lower() != "sgd":
+            raise NotImplementedError(f"{cfg.TRAIN.OPTIMIZER} not supported")   # reference train.py:97
+        self.model, self.cfg, self.group = model, cfg, group
+        self.momentum = cfg.TRAIN.MOMENTUM if momentum is None else momentum
+        self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
+        self.sync_moving_stats = sync_moving_stats and self.world > 1
+        n_st = len(model.arch.stages)
+        # bucket order = order in which the backward pass finishes them: head, stage 3..0, stem
+        self.stage_order = [n_st] + list(range(n_st - 1, -1, -1)) + [-1]
+        self.reducer = xdist.BucketReducer([model.grad_bucket(s) for s in self.stage_order], group)
+        self._slot = {s: i for i, s in enumerate(self.stage_order)}
+        xdist.broadcast_([model.flat_params, model.flat_velocity], 0, group)
+        self.epoch = 0
+
+    def step(self, clips, labels, lr: Optional[float] = None):
+        """clips: this replica's shard [B, T, H, W, 3]; labels [B].  Returns the plan (loss_rows, probs)."""
+        m = self.model
+        n = clips.shape[0]
+        if lr is None:
+            lr = lr_schedule(self.epoch, self.cfg)
+        hook = (lambda stage: self.reducer.launch(self._slot[stage])) if self.world > 1 else None
+        pl = m.forward_backward(clips, labels, global_batch=n * self.world, on_stage_done=hook)
+        self.reducer.finish()
+        if self.sync_moving_stats:
+            xdist.mean_(m.moving_stats_flat(), self.group)
+        m.apply_sgd(lr, self.momentum)
+        return pl
+
+    def loss(self, pl):
+        """global-batch mean cross-entropy + L2 term (what Keras reports as `loss`)."""
+        ce = pl.loss_rows.sum() / (pl.n * self.world)
+        if self.world > 1:
+            torch.distributed.all_reduce(ce, group=self.group)
+        return ce + self.model.regularization_loss().float().squeeze()
