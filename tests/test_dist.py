@@ -1,0 +1,128 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  The oracle stands in for the per-replica compute, the
+product's own sharding / bucketed all-reduce / mirrored-variable code (x3d_tf_amd.dist) does the exchange.
+Expected semantics (reference utils.py:160-167, MirroredStrategy): each replica normalises with ITS shard's
+batch statistics; gradients of the global-mean loss are summed over replicas; moving statistics are averaged."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    import x3d_tf_amd as x
+    from x3d_tf_amd.params import init_params, randomize_bn_
+    cfg = x.get_config("XS")
+    arch = x.build_arch(cfg)
+    params = randomize_bn_(init_params(arch, seed=3), seed=4)
+    torch.manual_seed(7)
+    clips = torch.randn(4, 4, 32, 32, 3)
+    labels = torch.randint(0, 400, (4,))
+    mask = torch.ones(4, 2048)
+    return cfg, arch, params, clips, labels, mask
+
+
+def _flat_layout(arch, params):
+    """trainable tensors grouped into the trainer's buckets: head, stage 3..0, stem"""
+    from x3d_tf_amd import arch as A
+    names = [s.name for s in A.param_specs(arch) if s.trainable]
+    groups = [[k for k in names if k.startswith(("conv5/", "fc1/", "fc2/"))]]
+    for st in range(len(arch.stages) - 1, -1, -1):
+        groups.append([k for k in names if k.startswith(f"stages/{st}/")])
+    groups.append([k for k in names if k.startswith("conv1/")])
+    assert sum(len(g) for g in groups) == len(names)
+    return groups
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from x3d_tf_amd import dist as xd
+    from oracle import x3d_oracle as O
+    r, lr_, w = xd.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    cfg, arch, params, clips, labels, mask = _problem()
+    # every replica starts from rank 0's variables
+    if rank != 0:
+        for v in params.values():
+            v.add_(1.0)
+    xd.broadcast_(list(params.values()), 0)
+    lo, hi = xd.shard_range(clips.shape[0], rank, world)
+    res = O.train_step(params, clips[lo:hi], labels[lo:hi], arch, lr=None, dropout_mask=mask[lo:hi],
+                       apply_update=False)
+    # loss is the mean over the LOCAL shard; divide by world so the sum over replicas is the global mean
+    groups = _flat_layout(arch, params)
+    buckets = [torch.cat([res["grads"][k].reshape(-1) for k in g]) / world for g in groups]
+    red = xd.BucketReducer(buckets)
+    for i in range(len(buckets)):          # launched in the order the backward pass finishes them
+        red.launch(i)
+    red.finish()
+    moving = torch.cat([v.reshape(-1) for k, v in sorted(res["state"].new_moving.items())])
+    xd.mean_(moving)
+    t = xd.max_over_ranks(float(rank + 1), device="cpu")
+    if rank == 0:
+        torch.save(dict(buckets=buckets, moving=moving, tmax=t, w0=params["fc2/bias"].clone()), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_replicas_match_per_shard_average(tmp_path):
+    from oracle import x3d_oracle as O
+    from x3d_tf_amd import dist as xd
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    cfg, arch, params, clips, labels, mask = _problem()
+    groups = _flat_layout(arch, params)
+    per = []
+    for lo, hi in (xd.shard_range(4, 0, 2), xd.shard_range(4, 1, 2)):
+        per.append(O.train_step({k: v.clone() for k, v in params.items()}, clips[lo:hi], labels[lo:hi], arch, lr=None,
+                                dropout_mask=mask[lo:hi], apply_update=False))
+    for gi, g in enumerate(groups):
+        ref = sum(torch.cat([r["grads"][k].reshape(-1) for k in g]) for r in per) / 2
+        # the workers run with a different thread count (summation order), amplified by the network's depth
+        err = (got["buckets"][gi] - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, f"bucket {gi}: {err}"
+    mref = sum(torch.cat([v.reshape(-1) for k, v in sorted(r["state"].new_moving.items())]) for r in per) / 2
+    assert torch.allclose(got["moving"], mref, rtol=1e-6, atol=1e-7)
+    assert got["tmax"] == 2.0
+    assert torch.equal(got["w0"], params["fc2/bias"])          # broadcast restored rank 0's values
+    # per-replica BN: the average of shard gradients is NOT the gradient of the concatenated batch
+    whole = O.train_step({k: v.clone() for k, v in params.items()}, clips, labels, arch, lr=None, dropout_mask=mask,
+                         apply_update=False)
+    ref_w = torch.cat([whole["grads"][k].reshape(-1) for k in groups[0]])
+    assert not torch.allclose(got["buckets"][0], ref_w, rtol=1e-3, atol=1e-6)
+
+
+def test_shard_range_and_schedule():
+    from x3d_tf_amd import dist as xd
+    from x3d_tf_amd.train import lr_schedule
+    import x3d_tf_amd as x
+    assert [xd.shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
+    with pytest.raises(ValueError):
+        xd.shard_range(10, 0, 4)
+    cfg = x.get_config("M")
+    # reference train.py:114-125: linear warm-up to BASE_LR at epoch 35, half-cosine afterwards
+    assert lr_schedule(0, cfg) == pytest.approx(0.01) and lr_schedule(35, cfg) == pytest.approx(0.05)
+    assert lr_schedule(36, cfg) == pytest.approx(0.05 * 0.5 * (1 + __import__("math").cos(3.141592653589793 * 36 / 256)))
+    assert lr_schedule(256, cfg) == pytest.approx(0.0, abs=1e-9)
+    from oracle import x3d_oracle as O
+    for e in (0, 10, 35, 36, 100, 255):
+        assert lr_schedule(e, cfg) == pytest.approx(O.lr_schedule(e, cfg))
+    assert xd.BucketReducer([torch.zeros(3)]).world == 1       # no process group: single replica, no-ops
