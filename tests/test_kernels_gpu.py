@@ -204,7 +204,10 @@ def test_pw_wgrad(gpu, dtype, shape):
     ops.pw_wgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), x.to(gpu), dw, in_ss=None if ss is None else ss.to(gpu),
                  in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride)
     torch.cuda.synchronize()
-    report("dw", dw, ref + 0.5, 2e-4, 2e-4 * ref.abs().max().item())
+    # fp32: exact-fp32 MFMA.  bf16: both operands (after the fp32 prologue) are rounded to bf16 for the matrix
+    # cores, 2^-9 relative per element, fp32 accumulation
+    tol = 2e-4 if dtype == torch.float32 else 1e-2
+    report("dw", dw, ref + 0.5, tol, tol * ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

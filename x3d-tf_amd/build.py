@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libx3d_hip.so")
 SOURCES = ["api.cpp", "pw_fwd.hip", "pw_dgrad.hip", "pw_wgrad.hip", "dw.hip", "elem.hip", "stem.hip",
            "se.hip", "head.hip"]
-HEADERS = ["common.h", "pw_gemm.h", os.path.join("..", "..", "include", "x3d_hip.h")]
+HEADERS = ["common.h", "pw_gemm.h", "pw_gemm_bf16.h", "pw_wgrad_bf16.h", os.path.join("..", "..", "include", "x3d_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 

@@ -1,5 +1,5 @@
 // x3d_pw_dgrad: pointwise convolution data gradient (see pw_gemm.h)
-#include "pw_gemm.h"
+#include "pw_gemm_bf16.h"
 
 template <typename T>
 static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
@@ -35,7 +35,15 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   const int eb = d->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, d->g, d->yraw);
   hipStream_t st = (hipStream_t)stream;
-  return d->dtype == X3D_F32 ? pw_dgrad_dispatch<float>(a, d->epi, vec, st)
-                             : pw_dgrad_dispatch<bf16>(a, d->epi, vec, st);
+  if (d->dtype == X3D_F32) return pw_dgrad_dispatch<float>(a, d->epi, vec, st);
+  const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
+  switch (d->epi) {  // bf16 storage: bf16 matrix cores
+    case X3D_EPI_STORE: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_STORE>(a, vec, ovec, st);
+    case X3D_EPI_ADD: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_ADD>(a, vec, ovec, st);
+    case X3D_EPI_ADD_STRIDED: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, vec, ovec, st);
+    case X3D_EPI_SWISH_BWD: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, vec, ovec, st);
+  }
+  x3d_set_error("pw_dgrad: unknown epilogue %d", d->epi);
+  return X3D_ERR_INVALID;
 }
 

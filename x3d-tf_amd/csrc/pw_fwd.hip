@@ -1,5 +1,5 @@
 // x3d_pw_fwd: pointwise convolution forward (see pw_gemm.h)
-#include "pw_gemm.h"
+#include "pw_gemm_bf16.h"
 
 extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   X3D_REQUIRE(f && f->x && f->w && f->y, "pw_fwd: null pointer");
@@ -26,7 +26,9 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   if (f->dtype == X3D_F32)
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
-  return pro ? pw_launch_vec<bf16, PRO_AFFINE, EPI_STATS>(a, vec, st)
-             : pw_launch_vec<bf16, PRO_NONE, EPI_STATS>(a, vec, st);
+  // bf16 storage: bf16 matrix cores (fp32 accumulate)
+  const int ovec = pick_vec(eb, a.P, f->y);
+  return pro ? pw_bf16_launch_vec<PRO_AFFINE, EPI_STATS>(a, vec, ovec, st)
+             : pw_bf16_launch_vec<PRO_NONE, EPI_STATS>(a, vec, ovec, st);
 }
 

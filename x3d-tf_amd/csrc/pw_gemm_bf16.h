@@ -1,0 +1,359 @@
+// Pointwise-conv GEMMs for bf16 activation storage on v_mfma_f32_32x32x16_bf16.
+//
+//   D[M rows][N = points] = W[M][K] * X[K][N]          (fwd: M=Cout,K=Cin;  dgrad: M=Cin,K=Cout)
+//
+// These GEMMs have K <= 432 and are HBM-bound by a wide margin (the MFMA work of a 128-point tile is
+// ~100-400 cycles against ~2000 cycles of HBM time), so the kernel is organised around the memory system:
+//  * A operand (weights): staged once per workgroup in LDS as [m][k] bf16 (fp32 master weights converted
+//    on the fly), read with ds_read_b128 (row pitch K+8 elements: the 16 lanes of a b128 group hit 16
+//    distinct slots).
+//  * B operand (activations): NCTHW makes the POINTS contiguous but the MFMA wants eight CHANNELS of one
+//    point per lane.  The tile is staged [k][points] exactly as it lies in HBM (16-byte coalesced loads,
+//    prologue transform in fp32, ds_write_b128) and read back transposed with ds_read_b64_tr_b16, the
+//    gfx950 hardware transpose (pitch 2*BN+64 bytes: the 4 rows of a half-wave sit on disjoint banks).
+//  * software pipeline: the global loads of the NEXT K-chunk / point tile are issued into registers before
+//    the MFMAs and the epilogue of the current one, so HBM latency hides behind them.
+//  * epilogue through LDS: the 32x32 accumulators (point index on the lane) are written to an fp32 LDS tile
+//    and re-read row-wise, so every global access of the epilogue (output store, residual add, raw
+//    depthwise output for swish') is a coalesced 16-byte row access, and the per-channel statistics are
+//    accumulated by the thread that owns the row (16 registers instead of 2x16 per accumulator tile).
+#pragma once
+#include "pw_gemm.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define PWB_BN 128
+#define PWB_KCH 64
+#define PWB_XP (PWB_BN + 32)   // X pitch (elements)
+#define PWB_OP (PWB_BN + 4)    // output-tile pitch (floats)
+
+template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
+__global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef bf16 T;
+  constexpr int BM = MT * 32, BN = PWB_BN, XP = PWB_XP, OP = PWB_OP, KCH = PWB_KCH;
+  constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
+  constexpr int VPR = BN / VEC;                       // staging vectors per row
+  constexpr int NSV = (KCH * VPR + 255) / 256;        // staging vectors per thread per chunk
+  constexpr int ROWS_PT = BM / 16;                    // output rows owned per thread in the epilogue pass
+  const int Kp = a.KC;                                // K rounded up to 16
+  const int WP = Kp + 8;
+  bf16* Xs = (bf16*)smem_raw;                         // [KCH][XP]
+  float* Os = (float*)(smem_raw + (size_t)KCH * XP * 2);   // [BM][OP]
+  bf16* Ws = (bf16*)(smem_raw + (size_t)KCH * XP * 2 + (size_t)BM * OP * 4);   // [BM][WP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.y * BM;
+  const int tiles_per_n = (int)((a.P + BN - 1) / BN);
+  const int chunks_per_n = (tiles_per_n + a.tiles_per_block - 1) / a.tiles_per_block;
+  const int n = blockIdx.x / chunks_per_n;
+  const int chunk = blockIdx.x - n * chunks_per_n;
+  const int tile_begin = chunk * a.tiles_per_block;
+  const int tile_end = min(tile_begin + a.tiles_per_block, tiles_per_n);
+  const int nkc = (Kp + KCH - 1) / KCH;
+
+  // ---- resident weight panel: Ws[m][k] = W(k, m), zero padded
+  for (int i = tid; i < BM * Kp; i += 256) {
+    int k, m;
+    if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
+    else { k = i / BM; m = i - k * BM; }
+    const int gm = m0 + m;
+    const float v = (k < a.K && gm < a.M) ? a.w[(long long)k * a.wsk + (long long)gm * a.wsm] : 0.f;
+    Ws[m * WP + k] = (bf16)v;
+  }
+
+  // ---- register-staged prefetch of one [kc][BN] chunk
+  bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs[]
+  float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && PRO == PRO_BNBWD) ? NSV : 1];
+  auto issue_loads = [&](int tile, int kc_idx) {
+    const long long p0 = (long long)tile * BN;
+    const int k0 = kc_idx * KCH;
+    const int kc = min(KCH, Kp - k0);
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = tid + i * 256;
+      const int k = v / VPR, pv = v - k * VPR;
+      const int gk = k0 + k;
+      const long long p = p0 + (long long)pv * VEC;
+      const bool ok = (k < kc) && (gk < a.K) && (p < a.P);
+      if constexpr (VEC == 8) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+        xr[i] = z;
+        if constexpr (PRO == PRO_BNBWD) yr[i] = z;
+        if (ok) {
+          const long long o = ((long long)n * a.K + gk) * a.Pin + p;
+          xr[i] = *(const bf16x8*)((const T*)a.x + o);
+          if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+        }
+      } else {
+        xs1[i] = 0.f;
+        if constexpr (PRO == PRO_BNBWD) ys1[i] = 0.f;
+        if (ok) {
+          long long src = p;
+          if constexpr (STRIDED) {
+            const long long hw = (long long)a.Ho * a.Wo;
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+          }
+          const long long o = ((long long)n * a.K + gk) * a.Pin + src;
+          xs1[i] = to_f<T>(((const T*)a.x)[o]);
+          if constexpr (PRO == PRO_BNBWD) ys1[i] = to_f<T>(((const T*)a.x2)[o]);
+        }
+      }
+    }
+  };
+  // transform (fp32) + write the prefetched chunk to LDS
+  auto commit = [&](int kc_idx) {
+    const int k0 = kc_idx * KCH;
+    const int kc = min(KCH, Kp - k0);
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = tid + i * 256;
+      const int k = v / VPR, pv = v - k * VPR;
+      if (k >= kc) continue;
+      const int gk = k0 + k;
+      bf16* dst = &Xs[k * XP + pv * VEC];
+      if constexpr (PRO == PRO_NONE) {
+        if constexpr (VEC == 8) *(bf16x8*)dst = xr[i];
+        else dst[0] = (bf16)xs1[i];
+      } else {
+        float val[VEC];
+        if constexpr (VEC == 8) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] = (float)xr[i][e];
+        } else {
+          val[0] = xs1[i];
+        }
+        const bool inb = gk < a.K;   // padded rows stay exactly zero (the affine shift must not leak in)
+        if constexpr (PRO == PRO_AFFINE) {
+          const float s = inb ? a.coef[gk * 2] : 0.f, t = inb ? a.coef[gk * 2 + 1] : 0.f;
+          const float g = (inb && a.gate) ? a.gate[(long long)n * a.K + gk] : 1.0f;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) {
+            float u = (s * val[e] + t) * g;
+            if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
+            else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
+            val[e] = u;
+          }
+        } else {  // PRO_BNBWD
+          const float A = inb ? a.coef[gk * 4] : 0.f, B = inb ? a.coef[gk * 4 + 1] : 0.f,
+                      C = inb ? a.coef[gk * 4 + 2] : 0.f;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) {
+            const float y2 = (VEC == 8) ? (float)yr[i][e] : ys1[i];
+            val[e] = A * val[e] + B * y2 + C;
+          }
+        }
+        VecIO<bf16, VEC>::store(dst, val);
+      }
+    }
+  };
+
+  float st1[HAS_SUMS ? ROWS_PT : 1], st2[HAS_SUMS ? ROWS_PT : 1];
+  if constexpr (HAS_SUMS) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
+
+  // transposed-read lane geometry
+  const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_col = wid * 32 + 16 * (g16 & 1) + 4 * pp;    // this wave's point tile = wid
+  const int tr_row = 8 * (g16 >> 1) + q;
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+  f32x16 acc[MT];
+  if (tile_begin < tile_end) issue_loads(tile_begin, 0);
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const long long p0 = (long long)tile * BN;
+#pragma unroll
+    for (int s = 0; s < MT; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+
+    for (int kc_idx = 0; kc_idx < nkc; ++kc_idx) {
+      const int k0 = kc_idx * KCH;
+      const int kc = min(KCH, Kp - k0);
+      __syncthreads();            // previous readers of Xs (and, at kc_idx 0, of Os) are done
+      commit(kc_idx);
+      __syncthreads();
+      // prefetch what comes next while the matrix cores and the epilogue run
+      if (kc_idx + 1 < nkc) issue_loads(tile, kc_idx + 1);
+      else if (tile + 1 < tile_end) issue_loads(tile + 1, 0);
+      for (int kk = 0; kk < kc; kk += 16) {
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row) * XP + tr_col]));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row + 4) * XP + tr_col]));
+        const s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bs);
+#pragma unroll
+        for (int s = 0; s < MT; s++) {
+          const bf16x8 afrag = *(const bf16x8*)&Ws[(s * 32 + r) * WP + k0 + kk + 8 * half];
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[s], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- accumulators -> LDS output tile (col = lane&31 -> point, rows in registers)
+#pragma unroll
+    for (int s = 0; s < MT; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        Os[(s * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) * OP + wid * 32 + r] = acc[s][j];
+    __syncthreads();
+
+    // ---- row-wise epilogue pass: thread owns rows (tid>>4) + 16*i, an 8-point column chunk (tid&15)
+    const int oc = (tid & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) {
+      const int row = (tid >> 4) + 16 * i;
+      const int m = m0 + row;
+      const long long p = p0 + oc;
+      if (m >= a.M || p >= a.P) continue;
+      float val[8];
+      {
+        const f32x4 v0 = *(const f32x4*)&Os[row * OP + oc], v1 = *(const f32x4*)&Os[row * OP + oc + 4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
+      }
+      const long long o = ((long long)n * a.M + m) * a.P + p;
+      const int nvalid = (OVEC == 8) ? 8 : (int)min((long long)8, a.P - p);
+      if constexpr (EPI == X3D_EPI_ADD) {
+        if constexpr (OVEC == 8) {
+          float ad[8];
+          VecIO<T, 8>::load((const T*)a.add + o, ad);
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] += ad[e];
+        } else {
+          for (int e = 0; e < nvalid; e++) val[e] += to_f<T>(((const T*)a.add)[o + e]);
+        }
+      } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
+        const long long hw = (long long)a.eH * a.eW;
+        const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+        const long long T_ = a.P / hw;
+        for (int e = 0; e < nvalid; e++) {
+          const long long pe = p + e;
+          const long long t = pe / hw;
+          const int rem = (int)(pe - t * hw);
+          const int h = rem / a.eW, w = rem - h * a.eW;
+          if (((h | w) & 1) == 0) {
+            const long long oa = ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
+            val[e] += to_f<T>(((const T*)a.add)[oa]);
+          }
+        }
+      } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+        float b[8];
+        if constexpr (OVEC == 8) {
+          VecIO<T, 8>::load((const T*)a.braw + o, b);
+        } else {
+          for (int e = 0; e < 8; e++) b[e] = (e < nvalid) ? to_f<T>(((const T*)a.braw)[o + e]) : 0.f;
+        }
+        const float sb = a.b_ss[m * 2], tb = a.b_ss[m * 2 + 1];
+        const float g = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float dv = val[e] * swish_grad_((sb * b[e] + tb) * g);
+          val[e] = dv;
+          if (e < nvalid) {
+            const float dvr = round_to<T>(dv);
+            st1[i] += dvr;
+            st2[i] += dvr * b[e];
+          }
+        }
+      }
+      if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          if (e < nvalid) {
+            const float vr = round_to<T>(val[e]);
+            st1[i] += vr;
+            st2[i] += vr * vr;
+          }
+        }
+      }
+      if constexpr (OVEC == 8) {
+        VecIO<T, 8>::store((T*)a.y + o, val);
+      } else {
+        for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
+      }
+    }
+    // Os is rewritten only after the next tile's first two barriers
+  }
+
+  if constexpr (HAS_SUMS) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) {
+      float s1 = st1[i], s2 = st2[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const int m = m0 + (tid >> 4) + 16 * i;
+      if ((tid & 15) == 0 && m < a.M) {
+        if constexpr (EPI == EPI_STATS) {
+          if (a.stats) {
+            atomic_add_d(&a.stats[m * 2], (double)s1);
+            atomic_add_d(&a.stats[m * 2 + 1], (double)s2);
+          }
+        } else {
+          double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
+          atomic_add_d(d, (double)s1);
+          atomic_add_d(d + 1, (double)s2);
+        }
+      }
+    }
+  }
+}
+
+template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
+static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
+  constexpr int BM = MT * 32, BN = PWB_BN;
+  a.KC = (a.K + 15) & ~15;
+  const size_t lds = (size_t)PWB_KCH * PWB_XP * 2 + (size_t)BM * PWB_OP * 4 + (size_t)BM * (a.KC + 8) * 2;
+  X3D_REQUIRE(lds <= 160 * 1024, "pw_gemm_bf16: K = %d needs %zu B of LDS", a.K, lds);
+  const int gy = ceil_div(a.M, BM);
+  const long long tiles_per_n = ceil_div_ll(a.P, BN);
+  const long long total = tiles_per_n * a.N * gy;
+  int tpb = (int)(total / 2048);
+  if (tpb < 1) tpb = 1;
+  if (tpb > 16) tpb = 16;
+  if (tpb > tiles_per_n) tpb = (int)tiles_per_n;
+  a.tiles_per_block = tpb;
+  const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
+  auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_gemm_bf16");
+  return X3D_OK;
+}
+
+template <int VEC, int PRO, int EPI, bool STRIDED, int OVEC>
+static int pw_bf16_launch_tile(PwGemmArgs& a, hipStream_t st) {
+  if (a.M <= 32) return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
+  return pw_bf16_launch_cfg<VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
+}
+
+// vec: common alignment (elements) of the streamed inputs; ovec: of the outputs / epilogue tensors
+template <int PRO, int EPI>
+static int pw_bf16_launch_vec(PwGemmArgs& a, int vec, int ovec, hipStream_t st) {
+  if (a.stride > 1) {
+    if constexpr (PRO == PRO_NONE && EPI == EPI_STATS) {
+      if (ovec >= 8) return pw_bf16_launch_tile<1, PRO, EPI, true, 8>(a, st);
+      return pw_bf16_launch_tile<1, PRO, EPI, true, 1>(a, st);
+    } else {
+      x3d_set_error("pw: strided gather only in forward");
+      return X3D_ERR_INVALID;
+    }
+  }
+  if (vec >= 8 && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, false, 8>(a, st);
+  return pw_bf16_launch_tile<1, PRO, EPI, false, 1>(a, st);
+}

@@ -16,6 +16,8 @@ struct PwWgradArgs {
   int steps_per_block;  // 32-point steps per block
 };
 
+#include "pw_wgrad_bf16.h"
+
 template <typename T, int VEC, int TPW, bool XPRO, bool STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -206,5 +208,5 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   const int vec = pick_vec(eb, a.P, w->g, w->yraw, w->x);
   hipStream_t st = (hipStream_t)stream;
   return w->dtype == X3D_F32 ? pw_wgrad_dispatch<float>(a, vec, xpro, st)
-                             : pw_wgrad_dispatch<bf16>(a, vec, xpro, st);
+                             : pw_wgrad_bf16_dispatch(a, vec, xpro, st);   // bf16 storage: bf16 matrix cores
 }

@@ -1,0 +1,188 @@
+// Pointwise-conv weight gradient for bf16 storage on v_mfma_f32_32x32x16_bf16.
+//   dW[co][ci] += sum_p dYraw[co][p] * f(X)[ci][p]       M = Cout, N = Cin, K = points
+// Both operands are [row][points] with the points contiguous -- exactly the K-contiguous fragment the
+// MFMA wants (lane = row, 8 consecutive k), so both tiles are staged as they lie in HBM and read with
+// ds_read_b128; no transpose anywhere.  Row pitch = 64 points + 8 (144 B) keeps the 16 lanes of a b128 group
+// on distinct 16-byte slots.  When a layer has fewer 32x32 tiles than waves (stage-2 widths: 54x24 = 2
+// tiles) the idle waves take a share of every 64-point step instead (split-K inside the workgroup); all
+// partial tiles meet in the fp32 atomics on dW.
+#pragma once
+#include "common.h"
+
+template <int VEC, int TPW, bool XPRO, bool STRIDED>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef bf16 T;
+  constexpr int BP = 64, LP = BP + 8;
+  const int rowsA = a.mt_per_group * 32, rowsB = a.nt_total * 32;
+  bf16* As = (bf16*)smem_raw;        // [rowsA][LP]  dYraw
+  bf16* Bs = As + rowsA * LP;        // [rowsB][LP]  f(X)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int co0 = blockIdx.y * rowsA;
+  const int steps_per_n = (int)((a.P + BP - 1) / BP);
+  const int chunks_per_n = (steps_per_n + a.steps_per_block - 1) / a.steps_per_block;
+  const int n = blockIdx.x / chunks_per_n;
+  const int chunk = blockIdx.x - n * chunks_per_n;
+  const int s_begin = chunk * a.steps_per_block;
+  const int s_end = min(s_begin + a.steps_per_block, steps_per_n);
+  const int mt_here = min(a.mt_per_group, (a.Cout - co0 + 31) / 32);
+  const int ntiles = mt_here * a.nt_total;
+  // split-K over waves when there are fewer tiles than waves (only possible with TPW == 1)
+  const int nks = (TPW == 1 && ntiles <= 2) ? 4 / ntiles : 1;   // 1, 2 or 4 k-parts per 64-point step
+  const int ksteps = (BP / 16) / nks;                            // 16-wide MFMA k-steps per wave per step
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+
+  constexpr int VPR = BP / VEC;
+  for (int step = s_begin; step < s_end; ++step) {
+    const long long p0 = (long long)step * BP;
+    __syncthreads();
+    for (int v = tid; v < rowsA * VPR; v += 256) {
+      const int row = v / VPR, pv = v - row * VPR;
+      const int co = co0 + row;
+      const long long p = p0 + (long long)pv * VEC;
+      float val[VEC];
+      if (co < a.Cout && p < a.P) {
+        const long long o = ((long long)n * a.Cout + co) * a.P + p;
+        VecIO<T, VEC>::load((const T*)a.g + o, val);
+        if (a.coef) {
+          float y2[VEC];
+          VecIO<T, VEC>::load((const T*)a.yraw + o, y2);
+          const float A = a.coef[co * 4], B = a.coef[co * 4 + 1], C = a.coef[co * 4 + 2];
+#pragma unroll
+          for (int e = 0; e < VEC; e++) val[e] = A * val[e] + B * y2[e] + C;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = 0.f;
+      }
+      VecIO<bf16, VEC>::store(&As[row * LP + pv * VEC], val);
+    }
+    for (int v = tid; v < rowsB * VPR; v += 256) {
+      const int row = v / VPR, pv = v - row * VPR;
+      const long long p = p0 + (long long)pv * VEC;
+      bf16* dst = &Bs[row * LP + pv * VEC];
+      if (row < a.Cin && p < a.P) {
+        if constexpr (!XPRO && !STRIDED && VEC == 8) {
+          *(bf16x8*)dst = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p);
+        } else {
+          float val[VEC];
+          if constexpr (STRIDED) {
+            const long long hw = (long long)a.Ho * a.Wo;
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+            val[0] = to_f<T>(((const T*)a.x)[((long long)n * a.Cin + row) * a.Pin + src]);
+          } else {
+            VecIO<T, VEC>::load((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p, val);
+          }
+          if constexpr (XPRO) {
+            const float s = a.xcoef[row * 2], t = a.xcoef[row * 2 + 1];
+            const float g = a.xgate ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+              float u = (s * val[e] + t) * g;
+              if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
+              else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
+              val[e] = u;
+            }
+          }
+          VecIO<bf16, VEC>::store(dst, val);
+        }
+      } else {
+        float z[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) z[e] = 0.f;
+        VecIO<bf16, VEC>::store(dst, z);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      int id = wid + 4 * s, kpart = 0;
+      if (nks > 1) { id = wid % ntiles; kpart = wid / ntiles; }
+      if (id < ntiles) {
+        const int mt = id / a.nt_total, nt = id - mt * a.nt_total;
+        const bf16* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const bf16* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        for (int ks = 0; ks < ksteps; ks++) {
+          const bf16x8 af = *(const bf16x8*)(ap + ks * 16);
+          const bf16x8 bf = *(const bf16x8*)(bp + ks * 16);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[s], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    int id = wid + 4 * s;
+    if (nks > 1) id = wid % ntiles;
+    if (id < ntiles) {
+      const int mt = id / a.nt_total, nt = id - mt * a.nt_total;
+      const int ci = nt * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int co = co0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+      }
+    }
+  }
+}
+
+template <int VEC, int TPW, bool XPRO, bool STRIDED>
+static int pw_wgrad_bf16_launch(PwWgradArgs& a, hipStream_t st) {
+  const int mt_total = ceil_div(a.Cout, 32);
+  a.nt_total = ceil_div(a.Cin, 32);
+  int g = (4 * TPW) / a.nt_total;
+  if (g < 1) g = 1;
+  if (g > mt_total) g = mt_total;
+  a.mt_per_group = g;
+  const int gy = ceil_div(mt_total, g);
+  const long long steps_per_n = ceil_div_ll(a.P, 64);
+  long long total = steps_per_n * a.N;
+  int spb = (int)(total / 2048);
+  if (spb < 4) spb = 4;
+  if (spb > 64) spb = 64;
+  if (spb > steps_per_n) spb = (int)steps_per_n;
+  a.steps_per_block = spb;
+  const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
+  const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * 72 * 2;
+  auto kern = pw_wgrad_bf16_kernel<VEC, TPW, XPRO, STRIDED>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_wgrad_bf16");
+  return X3D_OK;
+}
+
+template <int VEC, bool XPRO, bool STRIDED>
+static int pw_wgrad_bf16_tpw(PwWgradArgs& a, hipStream_t st) {
+  const int nt = ceil_div(a.Cin, 32), mt = ceil_div(a.Cout, 32);
+  const int tiles = nt * mt;
+  if (tiles <= 4) return pw_wgrad_bf16_launch<VEC, 1, XPRO, STRIDED>(a, st);
+  if (tiles <= 8) return pw_wgrad_bf16_launch<VEC, 2, XPRO, STRIDED>(a, st);
+  if (tiles <= 16) return pw_wgrad_bf16_launch<VEC, 4, XPRO, STRIDED>(a, st);
+  return pw_wgrad_bf16_launch<VEC, 8, XPRO, STRIDED>(a, st);
+}
+
+static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
+  if (a.stride > 1) {
+    if (xpro) { x3d_set_error("pw_wgrad: strided input takes no prologue"); return X3D_ERR_INVALID; }
+    return pw_wgrad_bf16_tpw<1, false, true>(a, st);
+  }
+  if (vec >= 8)
+    return xpro ? pw_wgrad_bf16_tpw<8, true, false>(a, st) : pw_wgrad_bf16_tpw<8, false, false>(a, st);
+  return xpro ? pw_wgrad_bf16_tpw<1, true, false>(a, st) : pw_wgrad_bf16_tpw<1, false, false>(a, st);
+}
