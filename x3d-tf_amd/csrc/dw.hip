@@ -1,12 +1,14 @@
 // Channelwise 3x3x3 convolution (stride (1,s,s), TF-SAME padding): forward and fused backward.
 //
 // HBM-bound: 27 FMAs per output against 2-10 bytes, so the design goal is "read every input element
-// once, write every output once".  One workgroup owns one (n, c, H-tile) and streams the T planes of
-// that channel through LDS:
-//   global --(vector load, folded BN+ReLU applied once per element)--> LDS plane with zero halo
-// Each thread owns a strip of SW consecutive outputs of one row and keeps THREE partial output
-// planes (t-1, t, t+1) in registers: a staged input plane is read from LDS once and scattered into
-// the three temporal taps, so no plane is ever re-read and only one plane lives in LDS.
+// once, write every output once, never wait for a load".  One workgroup owns one (n, c, H-tile) and
+// streams the T planes of that channel through LDS:
+//   global --(vector load into registers, issued ONE PLANE AHEAD)--> folded BN+ReLU, once per element
+//          --> LDS plane with zero halo (= the TF-SAME / temporal zero padding)
+// The staging map (which global vector lands where in LDS) is the same for every plane, so it is computed
+// once per thread before the T loop.  Each thread owns a strip of SW consecutive outputs of one row and
+// keeps THREE partial output planes (t-1, t, t+1) in registers: a staged plane is read from LDS once and
+// scattered into the three temporal taps, so no plane is ever re-read and only one plane lives in LDS.
 // Per-channel BatchNorm statistics and the squeeze-excite pool are reduced in the epilogue
 // (wave shuffles -> LDS -> one fp64 atomic per workgroup).
 #include "common.h"
@@ -19,8 +21,81 @@ struct DwGeom {
   int nstrips;       // strips of SW outputs per row
   int RIN;           // staged input rows  = (TH-1)*S + 3
   int LP;            // LDS pitch (floats) = (nstrips*SW-1)*S + 3
-  int vec;           // staging vector width along W
+  int vec;           // staging vector width along W (elements)
 };
+
+// ---- a staged vector: up to 16 raw bytes held in registers between the load and the LDS write
+struct Raw { uint32_t w[4]; };
+
+template <typename T>
+__device__ __forceinline__ void raw_load(Raw& r, const T* p, int vec) {
+  const int bytes = vec * (int)sizeof(T);
+  if (bytes == 16) { const uint4 v = *(const uint4*)p; r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
+  else if (bytes == 8) { const uint2 v = *(const uint2*)p; r.w[0] = v.x; r.w[1] = v.y; }
+  else if (bytes == 4) { r.w[0] = *(const uint32_t*)p; }
+  else { r.w[0] = *(const uint16_t*)p; }
+}
+template <typename T> __device__ __forceinline__ float raw_get(const Raw& r, int e);
+template <> __device__ __forceinline__ float raw_get<float>(const Raw& r, int e) { return __uint_as_float(r.w[e]); }
+template <> __device__ __forceinline__ float raw_get<bf16>(const Raw& r, int e) {
+  return __uint_as_float(((r.w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
+}
+template <typename T> struct MaxVec { static constexpr int v = 16 / sizeof(T); };
+
+// staging map of one plane tile: vector i of this thread reads goff[i] (elements from the plane origin,
+// -1 = nothing to load) and writes lds[loff[i] ...]
+template <int NSV>
+struct StageMap {
+  int goff[NSV], loff[NSV];
+  __device__ __forceinline__ void build(int RIN, int LP, int row0, int H, int W, int pw, int vec) {
+    const int nvr = W / vec, total = RIN * nvr;
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = threadIdx.x + i * blockDim.x;
+      goff[i] = -1; loff[i] = 0;
+      if (v < total) {
+        const int lr = v / nvr, jv = v - lr * nvr;
+        const int hi = row0 + lr;
+        if (hi >= 0 && hi < H) { goff[i] = hi * W + jv * vec; loff[i] = lr * LP + pw + jv * vec; }
+      }
+    }
+  }
+};
+
+// generic (no prefetch) staging for tiles with more vectors per thread than the register budget
+template <typename T, typename F>
+__device__ __forceinline__ void stage_direct(const T* src, float* lds, int RIN, int LP, int row0, int H, int W,
+                                             int pw, int vec, F f) {
+  const int nvr = W / vec, total = RIN * nvr;
+  for (int v = threadIdx.x; v < total; v += blockDim.x) {
+    const int lr = v / nvr, jv = v - lr * nvr;
+    const int hi = row0 + lr;
+    if (hi >= 0 && hi < H) {
+      Raw r;
+      raw_load<T>(r, src + (long long)hi * W + jv * vec, vec);
+      float* d = lds + lr * LP + pw + jv * vec;
+#pragma unroll
+      for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = f(raw_get<T>(r, e));
+    }
+  }
+}
+template <typename T, typename F>
+__device__ __forceinline__ void stage_direct2(const T* s0, const T* s1, float* lds, int RIN, int LP, int row0, int H,
+                                              int W, int pw, int vec, F f) {
+  const int nvr = W / vec, total = RIN * nvr;
+  for (int v = threadIdx.x; v < total; v += blockDim.x) {
+    const int lr = v / nvr, jv = v - lr * nvr;
+    const int hi = row0 + lr;
+    if (hi >= 0 && hi < H) {
+      Raw r0, r1;
+      raw_load<T>(r0, s0 + (long long)hi * W + jv * vec, vec);
+      raw_load<T>(r1, s1 + (long long)hi * W + jv * vec, vec);
+      float* d = lds + lr * LP + pw + jv * vec;
+#pragma unroll
+      for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = f(raw_get<T>(r0, e), raw_get<T>(r1, e));
+    }
+  }
+}
 
 struct DwFwdArgs {
   DwGeom g;
@@ -29,77 +104,15 @@ struct DwFwdArgs {
   double* stats; double* pool;
 };
 
-// stage rows [0, RIN) of image plane `src` (H x W, row-major) into lds[lr*LP + pw + col], applying
-// v = act(sc*x + sh) (identity when !affine).  Rows outside the image are left untouched (zero).
-template <typename T, int VEC, typename F>
-__device__ __forceinline__ void dw_stage_rows(const T* __restrict__ src, float* lds, int RIN, int LP,
-                                              int row0 /* image row of lds row 0 */, int H, int W,
-                                              int pw, F f) {
-  const int nvr = W / VEC;
-  const int total = RIN * nvr;
-  for (int v = threadIdx.x; v < total; v += blockDim.x) {
-    const int lr = v / nvr, jv = v - lr * nvr;
-    const int hi = row0 + lr;
-    if (hi >= 0 && hi < H) {
-      float val[VEC];
-      VecIO<T, VEC>::load(src + (long long)hi * W + jv * VEC, val);
-      float* d = lds + lr * LP + pw + jv * VEC;
-#pragma unroll
-      for (int e = 0; e < VEC; e++) d[e] = f(val[e]);
-    }
-  }
-}
-
-template <typename T, typename F>
-__device__ __forceinline__ void dw_stage_rows_v(int vec, const T* src, float* lds, int RIN, int LP,
-                                                int row0, int H, int W, int pw, F f) {
-  switch (vec) {
-    case 8: if constexpr (sizeof(T) == 2) { dw_stage_rows<T, 8>(src, lds, RIN, LP, row0, H, W, pw, f); break; }
-    case 4: dw_stage_rows<T, 4>(src, lds, RIN, LP, row0, H, W, pw, f); break;
-    case 2: dw_stage_rows<T, 2>(src, lds, RIN, LP, row0, H, W, pw, f); break;
-    default: dw_stage_rows<T, 1>(src, lds, RIN, LP, row0, H, W, pw, f); break;
-  }
-}
-
-// two-operand variant: f(a, b) -> value   (dB = A*dv + B*braw + C)
-template <typename T, int VEC, typename F>
-__device__ __forceinline__ void dw_stage_rows2(const T* __restrict__ s0, const T* __restrict__ s1,
-                                               float* lds, int RIN, int LP, int row0, int H, int W,
-                                               int pw, F f) {
-  const int nvr = W / VEC;
-  const int total = RIN * nvr;
-  for (int v = threadIdx.x; v < total; v += blockDim.x) {
-    const int lr = v / nvr, jv = v - lr * nvr;
-    const int hi = row0 + lr;
-    if (hi >= 0 && hi < H) {
-      float a[VEC], b[VEC];
-      VecIO<T, VEC>::load(s0 + (long long)hi * W + jv * VEC, a);
-      VecIO<T, VEC>::load(s1 + (long long)hi * W + jv * VEC, b);
-      float* d = lds + lr * LP + pw + jv * VEC;
-#pragma unroll
-      for (int e = 0; e < VEC; e++) d[e] = f(a[e], b[e]);
-    }
-  }
-}
-template <typename T, typename F>
-__device__ __forceinline__ void dw_stage_rows2_v(int vec, const T* s0, const T* s1, float* lds, int RIN,
-                                                 int LP, int row0, int H, int W, int pw, F f) {
-  switch (vec) {
-    case 8: if constexpr (sizeof(T) == 2) { dw_stage_rows2<T, 8>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break; }
-    case 4: dw_stage_rows2<T, 4>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
-    case 2: dw_stage_rows2<T, 2>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
-    default: dw_stage_rows2<T, 1>(s0, s1, lds, RIN, LP, row0, H, W, pw, f); break;
-  }
-}
-
 // ================================================================================================
-// forward
+// forward.  NSV = staging vectors per thread held in registers for the prefetch (0: direct staging)
 // ================================================================================================
-template <typename T, int S, int SW>
+template <typename T, int S, int SW, int NSV>
 __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const DwGeom& g = a.g;
   constexpr int WIN = (SW - 1) * S + 3;
+  constexpr int NS = NSV > 0 ? NSV : 1;
   const int plane_sz = g.RIN * g.LP;
   float* scratch = lds + plane_sz;
 
@@ -109,7 +122,6 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   const int n = b / g.C;
   const int h0 = tile * g.TH;
   const int th_here = min(g.TH, g.Ho - h0);
-
   const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
   const bool active = r < th_here;
   const int ho = h0 + r, wo0 = sidx * SW;
@@ -127,34 +139,72 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
     return act == X3D_ACT_RELU ? fmaxf(u, 0.f) : u;
   };
 
+  const long long iplane = (long long)g.H * g.W, oplane = (long long)g.Ho * g.Wo;
+  const T* xin = (const T*)a.x + ((long long)n * g.C + c) * g.T * iplane;
+  T* yout = (T*)a.y + ((long long)n * g.C + c) * g.T * oplane;
+  const int row0 = h0 * S - g.ph, vec = g.vec;
+
+  StageMap<NS> map;
+  Raw raw[NS];
+  if constexpr (NSV > 0) {
+    map.build(g.RIN, g.LP, row0, g.H, g.W, g.pw, vec);
+#pragma unroll
+    for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + map.goff[i], vec);
+  }
+
   float acc0[SW], acc1[SW], acc2[SW];
 #pragma unroll
   for (int i = 0; i < SW; i++) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
   float s1 = 0.f, s2 = 0.f;
 
-  const T* xin = (const T*)a.x + ((long long)n * g.C + c) * g.T * g.H * g.W;
-  T* yout = (T*)a.y + ((long long)n * g.C + c) * g.T * g.Ho * g.Wo;
-  const long long oplane = (long long)g.Ho * g.Wo;
-
+  // every strip is full and SW-aligned when Wo % SW == 0: one 8/16-byte store per thread and plane instead
+  // of SW two-byte stores (the scalar stores, not HBM, were the limiter of the stride-1 layers)
+  const bool vstore = (SW > 1) && (g.Wo % SW == 0) && (((uintptr_t)a.y) % (SW * sizeof(T)) == 0);
   auto store_plane = [&](int t, const float (&v)[SW]) {
     if (!active) return;
     T* dst = yout + t * oplane + (long long)ho * g.Wo + wo0;
+    if (vstore) {
+      VecIO<T, SW>::store(dst, v);
 #pragma unroll
-    for (int i = 0; i < SW; i++) {
-      if (wo0 + i < g.Wo) {
-        dst[i] = from_f<T>(v[i]);
+      for (int i = 0; i < SW; i++) {
         const float vr = round_to<T>(v[i]);
         s1 += vr;
         s2 += vr * vr;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SW; i++) {
+        if (wo0 + i < g.Wo) {
+          dst[i] = from_f<T>(v[i]);
+          const float vr = round_to<T>(v[i]);
+          s1 += vr;
+          s2 += vr * vr;
+        }
       }
     }
   };
 
   for (int t = 0; t < g.T; ++t) {
     __syncthreads();  // zero-fill / previous plane's readers done
-    dw_stage_rows_v<T>(g.vec, xin + (long long)t * g.H * g.W, lds, g.RIN, g.LP, h0 * S - g.ph, g.H,
-                       g.W, g.pw, xf);
+    if constexpr (NSV > 0) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        if (map.goff[i] >= 0) {
+          float* d = lds + map.loff[i];
+#pragma unroll
+          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = xf(raw_get<T>(raw[i], e));
+        }
+      }
+    } else {
+      stage_direct<T>(xin + t * iplane, lds, g.RIN, g.LP, row0, g.H, g.W, g.pw, vec, xf);
+    }
     __syncthreads();
+    if constexpr (NSV > 0) {  // next plane's loads fly while this one is consumed
+      if (t + 1 < g.T) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + (t + 1) * iplane + map.goff[i], vec);
+      }
+    }
     if (active) {
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
@@ -195,8 +245,7 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 
 // tile geometry shared by forward and backward
 static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int SW, int elem_bytes,
-                   const void* p0, const void* p1, const void* p2, int* block_dim, size_t* lds_floats,
-                   int max_items) {
+                   const void* p0, const void* p1, const void* p2, int* block_dim, size_t* lds_floats) {
   g.N = N; g.C = C; g.T = T; g.H = H; g.W = W; g.S = stride;
   g.Ho = ceil_div(H, stride); g.Wo = ceil_div(W, stride);
   const int tot_h = (g.Ho - 1) * stride + 3 - H, tot_w = (g.Wo - 1) * stride + 3 - W;
@@ -207,7 +256,6 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
   const int items = g.Ho * g.nstrips;
   if (items <= 64) bd = 64;
   else if (items <= 128) bd = 128;
-  if (bd > max_items) bd = max_items;
   if (g.nstrips > bd) return -1;
   int th = bd / g.nstrips;
   if (th > g.Ho) th = g.Ho;
@@ -223,6 +271,16 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
 
 static int dw_pick_sw(int Wo) { return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1); }
 
+// staging vectors per thread for a [rows][W] plane tile
+static int dw_nsv(int rows, int W, int vec, int bd) { return ceil_div(rows * (W / vec), bd); }
+
+template <typename T, int S, int SW>
+static void dw_fwd_launch_nsv(const DwFwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  if (nsv <= 2) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 2>), dim3(grid), dim3(bd), lds, st, a);
+  else if (nsv <= 4) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 4>), dim3(grid), dim3(bd), lds, st, a);
+  else hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 0>), dim3(grid), dim3(bd), lds, st, a);
+}
+
 template <typename T, int S>
 static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   DwFwdArgs a;
@@ -231,7 +289,7 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   const int Wo = ceil_div(f->W, S);
   const int SW = dw_pick_sw(Wo);
   int bd; size_t ldsf;
-  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->x, nullptr, nullptr, &bd, &ldsf, 256)) {
+  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->x, nullptr, nullptr, &bd, &ldsf)) {
     x3d_set_error("dw3d_fwd: row of %d outputs does not fit one workgroup", Wo);
     return X3D_ERR_INVALID;
   }
@@ -239,10 +297,11 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   X3D_REQUIRE(lds <= 64 * 1024, "dw3d_fwd: tile needs %zu B of LDS", lds);
   const long long grid = (long long)f->N * f->C * a.g.ntile_h;
   X3D_REQUIRE(grid < (1ll << 31), "dw3d_fwd: grid too large");
+  const int nsv = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd);
   switch (SW) {
-    case 4: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 4>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 2>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
-    default: hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, 1>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+    case 4: dw_fwd_launch_nsv<T, S, 4>(a, nsv, (unsigned)grid, bd, lds, st); break;
+    case 2: dw_fwd_launch_nsv<T, S, 2>(a, nsv, (unsigned)grid, bd, lds, st); break;
+    default: dw_fwd_launch_nsv<T, S, 1>(a, nsv, (unsigned)grid, bd, lds, st); break;
   }
   X3D_LAUNCH_CHECK("dw3d_fwd");
   return X3D_OK;
@@ -266,8 +325,8 @@ extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {
 //   dW[kt][kh][kw] += sum dB[t][ho][wo] * act[t+kt-1][ho*S+kh-ph][wo*S+kw-pw]
 //   dA[t][h][w]     = sum w[kt][kh][kw] * dB[t+1-kt][(h+ph-kh)/S][(w+pw-kw)/S]
 //   ga = dA * [sc*araw + sh > 0];   a_sums += (sum ga, sum ga*araw)
-// Planes of act and dB are streamed through LDS once; the temporal taps are handled with rotating
-// register accumulators (dA) and a one-plane-old register window (dW).
+// Planes of act and dB are streamed through LDS once (prefetched one plane ahead); the temporal taps are
+// handled with rotating register accumulators (dA) and a one-plane-old register window (dW).
 // ================================================================================================
 struct DwBwdArgs {
   DwGeom g;
@@ -278,7 +337,7 @@ struct DwBwdArgs {
   int vecB;     // staging vector width for the dv / braw planes
 };
 
-template <typename T, int S, int SW>
+template <typename T, int S, int SW, int NSV>
 __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const DwGeom& g = a.g;
@@ -287,6 +346,7 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   constexpr int BR = (S == 1) ? 3 : 2;           // dB window rows
   constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
   constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
+  constexpr int NS = NSV > 0 ? NSV : 1;
   const int aplane = g.RIN * g.LP;
   const int bplane = a.RB * a.LPB;
   float* Al = lds;
@@ -319,6 +379,27 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   const T* dvp = (const T*)a.dv + ((long long)n * g.C + c) * g.T * opl;
   const T* brp = (const T*)a.braw + ((long long)n * g.C + c) * g.T * opl;
   T* gap = (T*)a.ga + ((long long)n * g.C + c) * g.T * ipl;
+  const int rowA0 = h0 * S - g.ph, vecA = g.vec, vecB = a.vecB;
+
+  StageMap<NS> mapA, mapB;
+  Raw rawA[NS], rawD[NS], rawR[NS];
+  auto issue = [&](int t) {
+    if constexpr (NSV > 0) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        if (mapA.goff[i] >= 0) raw_load<T>(rawA[i], araw + t * ipl + mapA.goff[i], vecA);
+        if (mapB.goff[i] >= 0) {
+          raw_load<T>(rawD[i], dvp + t * opl + mapB.goff[i], vecB);
+          raw_load<T>(rawR[i], brp + t * opl + mapB.goff[i], vecB);
+        }
+      }
+    }
+  };
+  if constexpr (NSV > 0) {
+    mapA.build(g.RIN, g.LP, rowA0, g.H, g.W, g.pw, vecA);
+    mapB.build(a.RB, a.LPB, h0 - 1, g.Ho, g.Wo, 1, vecB);   // dB plane: lds row 0 <-> output row h0-1, col 0 <-> col -1
+    issue(0);
+  }
 
   float dA0[NR][NA], dA1[NR][NA], dA2[NR][NA];
 #pragma unroll
@@ -341,6 +422,29 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   const int hA = (S == 1) ? ho : ho * 2 - g.ph;
   const int wA0 = (S == 1) ? wo0 : wo0 * 2 - g.pw;
 
+  // this thread's own araw strip of the plane that is emitted at the end of the iteration: loaded at the
+  // top of the iteration so its latency hides behind the plane's arithmetic
+  // the NA owned columns of a row are contiguous and NA-aligned when the strips tile the row exactly and the
+  // left pad is 0: one vector load / store per row instead of NA two-byte accesses
+  const bool vown = (NA > 1) && (g.W % NA == 0) && (S == 1 || g.pw == 0) && (g.Wo % SW == 0) &&
+                    (((uintptr_t)a.araw) % (NA * sizeof(T)) == 0) && (((uintptr_t)a.ga) % (NA * sizeof(T)) == 0);
+  float ar[NR][NA];
+  auto load_own = [&](int t) {
+    if (!active) return;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      const int h = hA + q;
+      if (vown) {
+        if (h >= 0 && h < g.H) VecIO<T, NA>::load(araw + t * ipl + (long long)h * g.W + wA0, ar[q]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+          const int w = wA0 + i;
+          ar[q][i] = (h >= 0 && h < g.H && w >= 0 && w < g.W) ? to_f<T>(araw[t * ipl + (long long)h * g.W + w]) : 0.f;
+        }
+      }
+    }
+  };
   auto emit = [&](int t, const float (&v)[NR][NA]) {
     if (!active) return;
 #pragma unroll
@@ -348,16 +452,29 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
       const int h = hA + q;
       if (h < 0 || h >= g.H) continue;
       const long long base = t * ipl + (long long)h * g.W;
+      if (vown) {
+        float gv[NA];
 #pragma unroll
-      for (int i = 0; i < NA; i++) {
-        const int w = wA0 + i;
-        if (w >= 0 && w < g.W) {
-          const float av = to_f<T>(araw[base + w]);
-          const float gv = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
-          gap[base + w] = from_f<T>(gv);
-          const float gr = round_to<T>(gv);
+        for (int i = 0; i < NA; i++) {
+          const float av = ar[q][i];
+          gv[i] = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
+          const float gr = round_to<T>(gv[i]);
           s1 += gr;
           s2 += gr * av;
+        }
+        VecIO<T, NA>::store(gap + base + wA0, gv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+          const int w = wA0 + i;
+          if (w >= 0 && w < g.W) {
+            const float av = ar[q][i];
+            const float gv = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
+            gap[base + w] = from_f<T>(gv);
+            const float gr = round_to<T>(gv);
+            s1 += gr;
+            s2 += gr * av;
+          }
         }
       }
     }
@@ -365,11 +482,27 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 
   for (int t = 0; t < g.T; ++t) {
     __syncthreads();
-    dw_stage_rows_v<T>(g.vec, araw + t * ipl, Al, g.RIN, g.LP, h0 * S - g.ph, g.H, g.W, g.pw, af);
-    // dB plane: lds row 0 <-> output row h0-1, col 0 <-> output col -1
-    dw_stage_rows2_v<T>(a.vecB, dvp + t * opl, brp + t * opl, Bl, a.RB, a.LPB, h0 - 1,
-                        g.Ho, g.Wo, 1, bf);
+    if constexpr (NSV > 0) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        if (mapA.goff[i] >= 0) {
+          float* d = Al + mapA.loff[i];
+#pragma unroll
+          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecA) d[e] = af(raw_get<T>(rawA[i], e));
+        }
+        if (mapB.goff[i] >= 0) {
+          float* d = Bl + mapB.loff[i];
+#pragma unroll
+          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecB) d[e] = bf(raw_get<T>(rawD[i], e), raw_get<T>(rawR[i], e));
+        }
+      }
+    } else {
+      stage_direct<T>(araw + t * ipl, Al, g.RIN, g.LP, rowA0, g.H, g.W, g.pw, vecA, af);
+      stage_direct2<T>(dvp + t * opl, brp + t * opl, Bl, a.RB, a.LPB, h0 - 1, g.Ho, g.Wo, 1, vecB, bf);
+    }
     __syncthreads();
+    if (t + 1 < g.T) issue(t + 1);
+    if (t >= 1) load_own(t - 1);
     if (active) {
       float winA[3][WIN], winB[BR][BW];
 #pragma unroll
@@ -451,19 +584,31 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < NA; i++) { dA0[q][i] = dA1[q][i]; dA1[q][i] = dA2[q][i]; dA2[q][i] = 0.f; }
   }
+  load_own(g.T - 1);
   emit(g.T - 1, dA0);
 
-  float red[29];
+  // block reduction of the 27 weight-gradient taps and the two BN sums, one value at a time (registers)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int k = 0; k < 27; k++) red[k] = dW[k];
-  red[27] = s1; red[28] = s2;
-  block_sum<29>(red, scratch);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
-    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
-    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
+  for (int k = 0; k < 29; k++) {
+    float v = k < 27 ? dW[k] : (k == 27 ? s1 : s2);
+    v = wave_sum(v);
+    if (lane == 0) scratch[k * 4 + wid] = v;
   }
+  __syncthreads();
+  if (threadIdx.x < 29) {
+    float v = 0.f;
+    for (int w = 0; w < nw; w++) v += scratch[threadIdx.x * 4 + w];
+    if (threadIdx.x < 27) atomicAdd(&a.dw[c * 27 + threadIdx.x], v);
+    else atomic_add_d(&a.a_sums[c * 2 + (threadIdx.x - 27)], (double)v);
+  }
+}
+
+template <typename T, int S, int SW>
+static void dw_bwd_launch_nsv(const DwBwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  if (nsv <= 1) hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 1>), dim3(grid), dim3(bd), lds, st, a);
+  else if (nsv <= 2) hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 2>), dim3(grid), dim3(bd), lds, st, a);
+  else hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 0>), dim3(grid), dim3(bd), lds, st, a);
 }
 
 template <typename T, int S>
@@ -475,7 +620,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   int SW = dw_pick_sw(Wo);
   if (S == 2 && SW > 2) SW = 2;  // 2x2 input quads per output: keep the register footprint bounded
   int bd; size_t ldsf;
-  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->araw, f->ga, nullptr, &bd, &ldsf, 256)) {
+  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->araw, f->ga, nullptr, &bd, &ldsf)) {
     x3d_set_error("dw3d_bwd: row of %d outputs does not fit one workgroup", Wo);
     return X3D_ERR_INVALID;
   }
@@ -486,11 +631,13 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   X3D_REQUIRE(lds <= 64 * 1024, "dw3d_bwd: tile needs %zu B of LDS", lds);
   const long long grid = (long long)f->N * f->C * a.g.ntile_h;
   X3D_REQUIRE(grid < (1ll << 31), "dw3d_bwd: grid too large");
+  const int nsvA = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd), nsvB = dw_nsv(a.RB, a.g.Wo, a.vecB, bd);
+  const int nsv = nsvA > nsvB ? nsvA : nsvB;
   switch (SW) {
     case 4:
-      if constexpr (S == 1) { hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 4>), dim3((unsigned)grid), dim3(bd), lds, st, a); break; }
-    case 2: hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 2>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
-    default: hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, 1>), dim3((unsigned)grid), dim3(bd), lds, st, a); break;
+      if constexpr (S == 1) { dw_bwd_launch_nsv<T, S, 4>(a, nsv, (unsigned)grid, bd, lds, st); break; }
+    case 2: dw_bwd_launch_nsv<T, S, 2>(a, nsv, (unsigned)grid, bd, lds, st); break;
+    default: dw_bwd_launch_nsv<T, S, 1>(a, nsv, (unsigned)grid, bd, lds, st); break;
   }
   X3D_LAUNCH_CHECK("dw3d_bwd");
   return X3D_OK;

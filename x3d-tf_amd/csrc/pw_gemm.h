@@ -31,6 +31,7 @@ struct PwGemmArgs {
   long long P, Pin;
   int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
   int KC, nchunks, tiles_per_block;
+  int wvec;            // bf16 kernel: fp32 vector width for the weight-panel staging
   // epilogue
   void* y;
   double* stats;       // EPI_STATS: [M][2]

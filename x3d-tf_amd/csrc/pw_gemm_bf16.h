@@ -46,29 +46,54 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int m0 = blockIdx.y * BM;
+  // tiles are numbered across samples (tile -> sample n = tile / tiles_per_n), so a workgroup amortises its
+  // weight panel over `tiles_per_block` tiles even when one sample has only a handful (P = 784 at stage 5)
   const int tiles_per_n = (int)((a.P + BN - 1) / BN);
-  const int chunks_per_n = (tiles_per_n + a.tiles_per_block - 1) / a.tiles_per_block;
-  const int n = blockIdx.x / chunks_per_n;
-  const int chunk = blockIdx.x - n * chunks_per_n;
-  const int tile_begin = chunk * a.tiles_per_block;
-  const int tile_end = min(tile_begin + a.tiles_per_block, tiles_per_n);
+  const int total_tiles = tiles_per_n * a.N;
+  const int tile_begin = blockIdx.x * a.tiles_per_block;
+  const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
   const int nkc = (Kp + KCH - 1) / KCH;
 
-  // ---- resident weight panel: Ws[m][k] = W(k, m), zero padded
-  for (int i = tid; i < BM * Kp; i += 256) {
-    int k, m;
-    if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
-    else { k = i / BM; m = i - k * BM; }
-    const int gm = m0 + m;
-    const float v = (k < a.K && gm < a.M) ? a.w[(long long)k * a.wsk + (long long)gm * a.wsm] : 0.f;
-    Ws[m * WP + k] = (bf16)v;
+  // ---- resident weight panel: Ws[m][k] = W(k, m) as bf16, zero padded.  The fp32 master weights are read
+  // along their contiguous axis with the widest aligned vector (4/2/1 floats).
+  {
+    const int wv = a.wvec;
+    if (a.wsk == 1) {            // forward: source rows are k-contiguous -> one LDS row segment per vector
+      const int kv = Kp / wv;    // Kp % 4 == 0
+      for (int i = tid; i < BM * kv; i += 256) {
+        const int m = i / kv, k = (i - m * kv) * wv;
+        const int gm = m0 + m;
+        const float* src = a.w + (long long)gm * a.wsm + k;
+        bf16* dst = &Ws[m * WP + k];
+        for (int e = 0; e < wv; e += 1) dst[e] = (bf16)0.f;
+        if (gm < a.M && k < a.K) {
+          if (wv == 4) { const f32x4 v = *(const f32x4*)src; dst[0] = (bf16)v[0]; dst[1] = (bf16)v[1]; dst[2] = (bf16)v[2]; dst[3] = (bf16)v[3]; }
+          else if (wv == 2) { const float2 v = *(const float2*)src; dst[0] = (bf16)v.x; dst[1] = (bf16)v.y; }
+          else dst[0] = (bf16)src[0];
+        }
+      }
+    } else {                     // dgrad: source rows are m-contiguous -> a vector scatters over wv LDS rows
+      const int mv = BM / wv;
+      for (int i = tid; i < Kp * mv; i += 256) {
+        const int k = i / mv, m = (i - k * mv) * wv;
+        const int gm = m0 + m;
+        const float* src = a.w + (long long)k * a.wsk + gm;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K) {
+          if (wv == 4 && gm + 3 < a.M) { const f32x4 t = *(const f32x4*)src; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+          else for (int e = 0; e < wv; e++) if (gm + e < a.M) v[e] = src[e];
+        }
+        for (int e = 0; e < wv; e++) Ws[(m + e) * WP + k] = (bf16)v[e];
+      }
+    }
   }
 
   // ---- register-staged prefetch of one [kc][BN] chunk
   bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs[]
   float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && PRO == PRO_BNBWD) ? NSV : 1];
   auto issue_loads = [&](int tile, int kc_idx) {
-    const long long p0 = (long long)tile * BN;
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     const int k0 = kc_idx * KCH;
     const int kc = min(KCH, Kp - k0);
 #pragma unroll
@@ -109,7 +134,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     }
   };
   // transform (fp32) + write the prefetched chunk to LDS
-  auto commit = [&](int kc_idx) {
+  auto commit = [&](int tile, int kc_idx) {
+    const int n = tile / tiles_per_n;
     const int k0 = kc_idx * KCH;
     const int kc = min(KCH, Kp - k0);
 #pragma unroll
@@ -170,8 +196,41 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   f32x16 acc[MT];
   if (tile_begin < tile_end) issue_loads(tile_begin, 0);
 
+  // reduce the row sums over the 16 threads that share a row and publish them (fp64 atomics)
+  auto flush_sums = [&](int n) {
+    if constexpr (HAS_SUMS) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        float s1 = st1[i], s2 = st2[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const int m = m0 + (tid >> 4) + 16 * i;
+        if ((tid & 15) == 0 && m < a.M) {
+          if constexpr (EPI == EPI_STATS) {
+            if (a.stats) {
+              atomic_add_d(&a.stats[m * 2], (double)s1);
+              atomic_add_d(&a.stats[m * 2 + 1], (double)s2);
+            }
+          } else {
+            double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
+            atomic_add_d(d, (double)s1);
+            atomic_add_d(d + 1, (double)s2);
+          }
+        }
+        st1[i] = 0.f;
+        st2[i] = 0.f;
+      }
+    }
+  };
+
+  int n_prev = tile_begin < tile_end ? tile_begin / tiles_per_n : 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
-    const long long p0 = (long long)tile * BN;
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+    if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+      if (n != n_prev) flush_sums(n_prev);     // the sums are per (sample, channel)
+    }
+    n_prev = n;
 #pragma unroll
     for (int s = 0; s < MT; s++)
 #pragma unroll
@@ -181,7 +240,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const int k0 = kc_idx * KCH;
       const int kc = min(KCH, Kp - k0);
       __syncthreads();            // previous readers of Xs (and, at kc_idx 0, of Os) are done
-      commit(kc_idx);
+      commit(tile, kc_idx);
       __syncthreads();
       // prefetch what comes next while the matrix cores and the epilogue run
       if (kc_idx + 1 < nkc) issue_loads(tile, kc_idx + 1);
@@ -285,27 +344,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     // Os is rewritten only after the next tile's first two barriers
   }
 
-  if constexpr (HAS_SUMS) {
-#pragma unroll
-    for (int i = 0; i < ROWS_PT; i++) {
-      float s1 = st1[i], s2 = st2[i];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      const int m = m0 + (tid >> 4) + 16 * i;
-      if ((tid & 15) == 0 && m < a.M) {
-        if constexpr (EPI == EPI_STATS) {
-          if (a.stats) {
-            atomic_add_d(&a.stats[m * 2], (double)s1);
-            atomic_add_d(&a.stats[m * 2 + 1], (double)s2);
-          }
-        } else {
-          double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
-          atomic_add_d(d, (double)s1);
-          atomic_add_d(d + 1, (double)s2);
-        }
-      }
-    }
-  }
+  if (tile_begin < tile_end) flush_sums(n_prev);
 }
 
 template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
@@ -315,14 +354,21 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const size_t lds = (size_t)PWB_KCH * PWB_XP * 2 + (size_t)BM * PWB_OP * 4 + (size_t)BM * (a.KC + 8) * 2;
   X3D_REQUIRE(lds <= 160 * 1024, "pw_gemm_bf16: K = %d needs %zu B of LDS", a.K, lds);
   const int gy = ceil_div(a.M, BM);
-  const long long tiles_per_n = ceil_div_ll(a.P, BN);
-  const long long total = tiles_per_n * a.N * gy;
-  int tpb = (int)(total / 2048);
+  const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
+  X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
+  int tpb = (int)(total_tiles * gy / 1536);      // aim for >= ~6 workgroups per CU, <= 16 tiles per panel
   if (tpb < 1) tpb = 1;
   if (tpb > 16) tpb = 16;
-  if (tpb > tiles_per_n) tpb = (int)tiles_per_n;
   a.tiles_per_block = tpb;
-  const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
+  const long long gx = ceil_div_ll(total_tiles, tpb);
+  // widest aligned fp32 vector along the contiguous axis of the weight matrix
+  {
+    const int contig = (a.wsk == 1) ? a.K : a.M;          // row length of the source
+    int wv = 4;
+    while (wv > 1 && ((contig % wv) != 0 || ((uintptr_t)a.w % (wv * 4)) != 0)) wv >>= 1;
+    if (a.wsk != 1 && (BM % wv) != 0) wv = 1;
+    a.wvec = wv;
+  }
   auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;

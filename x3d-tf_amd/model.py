@@ -114,6 +114,7 @@ class _Plan:
         self._zero_chunks: List = []   # (numel) fp64 accumulators carved from one flat buffer
         self._zero_views: List = []
         self.bwd_stage_marks: Dict[int, int] = {}
+        self.structs: Dict = {}
 
     # -- allocation ------------------------------------------------------------------------------
     def act(self, *shape):
@@ -142,6 +143,10 @@ class _Plan:
     def rec(self, lst, name, *args):
         fn = getattr(self.lib, name)
         conv = []
+        for a in args:   # remember the argument struct of this launch (profiling tools read shapes from it)
+            st = a if isinstance(a, C.Structure) else (a[1] if isinstance(a, tuple) and len(a) > 1 and isinstance(a[1], C.Structure) else None)
+            if st is not None:
+                self.structs[(id(lst), len(lst))] = st
         for a in args:
             if isinstance(a, torch.Tensor):
                 self.keep.append(a)
