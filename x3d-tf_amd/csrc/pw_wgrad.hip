@@ -207,6 +207,8 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   const int eb = w->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, w->g, w->yraw, w->x);
   hipStream_t st = (hipStream_t)stream;
-  return w->dtype == X3D_F32 ? pw_wgrad_dispatch<float>(a, vec, xpro, st)
-                             : pw_wgrad_bf16_dispatch(a, vec, xpro, st);   // bf16 storage: bf16 matrix cores
+  if (w->dtype == X3D_F32) return pw_wgrad_dispatch<float>(a, vec, xpro, st);
+  // bf16 storage: bf16 matrix cores; v2 = aligned fast path, v1 = generic (odd point counts / widths)
+  const int rc = pw_wgrad_v2_dispatch(a, vec, xpro, st);
+  return rc >= 0 ? rc : pw_wgrad_bf16_dispatch(a, vec, xpro, st);
 }

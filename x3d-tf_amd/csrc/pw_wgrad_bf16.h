@@ -186,3 +186,210 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
     return xpro ? pw_wgrad_bf16_tpw<8, true, false>(a, st) : pw_wgrad_bf16_tpw<8, false, false>(a, st);
   return xpro ? pw_wgrad_bf16_tpw<1, true, false>(a, st) : pw_wgrad_bf16_tpw<1, false, false>(a, st);
 }
+
+// ================================================================================================
+// v2: the 16-byte-aligned fast path.
+//  * 2-D decomposition of dW: a workgroup owns MG x NG tiles of 32x32 (MG*NG <= 8, blockIdx.y / .z), so
+//    the fp32 partial it adds atomically at the end is <= 32 KB however wide the layer is, and the split
+//    over points (blockIdx.x) can be made as fine as the machine needs.  The price is that the dY rows are
+//    staged once per N-group and the X rows once per M-group (from L2 / Infinity Cache).
+//  * 64-point steps are numbered across samples, so layers with few points per sample (P = 784) still
+//    give every workgroup several steps to amortise its epilogue over.
+//  * the next step's global loads are issued into registers before the current step's MFMAs.
+//  * thread (tid>>3, tid&7) stages row (tid>>3) of every 32-row tile, points 8*(tid&7)..+7: one 16-byte
+//    vector per tile row-block and tensor.
+//  * strided shortcut (1x1x1, stride (1,2,2), valid): an output row segment of 8 points is the even
+//    elements of 16 contiguous input elements -> two 16-byte loads, no scalar gather.
+// ================================================================================================
+template <int MG, int NG, bool XPRO, bool STRIDED>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef bf16 T;
+  constexpr int BP = 64, LP = BP + 8;
+  constexpr int TPW = (MG * NG + 3) / 4;
+  bf16* As = (bf16*)smem_raw;              // [MG*32][LP]  dYraw
+  bf16* Bs = As + MG * 32 * LP;            // [NG*32][LP]  f(X)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int srow = tid >> 3, sp = (tid & 7) * 8;       // staging row within a 32-row tile, first point
+  const int co0 = blockIdx.y * MG * 32, ci0 = blockIdx.z * NG * 32;
+  const int steps_per_n = (int)((a.P + BP - 1) / BP);
+  const int total_steps = steps_per_n * a.N;
+  const int s_begin = blockIdx.x * a.steps_per_block;
+  const int s_end = min(s_begin + a.steps_per_block, total_steps);
+  const int mt_here = min(MG, (a.Cout - co0 + 31) / 32), nt_here = min(NG, (a.Cin - ci0 + 31) / 32);
+  const int ntiles = mt_here * nt_here;
+  const int nks = (TPW == 1 && ntiles <= 2) ? 4 / ntiles : 1;
+  const int ksteps = (BP / 16) / nks;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+
+  bf16x8 rg[MG], ry[MG], rx[NG], rx2[STRIDED ? NG : 1];
+  auto issue = [&](int step) {
+    const int n = step / steps_per_n;
+    const long long p = (long long)(step - n * steps_per_n) * BP + sp;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < MG; i++) {
+      const int co = co0 + i * 32 + srow;
+      rg[i] = z; ry[i] = z;
+      if (co < a.Cout && p < a.P) {
+        const long long o = ((long long)n * a.Cout + co) * a.P + p;
+        rg[i] = *(const bf16x8*)((const T*)a.g + o);
+        if (a.coef) ry[i] = *(const bf16x8*)((const T*)a.yraw + o);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+      const int ci = ci0 + i * 32 + srow;
+      rx[i] = z;
+      if constexpr (STRIDED) rx2[i] = z;
+      if (ci < a.Cin && p < a.P) {
+        if constexpr (STRIDED) {
+          // 8 output points of one output row = even elements of 16 contiguous input elements
+          const long long hw = (long long)a.Ho * a.Wo;
+          const long long t = p / hw;
+          const int rem = (int)(p - t * hw);
+          const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+          const long long src = ((long long)n * a.Cin + ci) * a.Pin + (t * a.H + (long long)ho * 2) * a.W + (long long)wo * 2;
+          rx[i] = *(const bf16x8*)((const T*)a.x + src);
+          if (wo * 2 + 8 < a.W) rx2[i] = *(const bf16x8*)((const T*)a.x + src + 8);
+        } else {
+          rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
+        }
+      }
+    }
+  };
+  auto commit = [&](int step) {
+    const int n = step / steps_per_n;
+#pragma unroll
+    for (int i = 0; i < MG; i++) {
+      const int co = co0 + i * 32 + srow;
+      bf16* dst = &As[(i * 32 + srow) * LP + sp];
+      if (a.coef && co < a.Cout) {
+        const float A = a.coef[co * 4], B = a.coef[co * 4 + 1], C = a.coef[co * 4 + 2];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
+        const int stp = step - n * steps_per_n;
+        const long long p = (long long)stp * BP + sp;
+        if (p >= a.P) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = 0.f;      // C must not leak into padded points
+        }
+        VecIO<bf16, 8>::store(dst, v);
+      } else {
+        *(bf16x8*)dst = rg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+      const int ci = ci0 + i * 32 + srow;
+      bf16* dst = &Bs[(i * 32 + srow) * LP + sp];
+      if constexpr (STRIDED) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { o[e] = rx[i][2 * e]; o[4 + e] = rx2[i][2 * e]; }
+        *(bf16x8*)dst = o;
+      } else if constexpr (XPRO) {
+        float v[8];
+        const bool inb = ci < a.Cin;
+        const float s = inb ? a.xcoef[ci * 2] : 0.f, t = inb ? a.xcoef[ci * 2 + 1] : 0.f;
+        const float g = (inb && a.xgate) ? a.xgate[(long long)n * a.Cin + ci] : 1.0f;
+        const long long p = (long long)(step - n * steps_per_n) * BP + sp;
+        const bool pin = p < a.P;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float u = (s * (float)rx[i][e] + t) * g;
+          if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
+          else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
+          v[e] = pin ? u : 0.f;
+        }
+        VecIO<bf16, 8>::store(dst, v);
+      } else {
+        *(bf16x8*)dst = rx[i];
+      }
+    }
+  };
+
+  if (s_begin < s_end) issue(s_begin);
+  for (int step = s_begin; step < s_end; ++step) {
+    __syncthreads();
+    commit(step);
+    __syncthreads();
+    if (step + 1 < s_end) issue(step + 1);
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      int id = wid + 4 * s, kpart = 0;
+      if (nks > 1) { id = wid % ntiles; kpart = wid / ntiles; }
+      if (id < ntiles) {
+        const int mt = id / nt_here, nt = id - mt * nt_here;
+        const bf16* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const bf16* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        for (int ks = 0; ks < ksteps; ks++) {
+          const bf16x8 af = *(const bf16x8*)(ap + ks * 16);
+          const bf16x8 bf = *(const bf16x8*)(bp + ks * 16);
+          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[s], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    int id = wid + 4 * s;
+    if (nks > 1) id = wid % ntiles;
+    if (id < ntiles && s_begin < s_end) {
+      const int mt = id / nt_here, nt = id - mt * nt_here;
+      const int ci = ci0 + nt * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int co = co0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+      }
+    }
+  }
+}
+
+template <int MG, int NG, bool XPRO, bool STRIDED>
+static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
+  const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
+  const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
+  const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
+  X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
+  long long spb = total_steps * gy * gz / 1536;
+  if (spb < 8) spb = 8;      // keeps the atomic partial (<= 32 KB) below ~10 % of the streamed bytes
+  if (spb > 64) spb = 64;
+  a.steps_per_block = (int)spb;
+  const long long gx = ceil_div_ll(total_steps, spb);
+  const size_t lds = (size_t)(MG + NG) * 32 * 72 * 2;
+  hipLaunchKernelGGL((pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
+  return X3D_OK;
+}
+
+template <bool XPRO, bool STRIDED>
+static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
+  const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
+  // X rows may carry the swish prologue: prefer few M-groups (each re-stages every X row of its N-group)
+  const int MG = mt >= 3 ? 4 : mt, NG = nt >= 2 ? 2 : 1;
+  if (MG == 1) return NG == 1 ? pw_wgrad_v2_launch<1, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<1, 2, XPRO, STRIDED>(a, st);
+  if (MG == 2) return NG == 1 ? pw_wgrad_v2_launch<2, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<2, 2, XPRO, STRIDED>(a, st);
+  return NG == 1 ? pw_wgrad_v2_launch<4, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<4, 2, XPRO, STRIDED>(a, st);
+}
+
+// returns -1 when the fast path does not apply (caller falls back to the generic kernel)
+static int pw_wgrad_v2_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
+  if (vec < 8) return -1;
+  if (a.stride > 1) {
+    if (a.stride != 2 || xpro || (a.Wo % 8) != 0 || (a.W % 8) != 0) return -1;
+    return pw_wgrad_v2_pick<false, true>(a, st);
+  }
+  return xpro ? pw_wgrad_v2_pick<true, false>(a, st) : pw_wgrad_v2_pick<false, false>(a, st);
+}
