@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   }
 
   // ---- register-staged prefetch of one [kc][BN] chunk
-  bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs[]
+  bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
   float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && PRO == PRO_BNBWD) ? NSV : 1];
   auto issue_loads = [&](int tile, int kc_idx) {
     const int n = tile / tiles_per_n;
@@ -109,10 +109,23 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
         xr[i] = z;
         if constexpr (PRO == PRO_BNBWD) yr[i] = z;
+        if constexpr (STRIDED) yr[i] = z;
         if (ok) {
-          const long long o = ((long long)n * a.K + gk) * a.Pin + p;
-          xr[i] = *(const bf16x8*)((const T*)a.x + o);
-          if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+          if constexpr (STRIDED) {
+            // stride-(1,2,2) 'valid' 1x1x1 conv: 8 output points of one output row are the even elements
+            // of 16 contiguous input elements -> two 16-byte loads (Wo % 8 == 0 checked by the host)
+            const long long hw = (long long)a.Ho * a.Wo;
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const long long o = ((long long)n * a.K + gk) * a.Pin + (t * a.H + (long long)ho * 2) * a.W + (long long)wo * 2;
+            xr[i] = *(const bf16x8*)((const T*)a.x + o);
+            yr[i] = *(const bf16x8*)((const T*)a.x + o + 8);
+          } else {
+            const long long o = ((long long)n * a.K + gk) * a.Pin + p;
+            xr[i] = *(const bf16x8*)((const T*)a.x + o);
+            if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+          }
         }
       } else {
         xs1[i] = 0.f;
@@ -146,7 +159,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const int gk = k0 + k;
       bf16* dst = &Xs[k * XP + pv * VEC];
       if constexpr (PRO == PRO_NONE) {
-        if constexpr (VEC == 8) *(bf16x8*)dst = xr[i];
+        if constexpr (VEC == 8 && STRIDED) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { o[e] = xr[i][2 * e]; o[4 + e] = yr[i][2 * e]; }
+          *(bf16x8*)dst = o;
+        } else if constexpr (VEC == 8) *(bf16x8*)dst = xr[i];
         else dst[0] = (bf16)xs1[i];
       } else {
         float val[VEC];
@@ -295,6 +313,20 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         const long long hw = (long long)a.eH * a.eW;
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
         const long long T_ = a.P / hw;
+        if (OVEC == 8 && (a.eW & 7) == 0) {
+          // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution
+          // values (one 8-byte load)
+          const long long t = p / hw;
+          const int rem = (int)(p - t * hw);
+          const int h = rem / a.eW, w = rem - h * a.eW;
+          if ((h & 1) == 0) {
+            const long long oa = ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
+            float ad[4];
+            VecIO<T, 4>::load((const T*)a.add + oa, ad);
+#pragma unroll
+            for (int e = 0; e < 4; e++) val[2 * e] += ad[e];
+          }
+        } else
         for (int e = 0; e < nvalid; e++) {
           const long long pe = p + e;
           const long long t = pe / hw;
@@ -393,6 +425,8 @@ template <int PRO, int EPI>
 static int pw_bf16_launch_vec(PwGemmArgs& a, int vec, int ovec, hipStream_t st) {
   if (a.stride > 1) {
     if constexpr (PRO == PRO_NONE && EPI == EPI_STATS) {
+      const bool vgather = a.stride == 2 && (a.Wo % 8) == 0 && (a.W % 8) == 0 && vec >= 8;
+      if (vgather && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, true, 8>(a, st);
       if (ovec >= 8) return pw_bf16_launch_tile<1, PRO, EPI, true, 8>(a, st);
       return pw_bf16_launch_tile<1, PRO, EPI, true, 1>(a, st);
     } else {

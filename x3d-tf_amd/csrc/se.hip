@@ -89,27 +89,31 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a
 }
 
 // stage 2 (one thread per channel): BN_b backward over du = dv*gate + dpool/P, then per-(n,c) coefficients
-__global__ void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
+// one 64-lane workgroup per channel: lanes split the samples, fp64 shuffle reduction
+__global__ __launch_bounds__(64) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   const int C = a.C, N = a.N;
   double sdu = 0.0, sdub = 0.0;
-  for (int n = 0; n < N; n++) {
+  for (int n = lane; n < N; n += 64) {
     const long long i = (long long)n * C + c;
     const double g = has_se ? (double)a.gate[i] : 1.0;
     const double dp = has_se ? (double)a.scratch[i] : 0.0;
     sdu += g * a.nc_sums[i * 2] + dp;
     sdub += g * a.nc_sums[i * 2 + 1] + (has_se ? dp / a.P * a.pool_sums[i] : 0.0);
   }
+  sdu = wave_sum_d(sdu);
+  sdub = wave_sum_d(sdub);
   const double count = (double)N * a.P;
   const double mean = a.b_mean_invstd[c * 2], invstd = a.b_mean_invstd[c * 2 + 1];
   const double dga = (sdub - mean * sdu) * invstd;
   const double k1 = (double)a.gamma_b[c] * invstd;
   const double B = -k1 * invstd * dga / count;
   const double Cc = -k1 * sdu / count - B * mean;
-  a.dgamma_b[c] += (float)dga;
-  a.dbeta_b[c] += (float)sdu;
-  for (int n = 0; n < N; n++) {
+  if (lane == 0) {
+    a.dgamma_b[c] += (float)dga;
+    a.dbeta_b[c] += (float)sdu;
+  }
+  for (int n = lane; n < N; n += 64) {
     const long long i = (long long)n * C + c;
     const double g = has_se ? (double)a.gate[i] : 1.0;
     const double dp = has_se ? (double)a.scratch[i] : 0.0;
@@ -134,7 +138,7 @@ extern "C" int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(se_bwd_kernel, dim3(a->N), dim3(256), 0, st, *a);
     X3D_LAUNCH_CHECK("se_bwd");
   }
-  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(ceil_div(a->C, 64)), dim3(64), 0, st, *a, has_se);
+  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(a->C), dim3(64), 0, st, *a, has_se);
   X3D_LAUNCH_CHECK("bnb_bwd");
   return X3D_OK;
 }
