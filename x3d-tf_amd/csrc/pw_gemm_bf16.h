@@ -390,6 +390,10 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
   int tpb = (int)(total_tiles * gy / 1536);      // aim for >= ~6 workgroups per CU, <= 16 tiles per panel
   if (tpb < 1) tpb = 1;
+  // a wide weight panel (K*BM bf16, converted from fp32 by every workgroup) must be amortised over several
+  // tiles even if that leaves fewer workgroups than CUs: measured 4x on the K=432 layers
+  const int tpb_min = a.K >= 384 ? 8 : (a.K >= 192 ? 4 : (a.K >= 96 ? 2 : 1));
+  if (tpb < tpb_min) tpb = tpb_min;
   if (tpb > 16) tpb = 16;
   a.tiles_per_block = tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
