@@ -1,0 +1,210 @@
+// x3d_dw3d_fwd: channelwise 3x3x3 convolution forward (design notes in dw_common.h)
+#include "dw_common.h"
+
+struct DwFwdArgs {
+  DwGeom g;
+  const void* x; const float* w; void* y;
+  const float* ss; int act;
+  double* stats; double* pool;
+};
+
+// ================================================================================================
+// forward.  NSV = staging vectors per thread held in registers for the prefetch (0: direct staging)
+// ================================================================================================
+// CV > 0: the staging vector width (CV elements) and SW-aligned strips are guaranteed by the host, so every
+// width / alignment decision is compile-time (the runtime-width path costs ~300 scalar instructions per plane)
+template <typename T, int S, int SW, int NSV, int CV>
+__global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwGeom& g = a.g;
+  constexpr int WIN = (SW - 1) * S + 3;
+  constexpr int NS = NSV > 0 ? NSV : 1;
+  const int plane_sz = g.RIN * g.LP;
+  float* scratch = lds + plane_sz;
+
+  int b = blockIdx.x;
+  const int tile = b % g.ntile_h; b /= g.ntile_h;
+  const int c = b % g.C;
+  const int n = b / g.C;
+  const int h0 = tile * g.TH;
+  const int th_here = min(g.TH, g.Ho - h0);
+  const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
+  const bool active = r < th_here;
+  const int ho = h0 + r, wo0 = sidx * SW;
+
+  for (int i = threadIdx.x; i < plane_sz; i += blockDim.x) lds[i] = 0.f;
+
+  float wgt[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  const bool affine = a.ss != nullptr;
+  const float sc = affine ? a.ss[c * 2] : 1.f, sh = affine ? a.ss[c * 2 + 1] : 0.f;
+  const int act = a.act;
+  auto xf = [=](float v) {
+    float u = sc * v + sh;
+    return act == X3D_ACT_RELU ? fmaxf(u, 0.f) : u;
+  };
+
+  const long long iplane = (long long)g.H * g.W, oplane = (long long)g.Ho * g.Wo;
+  const T* xin = (const T*)a.x + ((long long)n * g.C + c) * g.T * iplane;
+  T* yout = (T*)a.y + ((long long)n * g.C + c) * g.T * oplane;
+  const int row0 = h0 * S - g.ph;
+  const int vec = CV > 0 ? CV : g.vec;
+
+  StageMap<NS> map;
+  Raw raw[NS];
+  if constexpr (NSV > 0) {
+    map.build(g.RIN, g.LP, row0, g.H, g.W, g.pw, vec);
+#pragma unroll
+    for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + map.goff[i], vec);
+  }
+
+  float acc0[SW], acc1[SW], acc2[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
+  float s1 = 0.f, s2 = 0.f;
+
+  // every strip is full and SW-aligned when Wo % SW == 0: one 8/16-byte store per thread and plane instead
+  // of SW two-byte stores (the scalar stores, not HBM, were the limiter of the stride-1 layers)
+  const bool vstore = (CV > 0 && SW > 1) || ((SW > 1) && (g.Wo % SW == 0) && (((uintptr_t)a.y) % (SW * sizeof(T)) == 0));
+  auto store_plane = [&](int t, const float (&v)[SW]) {
+    if (!active) return;
+    T* dst = yout + t * oplane + (long long)ho * g.Wo + wo0;
+    if (vstore) {
+      VecIO<T, SW>::store(dst, v);
+#pragma unroll
+      for (int i = 0; i < SW; i++) {
+        const float vr = round_to<T>(v[i]);
+        s1 += vr;
+        s2 += vr * vr;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SW; i++) {
+        if (wo0 + i < g.Wo) {
+          dst[i] = from_f<T>(v[i]);
+          const float vr = round_to<T>(v[i]);
+          s1 += vr;
+          s2 += vr * vr;
+        }
+      }
+    }
+  };
+
+  for (int t = 0; t < g.T; ++t) {
+    __syncthreads();  // zero-fill / previous plane's readers done
+    if constexpr (NSV > 0) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        if (map.goff[i] >= 0) {
+          float* d = lds + map.loff[i];
+#pragma unroll
+          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = xf(raw_get<T>(raw[i], e));
+        }
+      }
+    } else {
+      stage_direct<T>(xin + t * iplane, lds, g.RIN, g.LP, row0, g.H, g.W, g.pw, vec, xf);
+    }
+    __syncthreads();
+    if constexpr (NSV > 0) {  // next plane's loads fly while this one is consumed
+      if (t + 1 < g.T) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + (t + 1) * iplane + map.goff[i], vec);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) {
+        float win[WIN];
+        const float* row = lds + (r * S + kh) * g.LP + wo0 * S;
+#pragma unroll
+        for (int j = 0; j < WIN; j++) win[j] = row[j];
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+          for (int i = 0; i < SW; i++) {
+            const float v = win[i * S + kw];
+            acc0[i] += wgt[18 + kh * 3 + kw] * v;  // out[t-1] sees this plane through kt = 2
+            acc1[i] += wgt[9 + kh * 3 + kw] * v;   // out[t]   through kt = 1
+            acc2[i] += wgt[kh * 3 + kw] * v;       // out[t+1] through kt = 0
+          }
+        }
+      }
+    }
+    if (t >= 1) store_plane(t - 1, acc0);
+#pragma unroll
+    for (int i = 0; i < SW; i++) { acc0[i] = acc1[i]; acc1[i] = acc2[i]; acc2[i] = 0.f; }
+  }
+  store_plane(g.T - 1, acc0);
+
+  if (a.stats || a.pool) {
+    float red[2] = {s1, s2};
+    block_sum<2>(red, scratch);
+    if (threadIdx.x == 0) {
+      if (a.stats) {
+        atomic_add_d(&a.stats[c * 2], (double)red[0]);
+        atomic_add_d(&a.stats[c * 2 + 1], (double)red[1]);
+      }
+      if (a.pool) atomic_add_d(&a.pool[(long long)n * g.C + c], (double)red[0]);
+    }
+  }
+}
+
+template <typename T, int S, int SW, int CV>
+static void dw_fwd_launch_cv(const DwFwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  if (nsv <= 2) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 2, CV>), dim3(grid), dim3(bd), lds, st, a);
+  else if (nsv <= 4) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 4, CV>), dim3(grid), dim3(bd), lds, st, a);
+  else hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 0, 0>), dim3(grid), dim3(bd), lds, st, a);
+}
+template <typename T, int S, int SW>
+static void dw_fwd_launch_nsv(const DwFwdArgs& a, int nsv, int cv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  switch (cv) {
+    case 8: if constexpr (sizeof(T) == 2) { dw_fwd_launch_cv<T, S, SW, 8>(a, nsv, grid, bd, lds, st); break; }
+    case 4: dw_fwd_launch_cv<T, S, SW, 4>(a, nsv, grid, bd, lds, st); break;
+    case 2: dw_fwd_launch_cv<T, S, SW, 2>(a, nsv, grid, bd, lds, st); break;
+    case 1: dw_fwd_launch_cv<T, S, SW, 1>(a, nsv, grid, bd, lds, st); break;
+    default: dw_fwd_launch_cv<T, S, SW, 0>(a, nsv, grid, bd, lds, st); break;
+  }
+}
+
+template <typename T, int S>
+static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
+  DwFwdArgs a;
+  a.x = f->x; a.w = f->w; a.y = f->y; a.ss = f->in_scale_shift; a.act = f->in_act;
+  a.stats = f->stats; a.pool = f->pool;
+  const int Wo = ceil_div(f->W, S);
+  const int SW = dw_pick_sw(Wo);
+  int bd; size_t ldsf;
+  if (dw_geom(a.g, f->N, f->C, f->T, f->H, f->W, S, SW, sizeof(T), f->x, nullptr, nullptr, &bd, &ldsf)) {
+    x3d_set_error("dw3d_fwd: row of %d outputs does not fit one workgroup", Wo);
+    return X3D_ERR_INVALID;
+  }
+  const size_t lds = (ldsf + 2 * 4 + 8) * sizeof(float);
+  X3D_REQUIRE(lds <= 64 * 1024, "dw3d_fwd: tile needs %zu B of LDS", lds);
+  const long long grid = (long long)f->N * f->C * a.g.ntile_h;
+  X3D_REQUIRE(grid < (1ll << 31), "dw3d_fwd: grid too large");
+  const int nsv = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd);
+  // compile-time staging width when every output strip is whole and SW-aligned (always true for SW == 1)
+  const bool strips_ok = (a.g.Wo % SW == 0) && (((uintptr_t)f->y) % (SW * sizeof(T)) == 0);
+  const int cv = strips_ok ? a.g.vec : 0;
+  switch (SW) {
+    case 4: dw_fwd_launch_nsv<T, S, 4>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
+    case 2: dw_fwd_launch_nsv<T, S, 2>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
+    default: dw_fwd_launch_nsv<T, S, 1>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
+  }
+  X3D_LAUNCH_CHECK("dw3d_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {
+  X3D_REQUIRE(f && f->x && f->w && f->y, "dw3d_fwd: null pointer");
+  X3D_REQUIRE(f->stride == 1 || f->stride == 2, "dw3d_fwd: stride must be 1 or 2");
+  X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_fwd: bad extents");
+  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_fwd: bad dtype");
+  X3D_REQUIRE(f->in_act == X3D_ACT_NONE || f->in_act == X3D_ACT_RELU, "dw3d_fwd: prologue act must be none/relu");
+  hipStream_t st = (hipStream_t)stream;
+  if (f->dtype == X3D_F32)
+    return f->stride == 1 ? dw_fwd_launch<float, 1>(f, st) : dw_fwd_launch<float, 2>(f, st);
+  return f->stride == 1 ? dw_fwd_launch<bf16, 1>(f, st) : dw_fwd_launch<bf16, 2>(f, st);
+}
+
