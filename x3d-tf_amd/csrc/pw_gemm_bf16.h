@@ -39,9 +39,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   constexpr int ROWS_PT = BM / 16;                    // output rows owned per thread in the epilogue pass
   const int Kp = a.KC;                                // K rounded up to 16
   const int WP = Kp + 8;
+  // the activation chunk and the fp32 output tile are never live together: they share one LDS region
+  // (a 34 KB saving that keeps two workgroups per CU up to K ~ 300)
+  constexpr size_t XO_BYTES = ((size_t)KCH * XP * 2 > (size_t)BM * OP * 4) ? (size_t)KCH * XP * 2 : (size_t)BM * OP * 4;
   bf16* Xs = (bf16*)smem_raw;                         // [KCH][XP]
-  float* Os = (float*)(smem_raw + (size_t)KCH * XP * 2);   // [BM][OP]
-  bf16* Ws = (bf16*)(smem_raw + (size_t)KCH * XP * 2 + (size_t)BM * OP * 4);   // [BM][WP]
+  float* Os = (float*)smem_raw;                       // [BM][OP]   (aliases Xs)
+  bf16* Ws = (bf16*)(smem_raw + XO_BYTES);            // [BM][WP]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     }
 
     // ---- accumulators -> LDS output tile (col = lane&31 -> point, rows in registers)
+    __syncthreads();   // Os aliases Xs: every wave must be done with the last chunk's fragments
 #pragma unroll
     for (int s = 0; s < MT; s++)
 #pragma unroll
@@ -383,7 +387,8 @@ template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, BN = PWB_BN;
   a.KC = (a.K + 15) & ~15;
-  const size_t lds = (size_t)PWB_KCH * PWB_XP * 2 + (size_t)BM * PWB_OP * 4 + (size_t)BM * (a.KC + 8) * 2;
+  const size_t xb = (size_t)PWB_KCH * PWB_XP * 2, ob = (size_t)BM * PWB_OP * 4;
+  const size_t lds = (xb > ob ? xb : ob) + (size_t)BM * (a.KC + 8) * 2;
   X3D_REQUIRE(lds <= 160 * 1024, "pw_gemm_bf16: K = %d needs %zu B of LDS", a.K, lds);
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
@@ -420,7 +425,9 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
 
 template <int VEC, int PRO, int EPI, bool STRIDED, int OVEC>
 static int pw_bf16_launch_tile(PwGemmArgs& a, hipStream_t st) {
-  if (a.M <= 32) return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
+  // 32-row panels when the panel is wide (K >= 320): 48 KB of LDS per workgroup -> three per CU instead of one;
+  // the extra row blocks re-read the activation tile through L2
+  if (a.M <= 32 || a.K >= 320) return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
   return pw_bf16_launch_cfg<VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
 }
 
