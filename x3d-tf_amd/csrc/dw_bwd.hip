@@ -142,9 +142,8 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
         for (int i = 0; i < NA; i++) {
           const float av = ar[q][i];
           gv[i] = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
-          const float gr = round_to<T>(gv[i]);
-          s1 += gr;
-          s2 += gr * av;
+          s1 += gv[i];
+          s2 += gv[i] * av;
         }
         VecIO<T, NA>::store(gap + base + wA0, gv);
       } else {
@@ -155,9 +154,8 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
             const float av = ar[q][i];
             const float gv = (sc * av + sh > 0.f) ? v[q][i] : 0.f;
             gap[base + w] = from_f<T>(gv);
-            const float gr = round_to<T>(gv);
-            s1 += gr;
-            s2 += gr * av;
+            s1 += gv;
+            s2 += gv * av;
           }
         }
       }

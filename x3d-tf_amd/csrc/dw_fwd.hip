@@ -74,18 +74,16 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
       VecIO<T, SW>::store(dst, v);
 #pragma unroll
       for (int i = 0; i < SW; i++) {
-        const float vr = round_to<T>(v[i]);
-        s1 += vr;
-        s2 += vr * vr;
+        s1 += v[i];
+        s2 += v[i] * v[i];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < SW; i++) {
         if (wo0 + i < g.Wo) {
           dst[i] = from_f<T>(v[i]);
-          const float vr = round_to<T>(v[i]);
-          s1 += vr;
-          s2 += vr * vr;
+          s1 += v[i];
+          s2 += v[i] * v[i];
         }
       }
     }

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
             xr[i] = *(const bf16x8*)((const T*)a.x + o);
             yr[i] = *(const bf16x8*)((const T*)a.x + o + 8);
           } else {
-            const long long o = ((long long)n * a.K + gk) * a.Pin + p;
+            // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
+            const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
             xr[i] = *(const bf16x8*)((const T*)a.x + o);
             if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
           }
@@ -354,10 +355,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         for (int e = 0; e < 8; e++) {
           const float dv = val[e] * swish_grad_((sb * b[e] + tb) * g);
           val[e] = dv;
-          if (e < nvalid) {
-            const float dvr = round_to<T>(dv);
-            st1[i] += dvr;
-            st2[i] += dvr * b[e];
+          if (e < nvalid) {   // sums of the fp32 values: equal to the sums of the stored (rounded) ones to ~2^-9/sqrt(count)
+            st1[i] += dv;
+            st2[i] += dv * b[e];
           }
         }
       }
@@ -365,9 +365,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           if (e < nvalid) {
-            const float vr = round_to<T>(val[e]);
-            st1[i] += vr;
-            st2[i] += vr * vr;
+            st1[i] += val[e];
+            st2[i] += val[e] * val[e];
           }
         }
       }
