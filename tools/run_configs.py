@@ -1,0 +1,53 @@
+"""Runs the other BASELINE.json configurations end to end on one MI355X and reports throughput
+(they are parity-test cases, not bench lines): S fp32 B=32 train, L bf16 train, XL 30-view inference."""
+import os, sys, time, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import x3d_tf_amd as x
+from x3d_tf_amd.model import X3D
+from x3d_tf_amd.train import Trainer
+
+def train_rate(variant, batch, t, s, dtype, steps=5):
+    cfg = x.get_config(variant)
+    m = X3D(cfg, dtype=dtype, device="cuda:0")
+    tr = Trainer(m, cfg)
+    clips = torch.randn(batch, t, s, s, 3, device="cuda").to(dtype)
+    labels = torch.randint(0, 400, (batch,), device="cuda")
+    for _ in range(2):
+        pl = tr.step(clips, labels, 0.01)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        pl = tr.step(clips, labels, 0.01)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    loss = float(tr.loss(pl).item())
+    del m, tr
+    torch.cuda.empty_cache()
+    return dict(variant=variant, mode="train", dtype=str(dtype), batch=batch, clip=f"{t}x{s}x{s}", clips_per_s=steps * batch / el,
+                ms_per_step=1e3 * el / steps, loss=loss, mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+
+def infer_rate(variant, videos, views, crops, t, s, dtype, steps=5):
+    cfg = x.get_config(variant, ["TEST.NUM_TEMPORAL_VIEWS", views, "TEST.NUM_SPATIAL_CROPS", crops])
+    m = X3D(cfg, dtype=dtype, device="cuda:0")
+    n = videos * views * crops
+    clips = torch.randn(n, t, s, s, 3, device="cuda").to(dtype)
+    for _ in range(2):
+        out = m(clips, training=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = m(clips, training=False)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out).all()) and tuple(out.shape) == (videos, 400)
+    del m
+    torch.cuda.empty_cache()
+    return dict(variant=variant, mode="inference", dtype=str(dtype), videos=videos, views=views * crops, clip=f"{t}x{s}x{s}",
+                clips_per_s=steps * n / el, videos_per_s=steps * videos / el, ok=ok)
+
+if __name__ == "__main__":
+    res = []
+    res.append(train_rate("S", 32, 13, 160, torch.float32))          # config 2
+    res.append(train_rate("L", 16, 16, 312, torch.bfloat16))         # config 4 (yaml batch 16)
+    res.append(train_rate("XL", 8, 16, 312, torch.bfloat16))
+    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.bfloat16))  # config 5 (30 views / video), bf16 instead of fp16
+    res.append(infer_rate("XS", 8, 10, 1, 4, 160, torch.float32))    # config 1 on the GPU
+    for r in res:
+        print(json.dumps(r))
