@@ -37,13 +37,11 @@ CLIP = {"XS": (4, 160), "S": (13, 160), "M": (16, 224), "L": (16, 312), "XL": (1
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 measured copy ceiling
 
 
-def dw_key(name, stride, w):
-    wo = -(-w // stride)
-    sw = 4 if wo >= 20 else (2 if wo >= 10 else 1)
-    if name == "x3d_dw3d_bwd" and stride == 2 and sw > 2:
-        sw = 2
-    kind = "dw3d_fwd_kernel" if name == "x3d_dw3d_fwd" else "dw3d_bwd_kernel"
-    return f"{kind}<bf16|f32, S={stride}, SW={sw}>"
+def dw_key(pl, lst, i):
+    """Name of the kernel instantiation this recorded depthwise launch runs -- asked of the library's own
+    dispatch (x3d_dw3d_kernel_name), so it is the kernel the rocprofv3 summary lists."""
+    from x3d_tf_amd import hip
+    return hip.dw3d_kernel_name(pl.structs[(id(lst), i)])
 
 
 class KernelTimer:
@@ -63,12 +61,12 @@ class KernelTimer:
             b = B.spec
             x_el = pl.n * b.inner * pl.t * B.hh * B.ww
             y_el = pl.n * b.inner * pl.t * B.ho * B.wo
-            s[3], s[4] = dw_key(s[2], b.stride, B.ww), elem_bytes * (x_el + y_el)
+            s[3], s[4] = dw_key(pl, pl.fwd, s[1]), elem_bytes * (x_el + y_el)
         for s, B in zip(bwd_slots, reversed(pl.blocks)):
             b = B.spec
             x_el = pl.n * b.inner * pl.t * B.hh * B.ww
             y_el = pl.n * b.inner * pl.t * B.ho * B.wo
-            s[3], s[4] = dw_key(s[2], b.stride, B.ww), elem_bytes * (2 * x_el + y_el)
+            s[3], s[4] = dw_key(pl, pl.bwd, s[1]), elem_bytes * (2 * x_el + y_el)
         self.events = []
 
     def wrap(self, pl):
@@ -212,6 +210,16 @@ def main():
         w = A.workload(model.arch, t, s, s)
         eb = 2 if dtype == torch.bfloat16 else 4
         step_bytes_per_clip = 3 * w["total_elements"] * eb
+        # HBM traffic per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py:
+        # separate FETCH_SIZE / WRITE_SIZE runs, (2*FETCH + WRITE) * 1024 on gfx950); null if not collected
+        # for this exact instantiation.
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if dom is not None and os.path.exists(pmc_file) and args.variant == "M" and B == 64:
+            with open(pmc_file) as fh:
+                rec = json.load(fh).get(dom["kernel"])
+            if rec and rec.get("dtype", args.dtype) == args.dtype:
+                traffic = rec["traffic_bytes_per_launch"]
         out = {
             "metric": "clips/sec (fwd+bwd) X3D-%s %dx%d^2; depthwise HBM GB/s" % (args.variant, t, s),
             "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,7 +231,7 @@ def main():
             "loss": loss,
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "launches": dom["launches"], "avg_us": dom["avg_us"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
             "kernels": kernels,

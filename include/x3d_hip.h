@@ -18,6 +18,9 @@
 #ifndef X3D_HIP_H
 #define X3D_HIP_H
 
+#include <stddef.h>
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -172,6 +175,11 @@ typedef struct {
   int N, C, T, H, W, stride, dtype;
 } x3d_dw3d_bwd_args;
 int x3d_dw3d_bwd(const x3d_dw3d_bwd_args* a, void* stream);
+/* Which kernel instantiation a launch with these arguments runs ("dw3d_fwd_kernel<bf16, S, SW, NSV, CV>"),
+ * without launching anything: the dispatch of x3d_dw3d_fwd / x3d_dw3d_bwd in dry-run mode.  Used by
+ * bench.py so that its roofline row names the same kernel as the rocprofv3 summary.  Exactly one of
+ * fwd / bwd is non-NULL.  Returns X3D_OK and a NUL-terminated string in out[0..cap). */
+int x3d_dw3d_kernel_name(const x3d_dw3d_fwd_args* fwd, const x3d_dw3d_bwd_args* bwd, char* out, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * K7/K8  squeeze-excite MLP: se_pool -> se_fc1(+bias, ReLU) -> se_fc2(+bias, sigmoid)
@@ -260,6 +268,12 @@ int x3d_l2_sumsq(const float* w, const unsigned char* l2_mask, double* out, long
 /* layout helpers at the module boundary: NTHWC (reference, model.py:113) <-> NCTHW (internal) */
 int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C,
                        long long P, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * host helper: CRC32C (Castagnoli), the checksum of TF tensor-bundle checkpoints
+ *     (reference train.py:151-158 / utils.py restore path reads such files through tf.train.Checkpoint)
+ * ------------------------------------------------------------------------------------------ */
+uint32_t x3d_crc32c(const void* data, size_t n, uint32_t crc);
 
 #ifdef __cplusplus
 }

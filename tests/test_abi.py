@@ -51,3 +51,24 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(hip.X3DHipError):
         hip.load(str(tmp_path / "libx3d_hip.so"))
+
+
+def test_dw3d_kernel_name_dry_run():
+    """x3d_dw3d_kernel_name runs the depthwise dispatch without launching (no GPU needed): the names are the
+    instantiations bench.py's roofline row and the rocprofv3 summaries refer to."""
+    f = hip.Dw3dFwdArgs()
+    f.x = f.w = f.y = 256
+    f.dtype = hip.BF16
+    f.N, f.C, f.T, f.H, f.W, f.stride = 64, 54, 16, 112, 112, 2
+    assert hip.dw3d_kernel_name(f) == "dw3d_fwd_kernel<bf16, 2, 4, 2, 8>"
+    b = hip.Dw3dBwdArgs()
+    b.dv = b.braw = b.coef_nc = b.araw = b.a_scale_shift = b.w = b.ga = b.a_sums = b.dw = 256
+    b.dtype = hip.BF16
+    b.N, b.C, b.T, b.H, b.W, b.stride = 64, 108, 16, 56, 56, 1
+    name = hip.dw3d_kernel_name(b)
+    assert name.startswith("dw3d_bwd_kernel<bf16, 1, 4, "), name
+    f.stride = 3
+    import pytest
+    with pytest.raises(hip.X3DHipError):
+        hip.dw3d_kernel_name(f)
+    assert hip.load().x3d_crc32c(b"123456789", 9, 0) == 0xE3069283

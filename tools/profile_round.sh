@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-end measurement on the GPU box:  bash tools/profile_round.sh <tag> [pmc]
+#   bench line, rocprofv3 kernel-trace stats of the same command, per-launch layer timing and (with "pmc")
+#   two separate PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950) for HBM traffic.
+# Everything lands in gpurun_out/<tag>/; copy the summaries worth judging into profiles/.
+set -u
+TAG=${1:-rXX}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 "$REPO/bench.py" --steps 10 --warmup 3 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+tail -c 600 "$OUT/bench_line.json"
+rocprofv3 -M --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+python3 "$REPO/tools/bench_layers.py" M 64 > "$OUT/per_launch_layers.txt" 2>&1
+if [ "${2:-}" = "pmc" ]; then
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 -M --pmc $ctr --kernel-trace --output-format csv -d "$OUT/pmc_$ctr" -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$ctr.json" 2> "$OUT/pmc_$ctr.err"
+  done
+  python3 "$REPO/tools/pmc_traffic.py" "$OUT" > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_traffic.err"
+  # the raw per-dispatch CSVs are large; keep only the summary
+  rm -rf "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
+fi
+rm -rf "$OUT/prof"
+ls -la "$OUT"

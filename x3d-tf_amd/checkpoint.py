@@ -50,12 +50,7 @@ def crc32c(data: bytes, crc: int = 0) -> int:
     a table-driven Python loop otherwise."""
     try:
         from . import hip
-        import ctypes as C
-        lib = hip.load()
-        fn = lib.x3d_crc32c
-        fn.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
-        fn.restype = C.c_uint32
-        return int(fn(data, len(data), crc))
+        return int(hip.load().x3d_crc32c(bytes(data), len(data), crc))
     except Exception:
         tbl = _crc_table()
         c = crc ^ 0xFFFFFFFF

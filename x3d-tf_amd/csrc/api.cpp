@@ -13,6 +13,9 @@ void x3d_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+struct X3dDescribe { char* out; int cap; };
+thread_local X3dDescribe x3d_describe = {nullptr, 0};
+
 extern "C" const char* x3d_last_error(void) { return g_err; }
 extern "C" int x3d_version(void) { return 100; }
 

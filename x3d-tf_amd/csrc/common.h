@@ -38,6 +38,11 @@ void x3d_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// x3d_dw3d_kernel_name(): when this buffer is set the depthwise launch helpers run their whole dispatch
+// but write the chosen instantiation's name here instead of launching it
+struct X3dDescribe { char* out; int cap; };
+extern thread_local X3dDescribe x3d_describe;
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -288,6 +288,12 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 
 template <typename T, int S, int SW, int CV>
 static void dw_bwd_launch_cv(const DwBwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  if (x3d_describe.out) {
+    const bool gen = nsv > 2;
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+             S, SW, gen ? 0 : (nsv <= 1 ? 1 : 2), gen ? 0 : CV);
+    return;
+  }
   if (nsv <= 1) hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 1, CV>), dim3(grid), dim3(bd), lds, st, a);
   else if (nsv <= 2) hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 2, CV>), dim3(grid), dim3(bd), lds, st, a);
   else hipLaunchKernelGGL((dw3d_bwd_kernel<T, S, SW, 0, 0>), dim3(grid), dim3(bd), lds, st, a);
@@ -342,6 +348,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     case 2: dw_bwd_launch_nsv<T, S, 2>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
     default: dw_bwd_launch_nsv<T, S, 1>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
   }
+  if (x3d_describe.out) return X3D_OK;
   X3D_LAUNCH_CHECK("dw3d_bwd");
   return X3D_OK;
 }

@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 
 template <typename T, int S, int SW, int CV>
 static void dw_fwd_launch_cv(const DwFwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  if (x3d_describe.out) {
+    const bool gen = nsv > 4;
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+             S, SW, gen ? 0 : (nsv <= 2 ? 2 : 4), gen ? 0 : CV);
+    return;
+  }
   if (nsv <= 2) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 2, CV>), dim3(grid), dim3(bd), lds, st, a);
   else if (nsv <= 4) hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 4, CV>), dim3(grid), dim3(bd), lds, st, a);
   else hipLaunchKernelGGL((dw3d_fwd_kernel<T, S, SW, 0, 0>), dim3(grid), dim3(bd), lds, st, a);
@@ -190,8 +196,18 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
     case 2: dw_fwd_launch_nsv<T, S, 2>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
     default: dw_fwd_launch_nsv<T, S, 1>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
   }
+  if (x3d_describe.out) return X3D_OK;
   X3D_LAUNCH_CHECK("dw3d_fwd");
   return X3D_OK;
+}
+
+extern "C" int x3d_dw3d_kernel_name(const x3d_dw3d_fwd_args* fwd, const x3d_dw3d_bwd_args* bwd, char* out, int cap) {
+  X3D_REQUIRE(out && cap > 0 && ((fwd != nullptr) != (bwd != nullptr)), "dw3d_kernel_name: pass exactly one of fwd / bwd");
+  out[0] = 0;
+  x3d_describe = {out, cap};
+  const int rc = fwd ? x3d_dw3d_fwd(fwd, nullptr) : x3d_dw3d_bwd(bwd, nullptr);
+  x3d_describe = {nullptr, 0};
+  return rc;
 }
 
 extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {

@@ -75,6 +75,7 @@ _SIGS = {
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
     "x3d_dw3d_fwd": ([C.POINTER(Dw3dFwdArgs), _vp], _i),
     "x3d_dw3d_bwd": ([C.POINTER(Dw3dBwdArgs), _vp], _i),
+    "x3d_dw3d_kernel_name": ([C.POINTER(Dw3dFwdArgs), C.POINTER(Dw3dBwdArgs), C.c_char_p, _i], _i),
     "x3d_se_fwd": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_se_bnb_bwd": ([C.POINTER(SeBnbBwdArgs), _vp], _i),
     "x3d_tail_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
@@ -88,6 +89,7 @@ _SIGS = {
     "x3d_sgd_nesterov": ([_vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp], _i),
     "x3d_l2_sumsq": ([_vp, _vp, _vp, _ll, _vp], _i),
     "x3d_nthwc_to_ncthw": ([_vp, _i, _vp, _i, _i, _i, _ll, _vp], _i),
+    "x3d_crc32c": ([C.c_char_p, C.c_size_t, C.c_uint32], C.c_uint32),
 }
 
 _lib = None
@@ -116,6 +118,17 @@ def load(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def dw3d_kernel_name(args):
+    """Instantiation x3d_dw3d_fwd / x3d_dw3d_bwd would launch for this argument struct (no launch)."""
+    buf = C.create_string_buffer(128)
+    fwd = C.byref(args) if isinstance(args, Dw3dFwdArgs) else None
+    bwd = C.byref(args) if isinstance(args, Dw3dBwdArgs) else None
+    rc = load().x3d_dw3d_kernel_name(fwd, bwd, buf, 128)
+    if rc != 0:
+        raise X3DHipError(load().x3d_last_error().decode())
+    return buf.value.decode()
 
 
 def dtype_code(dt):
