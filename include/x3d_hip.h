@@ -106,6 +106,7 @@ typedef struct {
   const float* in_gate;        /* [N][Cin] or NULL */
   int in_act;
   int N, Cin, Cout, T, H, W, stride, dtype;
+  const void* w_panel;         /* optional (bf16 path): forward panel from x3d_pw_pack_weights, else NULL */
 } x3d_pw_fwd_args;
 int x3d_pw_fwd(const x3d_pw_fwd_args* a, void* stream);
 
@@ -124,8 +125,25 @@ typedef struct {
   const float* gate;           /* EPI_SWISH_BWD: [N][Cin] or NULL */
   double* nc_sums;             /* EPI_SWISH_BWD: [N][Cin][2] += (sum dv, sum dv*braw) */
   int N, Cin, Cout, T, H, W, dtype; /* T,H,W: extents of the P = T*H*W output points */
+  const void* w_panel;         /* optional (bf16 path): dgrad panel from x3d_pw_pack_weights, else NULL */
 } x3d_pw_dgrad_args;
 int x3d_pw_dgrad(const x3d_pw_dgrad_args* a, void* stream);
+
+/* bf16 weight panels.  The bf16 GEMMs keep their A operand (the weights) resident in LDS as bf16 rows of
+ * pitch roundup(K,16)+8; without a panel every workgroup converts its rows from the fp32 master weights
+ * (a latency-serialised gather that dominates small-P layers).  x3d_pw_pack_weights converts every
+ * pointwise weight of the model once per step, in ONE launch, into the exact LDS image:
+ *   fwd_panel   bf16 [roundup(Cout,32)][roundup(Cin,16)+8]   row co, column ci   (zero padded)
+ *   dgrad_panel bf16 [roundup(Cin,32)][roundup(Cout,16)+8]   row ci, column co   (may be NULL)
+ * `items` is an array in DEVICE memory; x3d_pw_panel_elems gives the element count of a panel. */
+typedef struct {
+  const float* w;              /* [Cout][Cin] fp32 */
+  void* fwd_panel;
+  void* dgrad_panel;
+  int Cout, Cin;
+} x3d_pw_pack_item;
+long long x3d_pw_panel_elems(int rows, int cols);
+int x3d_pw_pack_weights(const x3d_pw_pack_item* items, int n_items, void* stream);
 
 /* weight gradient: dw [Cout][Cin] += sum_{n,p} dYraw[n][co][p] * act_in(x)[n][ci][q(p)] */
 typedef struct {

@@ -94,6 +94,36 @@ def test_pw_fwd(gpu, dtype, shape):
     report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 54, 4, 16, 16), (1, 96, 216, 2, 14, 14), (2, 200, 72, 2, 7, 7), (1, 432, 192, 3, 7, 7)])
+def test_pw_packed_panels(gpu, shape):
+    """bf16 GEMMs fed from x3d_pw_pack_weights panels give bit-identical results to the in-kernel fp32->bf16
+    conversion (same rounded weights, same accumulation order), forward and dgrad, incl. row tiles past M."""
+    ops = _ops()
+    n, cin, cout, t, h, w = shape
+    g_ = _gen(11)
+    wt = (torch.randn((cout, cin), generator=g_) * 0.2).to(gpu)
+    (fp, dp), = ops.pw_pack_weights([wt])
+    lib = __import__("x3d_tf_amd").hip.load()
+    assert fp.numel() == lib.x3d_pw_panel_elems(cout, cin) and dp.numel() == lib.x3d_pw_panel_elems(cin, cout)
+    pitch = (cin + 15) // 16 * 16 + 8
+    img = fp.view(-1, pitch).float().cpu()
+    assert torch.equal(img[:cout, :cin], wt.bfloat16().float().cpu())
+    assert img[cout:].abs().sum().item() == 0 and img[:, cin:].abs().sum().item() == 0
+    x = torch.randn((n, cin, t, h, w), generator=g_).bfloat16().to(gpu)
+    ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
+    y0 = ops.pw_fwd(x, wt, in_ss=ss, in_act=2)
+    y1 = ops.pw_fwd(x, wt, in_ss=ss, in_act=2, w_panel=fp)
+    gy = torch.randn((n, cout, t, h, w), generator=g_).bfloat16().to(gpu)
+    yraw = torch.randn((n, cout, t, h, w), generator=g_).bfloat16().to(gpu)
+    coef = (torch.randn((cout, 4), generator=g_) * 0.5).to(gpu)
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    ops.pw_dgrad(gy, yraw, coef, wt, dx0)
+    ops.pw_dgrad(gy, yraw, coef, wt, dx1, w_panel=dp)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(dx0, dx1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [
     # N, C, T, H, W, stride

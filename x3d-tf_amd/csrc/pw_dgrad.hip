@@ -23,6 +23,7 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
     X3D_REQUIRE(d->add, "pw_dgrad: epilogue needs `add`");
   if (d->epi == X3D_EPI_SWISH_BWD)
     X3D_REQUIRE(d->braw && d->b_scale_shift && d->nc_sums, "pw_dgrad: SWISH_BWD needs braw/b_scale_shift/nc_sums");
+  X3D_REQUIRE(((uintptr_t)d->w_panel % 16) == 0, "pw_dgrad: w_panel must be 16-byte aligned");
   PwGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.x = d->g; a.x2 = d->yraw; a.coef = d->coef;
@@ -32,6 +33,7 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   a.P = a.Pin = (long long)d->T * d->H * d->W;
   a.y = d->dx; a.add = d->add; a.braw = d->braw; a.b_ss = d->b_scale_shift; a.egate = d->gate;
   a.nc_sums = d->nc_sums; a.eH = d->H; a.eW = d->W;
+  a.wp = d->w_panel; a.wp_rows = (d->Cin + 31) & ~31;
   const int eb = d->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, d->g, d->yraw);
   hipStream_t st = (hipStream_t)stream;

@@ -8,6 +8,7 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
               "pw_fwd: bad extents");
   X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "pw_fwd: bad dtype");
   X3D_REQUIRE(!(f->stride > 1 && f->in_scale_shift), "pw_fwd: strided input takes no prologue");
+  X3D_REQUIRE(((uintptr_t)f->w_panel % 16) == 0, "pw_fwd: w_panel must be 16-byte aligned");
   PwGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.x = f->x; a.coef = f->in_scale_shift; a.gate = f->in_gate; a.act = f->in_act;
@@ -18,6 +19,7 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   a.Pin = (long long)f->T * f->H * f->W;
   a.P = (long long)f->T * a.Ho * a.Wo;
   a.y = f->y; a.stats = f->stats;
+  a.wp = f->w_panel; a.wp_rows = (f->Cout + 31) & ~31;
   hipStream_t st = (hipStream_t)stream;
   const int eb = f->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, f->x);

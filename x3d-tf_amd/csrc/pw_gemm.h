@@ -32,6 +32,8 @@ struct PwGemmArgs {
   int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
   int KC, nchunks, tiles_per_block;
   int wvec;            // bf16 kernel: fp32 vector width for the weight-panel staging
+  const void* wp;      // bf16 kernel: packed panel (x3d_pw_pack_weights) [wp_rows][KC + 8] or null
+  int wp_rows;
   // epilogue
   void* y;
   double* stats;       // EPI_STATS: [M][2]

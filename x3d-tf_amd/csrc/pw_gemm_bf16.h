@@ -18,6 +18,8 @@
 //    depthwise output for swish') is a coalesced 16-byte row access, and the per-channel statistics are
 //    accumulated by the thread that owns the row (16 registers instead of 2x16 per accumulator tile).
 #pragma once
+#include <stdlib.h>
+
 #include "pw_gemm.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -36,14 +38,17 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr int VPR = BN / VEC;                       // staging vectors per row
   constexpr int NSV = (KCH * VPR + 255) / 256;        // staging vectors per thread per chunk
-  constexpr int ROWS_PT = BM / 16;                    // output rows owned per thread in the epilogue pass
+  constexpr int ROWS_PT = BM / 16;                    // output rows owned per thread in the epilogue passes
+  // the fp32 output tile goes through LDS in slabs of SLAB 32-row tiles, so a tall panel (MT up to 7: every
+  // output channel of a stage-4 layer from ONE staging + prologue pass over the activations) costs no extra LDS
+  constexpr int SLAB = (MT <= 2) ? MT : 1, NSLAB = MT / SLAB, ROWS_SL = 2 * SLAB;
   const int Kp = a.KC;                                // K rounded up to 16
   const int WP = Kp + 8;
   // the activation chunk and the fp32 output tile are never live together: they share one LDS region
   // (a 34 KB saving that keeps two workgroups per CU up to K ~ 300)
-  constexpr size_t XO_BYTES = ((size_t)KCH * XP * 2 > (size_t)BM * OP * 4) ? (size_t)KCH * XP * 2 : (size_t)BM * OP * 4;
+  constexpr size_t XO_BYTES = ((size_t)KCH * XP * 2 > (size_t)SLAB * 32 * OP * 4) ? (size_t)KCH * XP * 2 : (size_t)SLAB * 32 * OP * 4;
   bf16* Xs = (bf16*)smem_raw;                         // [KCH][XP]
-  float* Os = (float*)smem_raw;                       // [BM][OP]   (aliases Xs)
+  float* Os = (float*)smem_raw;                       // [SLAB * 32][OP]   (aliases Xs)
   bf16* Ws = (bf16*)(smem_raw + XO_BYTES);            // [BM][WP]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -59,7 +64,17 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 
   // ---- resident weight panel: Ws[m][k] = W(k, m) as bf16, zero padded.  The fp32 master weights are read
   // along their contiguous axis with the widest aligned vector (4/2/1 floats).
-  {
+  if (a.wp) {
+    // packed panel: the LDS image itself, rows m0.. of pitch WP -> a flat 16-byte copy (rows past the panel: zero)
+    const bf16x8* src = (const bf16x8*)((const bf16*)a.wp + (long long)m0 * WP);
+    const int nvec = BM * WP / 8;
+    const int lim = max(0, min(BM, a.wp_rows - m0)) * WP / 8;
+    bf16x8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; e++) zero[e] = (bf16)0.f;
+#pragma unroll 4
+    for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
+  } else {
     const int wv = a.wvec;
     if (a.wsk == 1) {            // forward: source rows are k-contiguous -> one LDS row segment per vector
       const int kv = Kp / wv;    // Kp % 4 == 0
@@ -280,21 +295,23 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       }
     }
 
-    // ---- accumulators -> LDS output tile (col = lane&31 -> point, rows in registers)
-    __syncthreads();   // Os aliases Xs: every wave must be done with the last chunk's fragments
-#pragma unroll
-    for (int s = 0; s < MT; s++)
-#pragma unroll
-      for (int j = 0; j < 16; j++)
-        Os[(s * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) * OP + wid * 32 + r] = acc[s][j];
-    __syncthreads();
-
-    // ---- row-wise epilogue pass: thread owns rows (tid>>4) + 16*i, an 8-point column chunk (tid&15)
+    // ---- accumulators -> LDS output slab (col = lane&31 -> point, rows in registers) -> row-wise epilogue pass:
+    // thread owns rows (tid>>4) + 16*i of the slab, an 8-point column chunk (tid&15)
     const int oc = (tid & 15) * 8;
 #pragma unroll
-    for (int i = 0; i < ROWS_PT; i++) {
-      const int row = (tid >> 4) + 16 * i;
-      const int m = m0 + row;
+    for (int sl = 0; sl < NSLAB; sl++) {
+    __syncthreads();   // Os aliases Xs: every wave is done with the last chunk's fragments / the previous slab
+#pragma unroll
+    for (int s = 0; s < SLAB; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        Os[(s * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) * OP + wid * 32 + r] = acc[sl * SLAB + s][j];
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < ROWS_SL; ii++) {
+      const int i = sl * ROWS_SL + ii;                 // index into the per-thread row sums
+      const int row = (tid >> 4) + 16 * ii;            // row inside the slab
+      const int m = m0 + sl * SLAB * 32 + row;
       const long long p = p0 + oc;
       if (m >= a.M || p >= a.P) continue;
       float val[8];
@@ -376,27 +393,61 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
       }
     }
+    }
     // Os is rewritten only after the next tile's first two barriers
   }
 
   if (tile_begin < tile_end) flush_sums(n_prev);
 }
 
+static inline size_t pw_bf16_lds_bytes(int mt, int K) {
+  const int slab = mt <= 2 ? mt : 1;
+  const size_t xb = (size_t)PWB_KCH * PWB_XP * 2, ob = (size_t)slab * 32 * PWB_OP * 4;
+  return (xb > ob ? xb : ob) + (size_t)mt * 32 * (((K + 15) & ~15) + 8) * 2;
+}
+
+// rows of 32 output channels per workgroup.  Every extra row block (gy > 1) re-stages the activation tile and
+// repeats its prologue, but tall panels serialise the epilogue and cost registers; measured on X3D-M (r01c):
+// three row tiles in one panel win when they remove the second row block (M in 65..96: 133 -> 91 us on the
+// 216->96 layers), taller panels lose (96->216: 69 -> 118 us with MT = 7), and K >= 320 panels are too wide
+// for more than 32 rows at three workgroups per CU.
+static inline int pw_bf16_pick_mt(int M, int K) {
+  const int mt = ceil_div(M, 32);
+  // experiment hook: X3D_PW_MTMAP="7:4,14:7" maps a row-tile count to a panel height
+  static const char* map = getenv("X3D_PW_MTMAP");
+  if (map) {
+    for (const char* q = map; *q;) {
+      const int key = atoi(q);
+      const char* c = strchr(q, ':');
+      if (!c) break;
+      const int val = atoi(c + 1);
+      if (key == mt && (val == 1 || val == 2 || val == 3 || val == 4 || val == 7) && pw_bf16_lds_bytes(val, K) <= 160 * 1024) return val;
+      const char* n = strchr(c, ',');
+      if (!n) break;
+      q = n + 1;
+    }
+  }
+  if (mt <= 1 || K >= 320) return 1;
+  if (mt == 3 && pw_bf16_lds_bytes(3, K) <= 80 * 1024) return 3;
+  return 2;
+}
+
 template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, BN = PWB_BN;
   a.KC = (a.K + 15) & ~15;
-  const size_t xb = (size_t)PWB_KCH * PWB_XP * 2, ob = (size_t)BM * PWB_OP * 4;
-  const size_t lds = (xb > ob ? xb : ob) + (size_t)BM * (a.KC + 8) * 2;
+  const size_t lds = pw_bf16_lds_bytes(MT, a.K);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_gemm_bf16: K = %d needs %zu B of LDS", a.K, lds);
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
   int tpb = (int)(total_tiles * gy / 1536);      // aim for >= ~6 workgroups per CU, <= 16 tiles per panel
   if (tpb < 1) tpb = 1;
-  // a wide weight panel (K*BM bf16, converted from fp32 by every workgroup) must be amortised over several
-  // tiles even if that leaves fewer workgroups than CUs: measured 4x on the K=432 layers
-  const int tpb_min = a.K >= 384 ? 8 : (a.K >= 192 ? 4 : (a.K >= 96 ? 2 : 1));
+  // a wide weight panel (K*BM bf16 per workgroup, through L2) must be amortised over several tiles even if that
+  // leaves fewer workgroups than CUs (r01c sweep: 4 tiles is the optimum for K >= 192 with packed panels)
+  int tpb_min = a.K >= 192 ? 4 : (a.K >= 96 ? 2 : 1);
+  static const char* tpb_env = getenv("X3D_PW_TPBMIN");   // experiment hook
+  if (tpb_env) tpb_min = atoi(tpb_env);
   if (tpb < tpb_min) tpb = tpb_min;
   if (tpb > 16) tpb = 16;
   a.tiles_per_block = tpb;
@@ -424,10 +475,15 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
 
 template <int VEC, int PRO, int EPI, bool STRIDED, int OVEC>
 static int pw_bf16_launch_tile(PwGemmArgs& a, hipStream_t st) {
-  // 32-row panels when the panel is wide (K >= 320): 48 KB of LDS per workgroup -> three per CU instead of one;
-  // the extra row blocks re-read the activation tile through L2
-  if (a.M <= 32 || a.K >= 320) return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
-  return pw_bf16_launch_cfg<VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
+  int mt = pw_bf16_pick_mt(a.M, a.K);
+  if constexpr (VEC == 1) mt = mt > 2 ? 2 : mt;   // scalar fallback path: 32 staging registers per chunk, keep the panel small
+  switch (mt) {
+    case 7: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 7, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 4: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 4, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 3: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 3, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 2: return pw_bf16_launch_cfg<VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
+    default: return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
+  }
 }
 
 // vec: common alignment (elements) of the streamed inputs; ovec: of the outputs / epilogue tensors

@@ -25,13 +25,18 @@ class X3DHipError(RuntimeError):
 class PwFwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("stats", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i),
-                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
+                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("w_panel", _vp)]
 
 
 class PwDgradArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("w", _vp), ("dx", _vp), ("epi", _i),
                 ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
-                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
+                ("w_panel", _vp)]
+
+
+class PwPackItem(C.Structure):
+    _fields_ = [("w", _vp), ("fwd_panel", _vp), ("dgrad_panel", _vp), ("Cout", _i), ("Cin", _i)]
 
 
 class PwWgradArgs(C.Structure):
@@ -73,6 +78,8 @@ _SIGS = {
     "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
     "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
+    "x3d_pw_panel_elems": ([_i, _i], _ll),
+    "x3d_pw_pack_weights": ([_vp, _i, _vp], _i),
     "x3d_dw3d_fwd": ([C.POINTER(Dw3dFwdArgs), _vp], _i),
     "x3d_dw3d_bwd": ([C.POINTER(Dw3dBwdArgs), _vp], _i),
     "x3d_dw3d_kernel_name": ([C.POINTER(Dw3dFwdArgs), C.POINTER(Dw3dBwdArgs), C.c_char_p, _i], _i),

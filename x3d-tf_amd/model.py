@@ -197,6 +197,7 @@ class X3D:
         hip.load()
         self._plans: Dict = {}
         self._build_params(seed)
+        self._build_panels()
         self._build_layers()
         self._dropout_mask_override = None
         self.last_loss = None
@@ -244,6 +245,41 @@ class X3D:
         self.param_order = [s.name for s in order]
         self.n_params = sum(numel(s) for s in order)
         self.n_trainable = sum(numel(s) for s in order if s.trainable)
+
+    def _build_panels(self):
+        """bf16 LDS-image panels of every pointwise-conv weight (x3d_pw_pack_weights): refreshed by one launch
+        at the start of each forward so the GEMM workgroups copy their weight rows instead of converting them."""
+        self._panels: Dict[str, tuple] = {}
+        self._panel_table = None
+        if self.dtype != torch.bfloat16:
+            return
+        lib = hip.load()
+        names = [s.name for s in self.specs.values() if s.kind == "pw" and
+                 (s.name.endswith(("/a/kernel", "/c/kernel", "/residual/kernel")) or s.name.startswith("conv5/"))]
+        sizes = []
+        for nm in names:
+            cout, cin = self.specs[nm].shape
+            sizes.append((lib.x3d_pw_panel_elems(cout, cin), lib.x3d_pw_panel_elems(cin, cout)))
+        total = sum(a + b for a, b in sizes)
+        self._panel_buf = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+        items = (hip.PwPackItem * len(names))()
+        off = 0
+        for i, (nm, (nf, nd)) in enumerate(zip(names, sizes)):   # panel sizes are multiples of 8 elements: 16-B aligned
+            fp, dp = self._panel_buf[off:off + nf], self._panel_buf[off + nf:off + nf + nd]
+            off += nf + nd
+            cout, cin = self.specs[nm].shape
+            items[i] = hip.PwPackItem(self.params[nm].data_ptr(), fp.data_ptr(), dp.data_ptr(), cout, cin)
+            self._panels[nm] = (fp, dp)
+        self._panel_table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+        self._n_panels = len(names)
+
+    def _pack_panels(self):
+        if self._panel_table is not None:
+            hip.call("x3d_pw_pack_weights", self._panel_table.data_ptr(), self._n_panels)
+
+    def _wp(self, name, dgrad=False):
+        pr = self._panels.get(name)
+        return None if pr is None else pr[1 if dgrad else 0].data_ptr()
 
     def _bn(self, prefix):
         p = self.params
@@ -426,6 +462,7 @@ class X3D:
             # a: 1x1x1 on the (materialised, already activated) block input
             sa = hip.PwFwdArgs(_p(x_cur), _p(p[f"{q}/a/kernel"]), _p(B.a_raw), None, None, None, ACT_NONE, n, b.cin,
                                b.inner, t, hh, ww, 1, dt)
+            sa.w_panel = self._wp(f"{q}/a/kernel")
             B.sa = sa
             pl.rec(F, "x3d_pw_fwd", ("stats", sa, B.bn_a.stats))
             bn_finish(B.bn_a, n * P_in)
@@ -442,6 +479,7 @@ class X3D:
             # c: 1x1x1 with BN_b * SE gate -> swish folded into the load
             sc = hip.PwFwdArgs(_p(B.b_raw), _p(p[f"{q}/c/kernel"]), _p(B.c_raw), None, _p(B.bn_b.ss), _p(B.gate),
                                ACT_SWISH, n, b.inner, b.cout, t, ho, wo, 1, dt)
+            sc.w_panel = self._wp(f"{q}/c/kernel")
             B.sc = sc
             pl.rec(F, "x3d_pw_fwd", ("stats", sc, B.bn_c.stats))
             bn_finish(B.bn_c, n * P_out)
@@ -450,6 +488,7 @@ class X3D:
                 B.bn_r = bn_bufs(f"{pre}/bn_r", b.cout)
                 sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
                                    n, b.cin, b.cout, t, hh, ww, b.stride, dt)
+                sr.w_panel = self._wp(f"{pre}/residual/kernel")
                 B.sr = sr
                 pl.rec(F, "x3d_pw_fwd", ("stats", sr, B.bn_r.stats))
                 bn_finish(B.bn_r, n * P_out)
@@ -469,6 +508,7 @@ class X3D:
         pl.bn5 = bn_bufs("conv5/layer_with_weights-1", c5)
         s5 = hip.PwFwdArgs(_p(x_cur), _p(p["conv5/layer_with_weights-0/kernel"]), _p(pl.c5_raw), None, None, None,
                            ACT_NONE, n, c_last, c5, t, hh, ww, 1, dt)
+        s5.w_panel = self._wp("conv5/layer_with_weights-0/kernel")
         pl.s5 = s5
         pl.rec(F, "x3d_pw_fwd", ("stats", s5, pl.bn5.stats))
         bn_finish(pl.bn5, n * P5)
@@ -579,6 +619,7 @@ class X3D:
         dy = pl.gbuf[cur][:pl.y_last.numel()]
         d5 = hip.PwDgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(p["conv5/layer_with_weights-0/kernel"]),
                              _p(dy), EPI_STORE, None, None, None, None, None, n, c_last, c5, t, pl.h5, pl.w5, dt)
+        d5.w_panel = self._wp("conv5/layer_with_weights-0/kernel", True)
         pl.rec(Bk, "x3d_pw_dgrad", d5)
         pl.bwd_stage_marks[len(a.stages)] = len(Bk)   # head finished
 
@@ -604,6 +645,7 @@ class X3D:
             dc = hip.PwDgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(p[f"{q}/c/kernel"]), _p(dvv),
                                  EPI_SWISH_BWD, None, _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, n, b.inner,
                                  b.cout, t, B.ho, B.wo, dt)
+            dc.w_panel = self._wp(f"{q}/c/kernel", True)
             pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
             # SE + BN_b backward from the per-(n,c) sums
             se = hip.SeBnbBwdArgs(
@@ -636,6 +678,7 @@ class X3D:
                 rt = pl.rtmp[:n * b.cin * P_out]
                 dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(p[f"{pre}/residual/kernel"]), _p(rt),
                                      EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
+                dr.w_panel = self._wp(f"{pre}/residual/kernel", True)
                 pl.rec(Bk, "x3d_pw_dgrad", dr)
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt),
                                      EPI_ADD_STRIDED if b.stride == 2 else EPI_ADD, _p(rt), None, None, None, None, n,
@@ -643,6 +686,7 @@ class X3D:
             else:
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt), EPI_ADD,
                                      _p(gten), None, None, None, None, n, b.cin, b.inner, t, B.hh, B.ww, dt)
+            da.w_panel = self._wp(f"{q}/a/kernel", True)
             pl.rec(Bk, "x3d_pw_dgrad", da)
             cur = 1 - cur
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
@@ -699,6 +743,7 @@ class X3D:
         n, t, h, w, _ = input.shape
         pl = self._plan(n, t, h, w, training)
         self._bind_input(pl, input)
+        self._pack_panels()
         if training:
             pl.zero_buf.zero_()
             self._draw_dropout(pl)
@@ -724,6 +769,7 @@ class X3D:
         pl = self._plan(n, t, h, w, True)
         self._bind_input(pl, input)
         pl.labels.copy_(labels.to(self.device, non_blocking=True).to(torch.int32))
+        self._pack_panels()
         pl.zero_buf.zero_()
         self.flat_grads.zero_()
         self._draw_dropout(pl)

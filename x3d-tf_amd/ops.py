@@ -79,28 +79,48 @@ def bn_bwd_finalize(sums, count, mi, gamma, coef, dgamma, dbeta):
 
 
 # ---- pointwise ----------------------------------------------------------------------------------
-def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
-    _chk(x, w, y, stats, in_ss, in_gate)
+def pw_pack_weights(weights, dgrad=True):
+    """fp32 [Cout, Cin] weights -> list of (fwd_panel, dgrad_panel) bf16 LDS-image panels, one launch
+    (x3d_pw_pack_weights)."""
+    import ctypes as C
+    lib = hip.load()
+    items = (hip.PwPackItem * len(weights))()
+    out = []
+    for i, w in enumerate(weights):
+        _chk(w)
+        cout, cin = w.shape
+        fp = torch.empty(lib.x3d_pw_panel_elems(cout, cin), dtype=torch.bfloat16, device=w.device)
+        dp = torch.empty(lib.x3d_pw_panel_elems(cin, cout), dtype=torch.bfloat16, device=w.device) if dgrad else None
+        items[i] = hip.PwPackItem(ptr(w), ptr(fp), ptr(dp), cout, cin)
+        out.append((fp, dp))
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(weights[0].device)
+    hip.call("x3d_pw_pack_weights", table.data_ptr(), len(weights))
+    torch.cuda.current_stream().synchronize()   # `table` must outlive the launch
+    return out
+
+
+def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, w_panel=None):
+    _chk(x, w, y, stats, in_ss, in_gate, w_panel)
     n, cin, t, h, ww = x.shape
     cout = w.shape[0]
     ho, wo = _out_hw(h, ww, stride)
     if y is None:
         y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
     a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(stats), ptr(in_ss), ptr(in_gate), in_act, n, cin,
-                      cout, t, h, ww, stride, hip.dtype_code(x.dtype))
+                      cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel))
     hip.call_struct("x3d_pw_fwd", a)
     return y
 
 
 def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None, gate=None,
-             nc_sums=None):
+             nc_sums=None, w_panel=None):
     """g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]."""
     _chk(g, yraw, coef, w, dx, add, braw, b_ss, gate, nc_sums)
     n, cout, t, h, ww = g.shape
     cin = w.shape[1]
     a = hip.PwDgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w), ptr(dx), epi, ptr(add), ptr(braw),
                         ptr(b_ss), ptr(gate), ptr(nc_sums), n, cin, cout, t, h, ww,
-                        hip.dtype_code(g.dtype))
+                        hip.dtype_code(g.dtype), ptr(w_panel))
     hip.call_struct("x3d_pw_dgrad", a)
     return dx
 
