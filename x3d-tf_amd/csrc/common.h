@@ -153,10 +153,28 @@ __device__ __forceinline__ float swish_grad_(float v) {
 // ---------------------------------------------------------------------------------------------
 // reductions: 64-wide wavefront shuffles, then LDS across the waves of a block
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP (data-parallel primitive) adds: cross-lane operands inside the VALU instruction, no LDS round trip.
+// __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt; the 29 wave sums at the end of the depthwise backward
+// were 174 of those (r01c ISA).  Controls: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140,
+// row_bcast15 0x142, row_bcast31 0x143; a lane whose row is masked off adds 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// every lane ends with the sum over its row of 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);   // row_mirror
   return v;
+}
+// sum over the 64 lanes, returned to every lane (as a wave-uniform value)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
       for (int i = 0; i < ROWS_PT; i++) {
         float s1 = st1[i], s2 = st2[i];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 = row16_sum(s1);   // the 16 threads of a row are one DPP row
+        s2 = row16_sum(s2);
         const int m = m0 + (tid >> 4) + 16 * i;
         if ((tid & 15) == 0 && m < a.M) {
           if constexpr (EPI == EPI_STATS) {
