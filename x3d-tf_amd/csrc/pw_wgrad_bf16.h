@@ -363,13 +363,25 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
   const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
-  long long spb = total_steps * gy * gz / 1536;
+  const size_t lds = (size_t)(MG + NG) * 32 * 72 * 2;
+  auto kern = pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>;
+  // one balanced round: as many workgroups as the chip holds at once (occupancy x CUs), the 64-point steps split
+  // evenly among them.  A fixed steps-per-block left e.g. 1568 workgroups on 1280 slots: a second round at 22 %.
+  static int slots = 0;
+  if (slots == 0) {
+    int nb = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+    slots = nb * cus;
+  }
+  long long gx_target = slots / (gy * gz);
+  if (gx_target < 1) gx_target = 1;
+  long long spb = ceil_div_ll(total_steps, gx_target);
   if (spb < 8) spb = 8;      // keeps the atomic partial (<= 32 KB) below ~10 % of the streamed bytes
-  if (spb > 64) spb = 64;
   a.steps_per_block = (int)spb;
   const long long gx = ceil_div_ll(total_steps, spb);
-  const size_t lds = (size_t)(MG + NG) * 32 * 72 * 2;
-  hipLaunchKernelGGL((pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
   return X3D_OK;
 }
