@@ -441,15 +441,38 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
-  int tpb = (int)(total_tiles * gy / 1536);      // aim for >= ~6 workgroups per CU, <= 16 tiles per panel
-  if (tpb < 1) tpb = 1;
+  auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  // One balanced round: as many workgroups as the chip holds at once (occupancy of THIS instantiation at THIS
+  // LDS size x CUs), the point tiles split evenly among them -- a fixed tile count per workgroup left partial
+  // last rounds (e.g. 1568 workgroups on 768 slots).  The occupancy is cached per LDS size.
+  static size_t occ_lds[8];
+  static int occ_slots[8], occ_n = 0;
+  int slots = 0;
+  for (int i = 0; i < occ_n; i++) if (occ_lds[i] == lds) slots = occ_slots[i];
+  if (slots == 0) {
+    int nb = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    slots = nb * cus;
+    if (occ_n < 8) { occ_lds[occ_n] = lds; occ_slots[occ_n] = slots; occ_n++; }
+  }
+  long long gx_target = slots / gy;
+  if (gx_target < 1) gx_target = 1;
+  int tpb = (int)ceil_div_ll(total_tiles, gx_target);
   // a wide weight panel (K*BM bf16 per workgroup, through L2) must be amortised over several tiles even if that
-  // leaves fewer workgroups than CUs (r01c sweep: 4 tiles is the optimum for K >= 192 with packed panels)
+  // leaves fewer workgroups than slots (r01c sweep: 4 tiles is the optimum for K >= 192 with packed panels)
   int tpb_min = a.K >= 192 ? 4 : (a.K >= 96 ? 2 : 1);
   static const char* tpb_env = getenv("X3D_PW_TPBMIN");   // experiment hook
   if (tpb_env) tpb_min = atoi(tpb_env);
   if (tpb < tpb_min) tpb = tpb_min;
-  if (tpb > 16) tpb = 16;
   a.tiles_per_block = tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
   // widest aligned fp32 vector along the contiguous axis of the weight matrix
@@ -459,14 +482,6 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
     while (wv > 1 && ((contig % wv) != 0 || ((uintptr_t)a.w % (wv * 4)) != 0)) wv >>= 1;
     if (a.wsk != 1 && (BM % wv) != 0) wv = 1;
     a.wvec = wv;
-  }
-  auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
-  if (lds > 48 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm_bf16");
