@@ -226,7 +226,7 @@ typedef struct {
   float* dw1; float* db1; float* dw2; float* db2;
   float* dgamma_b; float* dbeta_b;
   float* coef_nc;              /* out [N][C][4] */
-  float* scratch;              /* [N][C] floats (dpool) */
+  float* scratch;              /* N*(2*C + Wd) floats: dpool [N][C] | dz2 [N][C] | dz1 [N][Wd] */
   int N, C, Wd;
 } x3d_se_bnb_bwd_args;
 int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream);

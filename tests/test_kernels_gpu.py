@@ -446,12 +446,13 @@ def test_se(gpu):
     report("gate", gate, gr, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("dims", [(3, 12, 8), (70, 40, 16)])
 @pytest.mark.parametrize("has_se", [True, False])
-def test_se_bnb_bwd(gpu, has_se):
+def test_se_bnb_bwd(gpu, has_se, dims):
     """Composite check: u = bn_b(braw) [train stats] -> (SE gate) -> v ; L = sum(dv * v).  The kernel sees only the
     per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients."""
     ops = _ops()
-    n, c, wd = 3, 12, 8
+    n, c, wd = dims
     T, H, W = 2, 3, 4
     P = T * H * W
     g_ = _gen(9)
@@ -491,7 +492,7 @@ def test_se_bnb_bwd(gpu, has_se):
         kw = dict(w1=f32(w1), b1=f32(b1), w2=f32(w2), b2=f32(b2), gate=f32(gate), hidden=f32(h),
                   dw1=torch.zeros((wd, c), device=gpu), db1=torch.zeros(wd, device=gpu),
                   dw2=torch.zeros((c, wd), device=gpu), db2=torch.zeros(c, device=gpu),
-                  scratch=torch.empty((n, c), device=gpu))
+                  scratch=torch.empty(n * (2 * c + wd), device=gpu))
     ops.se_bnb_bwd(nc_sums, pool_sums if has_se else None, P, f32(bss), f32(bmi), f32(gamma), dgam, dbet, coef_nc,
                    n, c, **kw)
     torch.cuda.synchronize()

@@ -47,24 +47,25 @@ extern "C" int x3d_se_fwd(const double* pool_sums, double P, const float* b_scal
   return X3D_OK;
 }
 
-// stage 1 (one block per sample): gradient through gate -> fc2 -> ReLU -> fc1 -> pooled
+// stage 1 (one block per sample): gradient through gate -> fc2 -> ReLU -> fc1 -> pooled.  No atomics: the
+// per-sample vectors dz2 [N][C] (pre-sigmoid grad of fc2) and dz1 [N][Wd] (pre-ReLU grad of fc1) go to scratch
+// and stage 2 contracts them over the samples.  scratch = dpool [N][C] | dz2 [N][C] | dz1 [N][Wd].
 __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a) {
-  __shared__ float pooled[SE_MAXC];
   __shared__ float dz2[SE_MAXC];
   __shared__ float dz1[SE_MAXW];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = a.C, Wd = a.Wd;
+  float* dz2_out = a.scratch + (long long)a.N * C;
+  float* dz1_out = a.scratch + 2ll * a.N * C;
   for (int c = tid; c < C; c += 256) {
     const float sb = a.b_scale_shift[c * 2], tb = a.b_scale_shift[c * 2 + 1];
     const long long i = (long long)n * C + c;
-    pooled[c] = sb * (float)(a.pool_sums[i] / a.P) + tb;
     // dgate = sum_p dv*u, u = sb*braw + tb
     const float dgate = (float)((double)sb * a.nc_sums[i * 2 + 1] + (double)tb * a.nc_sums[i * 2]);
     const float g = a.gate[i];
     const float d = dgate * g * (1.f - g);
     dz2[c] = d;
-    atomicAdd(&a.db2[c], d);
-    for (int j = 0; j < Wd; j++) atomicAdd(&a.dw2[c * Wd + j], d * a.hidden[(long long)n * Wd + j]);
+    dz2_out[i] = d;
   }
   __syncthreads();
   for (int j = wid; j < Wd; j += 4) {
@@ -74,22 +75,22 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a
     if (lane == 0) {
       const float d = a.hidden[(long long)n * Wd + j] > 0.f ? acc : 0.f;
       dz1[j] = d;
-      atomicAdd(&a.db1[j], d);
+      dz1_out[(long long)n * Wd + j] = d;
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dp = 0.f;
-    for (int j = 0; j < Wd; j++) {
-      dp += a.w1[j * C + c] * dz1[j];
-      atomicAdd(&a.dw1[j * C + c], dz1[j] * pooled[c]);
-    }
+    for (int j = 0; j < Wd; j++) dp += a.w1[j * C + c] * dz1[j];
     a.scratch[(long long)n * C + c] = dp;  // d loss / d pooled[n][c]
   }
 }
 
-// stage 2 (one thread per channel): BN_b backward over du = dv*gate + dpool/P, then per-(n,c) coefficients
-// one 64-lane workgroup per channel: lanes split the samples, fp64 shuffle reduction
+// stage 2 (one 64-lane workgroup per channel, lanes split the samples): BN_b backward over
+// du = dv*gate + dpool/P with fp64 sums, the per-(n,c) coefficients, and the SE weight gradients of this channel
+//   dw2[c][j] += sum_n dz2[n][c]*hidden[n][j]    db2[c] += sum_n dz2[n][c]
+//   dw1[j][c] += sum_n dz1[n][j]*pooled[n][c]    db1[j]  += sum_n dz1[n][j]   (workgroup 0)
+// Each gradient element has exactly one writer, so the += are plain read-modify-writes.
 __global__ __launch_bounds__(64) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
   const int c = blockIdx.x, lane = threadIdx.x;
   const int C = a.C, N = a.N;
@@ -122,6 +123,32 @@ __global__ __launch_bounds__(64) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a
     o[1] = (float)B;
     o[2] = (float)(Cc + k1 * dp / a.P);
     o[3] = 0.f;
+  }
+  if (!has_se) return;
+  const int Wd = a.Wd;
+  const float* dz2 = a.scratch + (long long)N * C;
+  const float* dz1 = a.scratch + 2ll * N * C;
+  const float sb = a.b_scale_shift[c * 2], tb = a.b_scale_shift[c * 2 + 1];
+  float sb2 = 0.f;
+  for (int n = lane; n < N; n += 64) sb2 += dz2[(long long)n * C + c];
+  sb2 = wave_sum(sb2);
+  if (lane == 0) a.db2[c] += sb2;
+  // lanes = hidden units: a sequential pass over the samples, no cross-lane traffic
+  if (lane < Wd) {
+    float s2 = 0.f, s1 = 0.f, sj = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; n++) {
+      const long long i = (long long)n * C + c;
+      const float d2 = dz2[i];
+      const float pooled = sb * (float)(a.pool_sums[i] / a.P) + tb;
+      const float d1 = dz1[(long long)n * Wd + lane], h = a.hidden[(long long)n * Wd + lane];
+      s2 += d2 * h;
+      s1 += d1 * pooled;
+      sj += d1;
+    }
+    a.dw2[c * Wd + lane] += s2;
+    a.dw1[lane * C + c] += s1;
+    if (c == 0) a.db1[lane] += sj;
   }
 }
 

@@ -595,7 +595,7 @@ class X3D:
         pl.ga = flat(max_inner_in)
         pl.rtmp = flat(max_r)
         pl.coef_nc = pl.f32(max_nc * 4)
-        pl.se_scratch = pl.f32(max_nc)
+        pl.se_scratch = pl.f32(max([1] + [n * (2 * B.spec.inner + B.spec.se_width) for B in pl.blocks if B.spec.has_se]))
         pl.g5 = pl.act(*pl.c5_raw.shape)
         pl.dh1 = pl.f32(n, a.fc1_out)
         pl.dpooled = pl.f32(n, c5)
