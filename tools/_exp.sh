@@ -1,4 +1,3 @@
-python -m pytest tests/test_kernels_gpu.py -x -q -k "se_" 2>&1 | tail -5
-python -m pytest tests/test_model_gpu.py -x -q 2>&1 | tail -3
-python tools/bench_layers.py M 64 > gpurun_out/exp_se.txt 2>&1
-grep "se_\|sum of" gpurun_out/exp_se.txt | head
+python -m pytest tests/test_kernels_gpu.py -x -q -k "dw3d" 2>&1 | tail -3
+python tools/bench_layers.py M 64 > gpurun_out/exp_l63.txt 2>&1
+grep "dw3d_bwd  \|sum of" gpurun_out/exp_l63.txt | head -4

@@ -169,12 +169,16 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_get<0x140, 0xF>(v);   // row_mirror
   return v;
 }
-// sum over the 64 lanes, returned to every lane (as a wave-uniform value)
-__device__ __forceinline__ float wave_sum(float v) {
+// sum over the 64 lanes, valid in lane 63 only (no v_readlane / SGPR round trip: for many sums in a row)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
   v = row16_sum(v);
   v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
   v += dpp_get<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return v;
+}
+// sum over the 64 lanes, returned to every lane (as a wave-uniform value)
+__device__ __forceinline__ float wave_sum(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(v)), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -269,13 +269,15 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   load_own(g.T - 1);
   emit(g.T - 1, dA0);
 
-  // block reduction of the 27 weight-gradient taps and the two BN sums, one value at a time (registers)
+  // block reduction of the 27 weight-gradient taps and the two BN sums: DPP wave sums that end in lane 63,
+  // which alone writes the 29 partials (one predicate around all the LDS writes)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float red[29];
 #pragma unroll
-  for (int k = 0; k < 29; k++) {
-    float v = k < 27 ? dW[k] : (k == 27 ? s1 : s2);
-    v = wave_sum(v);
-    if (lane == 0) scratch[k * 4 + wid] = v;
+  for (int k = 0; k < 29; k++) red[k] = wave_sum_lane63(k < 27 ? dW[k] : (k == 27 ? s1 : s2));
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 29; k++) scratch[k * 4 + wid] = red[k];
   }
   __syncthreads();
   if (threadIdx.x < 29) {
