@@ -129,6 +129,32 @@ typedef struct {
 } x3d_pw_dgrad_args;
 int x3d_pw_dgrad(const x3d_pw_dgrad_args* a, void* stream);
 
+/* fused data + weight gradient of one pointwise conv (bf16 storage, <= 128 channels on either side, stride 1):
+ * ONE pass over g / yraw instead of the two that x3d_pw_dgrad + x3d_pw_wgrad make, and for the `c` conv one
+ * pass over braw (swish for dw and swish' for dx from the same load).  Fields as in the two structs above:
+ *   epi = X3D_EPI_ADD / X3D_EPI_ADD_STRIDED : `a` conv; x = conv input [N][Cin][P], add as in dgrad
+ *   epi = X3D_EPI_SWISH_BWD                 : `c` conv; the conv input is swish(gate * (s_b*braw + t_b)); x unused
+ * w_panel is the DGRAD panel of x3d_pw_pack_weights (required).  x3d_pw_bwd_supported() says whether a launch
+ * is covered (shape, alignment); x3d_pw_bwd fails with X3D_ERR_INVALID otherwise -- callers then use the pair. */
+typedef struct {
+  const void* g;               /* [N][Cout][P] */
+  const void* yraw;            /* [N][Cout][P] */
+  const float* coef;           /* [Cout][4] */
+  const void* w_panel;         /* dgrad panel (bf16) */
+  void* dx;                    /* [N][Cin][P] */
+  int epi;
+  const void* add;
+  const void* braw;
+  const float* b_scale_shift;
+  const float* gate;
+  double* nc_sums;
+  const void* x;               /* [N][Cin][P] conv input (ADD epilogues) */
+  float* dw;                   /* [Cout][Cin] += */
+  int N, Cin, Cout, T, H, W, dtype;
+} x3d_pw_bwd_args;
+int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
+int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
+
 /* bf16 weight panels.  The bf16 GEMMs keep their A operand (the weights) resident in LDS as bf16 rows of
  * pitch roundup(K,16)+8; without a panel every workgroup converts its rows from the fp32 master weights
  * (a latency-serialised gather that dominates small-P layers).  x3d_pw_pack_weights converts every

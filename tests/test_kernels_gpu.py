@@ -94,6 +94,58 @@ def test_pw_fwd(gpu, dtype, shape):
     report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, T, H, W, epi                 (a conv: Cin = block input, Cout = inner; c conv: Cin = inner, Cout = out)
+    (2, 24, 54, 4, 16, 16, "add"), (2, 48, 108, 2, 28, 28, "add"), (1, 24, 108, 3, 16, 16, "add_strided"),
+    (2, 24, 54, 2, 28, 28, "add_strided"),
+    (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
+    (1, 96, 32, 2, 10, 12, "swish_bwd"),
+])
+def test_pw_bwd_fused(gpu, shape):
+    """x3d_pw_bwd (one pass over dY) against x3d_pw_dgrad + x3d_pw_wgrad: dx bit-identical (same bf16 operands,
+    same accumulation order over Cout), dw and the per-(n,c) sums to fp32 summation-order tolerance."""
+    ops = _ops()
+    n, cin, cout, t, h, w, epi = shape
+    g_ = _gen(21)
+    bf = torch.bfloat16
+    wt = (torch.randn((cout, cin), generator=g_) * 0.2).to(gpu)
+    (fp, dp), = ops.pw_pack_weights([wt])
+    gy = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
+    yraw = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
+    coef = (torch.randn((cout, 4), generator=g_) * 0.5).to(gpu)
+    dx0 = torch.empty((n, cin, t, h, w), dtype=bf, device=gpu)
+    dx1 = torch.empty_like(dx0)
+    dw0 = torch.zeros((cout, cin), device=gpu)
+    dw1 = torch.zeros_like(dw0)
+    if epi == "swish_bwd":
+        braw = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+        bss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
+        gate = torch.rand((n, cin), generator=g_).to(gpu)
+        nc0 = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+        nc1 = torch.zeros_like(nc0)
+        ops.pw_dgrad(gy, yraw, coef, wt, dx0, epi=ops.EPI_SWISH_BWD, braw=braw, b_ss=bss, gate=gate, nc_sums=nc0, w_panel=dp)
+        ops.pw_wgrad(gy, yraw, coef, braw, dw0, in_ss=bss, in_gate=gate, in_act=2)
+        ok = ops.pw_bwd(gy, yraw, coef, dp, dx1, dw1, ops.EPI_SWISH_BWD, braw=braw, b_ss=bss, gate=gate, nc_sums=nc1)
+    else:
+        x = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+        if epi == "add":
+            add = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+            e = ops.EPI_ADD
+        else:
+            add = torch.randn((n, cin, t, (h + 1) // 2, (w + 1) // 2), generator=g_).to(bf).to(gpu)
+            e = ops.EPI_ADD_STRIDED
+        ops.pw_dgrad(gy, yraw, coef, wt, dx0, epi=e, add=add, w_panel=dp)
+        ops.pw_wgrad(gy, yraw, coef, x, dw0)
+        ok = ops.pw_bwd(gy, yraw, coef, dp, dx1, dw1, e, x=x, add=add)
+    torch.cuda.synchronize()
+    assert ok, "fused kernel should cover this shape"
+    assert torch.equal(dx0, dx1)
+    scale = dw0.abs().max().item()
+    report("dw", dw1, dw0.double().cpu(), 2e-3, 2e-3 * scale)
+    if epi == "swish_bwd":
+        report("nc_sums", nc1, nc0.cpu(), 1e-4, 1e-4 * max(1.0, nc0.abs().max().item()))
+
+
 @pytest.mark.parametrize("shape", [(2, 24, 54, 4, 16, 16), (1, 96, 216, 2, 14, 14), (2, 200, 72, 2, 7, 7), (1, 432, 192, 3, 7, 7)])
 def test_pw_packed_panels(gpu, shape):
     """bf16 GEMMs fed from x3d_pw_pack_weights panels give bit-identical results to the in-kernel fp32->bf16

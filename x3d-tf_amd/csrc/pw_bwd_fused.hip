@@ -1,0 +1,435 @@
+// x3d_pw_bwd: data AND weight gradient of a pointwise convolution in ONE pass over dY (bf16 storage).
+//
+// The separate kernels (pw_dgrad.hip, pw_wgrad.hip) each stream g and yraw to rebuild dY = A*g + B*yraw + C,
+// and the `c` conv additionally streams the raw depthwise output twice (swish' in the dgrad epilogue, swish in
+// the wgrad prologue).  On the stage-2/3 layers (<= 128 channels either side) those re-reads are ~40 % of the
+// backward traffic of the layer.  Here a workgroup stages the dY tile [Co][128 points] once in LDS and uses it
+//   * as the B operand of   dX[ci][p]  = sum_co W[co][ci] * dY[co][p]      (read transposed, ds_read_b64_tr_b16)
+//   * as the A operand of   dW[co][ci] += sum_p dY[co][p] * Xh[ci][p]      (read row-wise, ds_read_b128)
+// Xh is the conv input: for the `a` conv the block input (loaded with the tile), for the `c` conv
+// swish(gate * bn_b(braw)) -- produced by the SWISH_BWD epilogue of the dX tile from the braw values it loads
+// anyway (sigmoid shared between swish and swish').
+//
+// LDS pitch of the dY tile: the transposed read wants pitch = 64 mod 256 bytes, the row read wants an odd
+// number of 16-byte units; both hold with pitch 320 B and the 16-byte units of row k XOR-swizzled by (k>>2)&3
+// (permutes the four units of each 64-byte segment: the transposed read of a half-wave still covers one whole
+// segment per row, the 16 rows of a b128 group land on 16 distinct slots).
+//
+// dW partials stay in accumulators across the tiles of a workgroup and are added to dw with fp32 atomics once.
+#include <stdlib.h>
+
+#include "pw_gemm.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_f;
+typedef __attribute__((ext_vector_type(8))) short s16x8_f;
+
+struct PwBwdArgs {
+  const void* g; const void* yraw; const float* coef;   // dY = A*g + B*yraw + C   rows = Co
+  const void* wp; int wp_rows;                          // dgrad panel [roundup(Ci,32)][Kp + 8] bf16
+  void* dx;                                             // [N][Ci][P]
+  const void* add; const void* braw; const float* b_ss; const float* egate; double* nc_sums;
+  int eH, eW;
+  const void* x;                                        // EPI != SWISH_BWD: conv input [N][Ci][P]
+  float* dw;                                            // [Co][Ci]
+  int N, Co, Ci, Kp;
+  long long P;
+  int tiles_per_block;
+};
+
+#define FB_BN 128
+#define FB_YP 160    // dY pitch (elements): 320 B
+#define FB_XP 136    // Xh pitch (elements): 272 B = 17 units
+#define FB_OP 132    // fp32 output slab pitch
+
+// MT: 32-row tiles of Ci (dX rows / dW columns); KT: 32-row tiles of Co (dY rows / dW rows)
+template <int MT, int KT, int EPI>
+__global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef bf16 T;
+  constexpr int BN = FB_BN, YP = FB_YP, XP = FB_XP, OP = FB_OP;
+  constexpr bool SWB = (EPI == X3D_EPI_SWISH_BWD);
+  constexpr int NT = MT * KT;                       // dW tiles
+  constexpr int TPW = (NT + 3) / 4;                 // dW tiles per wave
+  constexpr int NKS = NT >= 4 ? 1 : 4 / NT;         // k-parts (points) per tile when there are fewer tiles than waves
+  constexpr int NVY = KT * 2;                       // dY staging vectors per thread (each of g, yraw)
+  constexpr int NVX = MT * 2;                       // x staging vectors per thread
+  constexpr int ROWS_PT = MT * 2;                   // dX rows per thread over all slabs
+  const int Kp = a.Kp, WP = Kp + 8;
+  // LDS: dY tile | Xh tile | W panel | fp32 slab (the slab aliases the dY tile when the weight-gradient MFMAs
+  // run before the epilogue, i.e. whenever Xh does not come out of the epilogue)
+  // the widest `c` layers pass the slab in two 16-row halves: 8.4 KB less LDS keeps two workgroups per CU
+  constexpr bool HALF_SLAB = SWB && MT == 4;
+  constexpr size_t YS_B = (size_t)KT * 32 * YP * 2, XS_B = (size_t)MT * 32 * XP * 2, OS_B = (size_t)(HALF_SLAB ? 16 : 32) * OP * 4;
+  bf16* Ys = (bf16*)smem_raw;
+  bf16* Xs = (bf16*)(smem_raw + YS_B);
+  bf16* Ws = (bf16*)(smem_raw + YS_B + XS_B);
+  float* Os = SWB ? (float*)(smem_raw + YS_B + XS_B + (size_t)MT * 32 * WP * 2) : (float*)smem_raw;
+  static_assert(SWB || OS_B <= YS_B + XS_B, "slab must fit the dY + Xh tiles it aliases (both are rewritten by every commit)");
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int tiles_per_n = (int)((a.P + BN - 1) / BN);
+  const int total_tiles = tiles_per_n * a.N;
+  const int tile_begin = blockIdx.x * a.tiles_per_block;
+  const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
+
+  // ---- one-time LDS set-up: zero the dY / Xh tiles (padding rows stay zero), copy the weight panel
+  {
+    bf16x8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; e++) zero[e] = (bf16)0.f;
+    for (int i = tid; i < (int)((YS_B + XS_B) / 16); i += 256) ((bf16x8*)smem_raw)[i] = zero;
+    const bf16x8* src = (const bf16x8*)a.wp;
+    const int nvec = MT * 32 * WP / 8;
+    const int lim = min(MT * 32, a.wp_rows) * WP / 8;
+#pragma unroll 4
+    for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
+  }
+
+  // ---- register-staged prefetch of the next tile: row (tid>>4) + 16*i, 8 points at unit (tid&15)
+  const int srow = tid >> 4, sunit = tid & 15;
+  bf16x8 rg[NVY], ry[NVY], rx[SWB ? 1 : NVX];
+  auto issue = [&](int tile) {
+    const int n = tile / tiles_per_n;
+    const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < NVY; i++) {
+      const int k = srow + 16 * i;
+      rg[i] = z; ry[i] = z;
+      if (k < a.Co && p < a.P) {
+        const long long o = ((long long)n * a.Co + k) * a.P + p;
+        rg[i] = *(const bf16x8*)((const T*)a.g + o);
+        ry[i] = *(const bf16x8*)((const T*)a.yraw + o);
+      }
+    }
+    if constexpr (!SWB) {
+#pragma unroll
+      for (int i = 0; i < NVX; i++) {
+        const int m = srow + 16 * i;
+        rx[i] = z;
+        if (m < a.Ci && p < a.P) rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Ci + m) * a.P + p);
+      }
+    }
+  };
+  auto commit = [&](int tile) {
+    const int n = tile / tiles_per_n;
+    const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
+    const bool pin = p < a.P;
+#pragma unroll
+    for (int i = 0; i < NVY; i++) {
+      const int k = srow + 16 * i;
+      if (k >= Kp) continue;                      // rows Kp.. stay zero
+      const bool inb = (k < a.Co) && pin;         // padded rows / points are exactly zero (C must not leak in)
+      const float A = inb ? a.coef[k * 4] : 0.f, B = inb ? a.coef[k * 4 + 1] : 0.f, C = inb ? a.coef[k * 4 + 2] : 0.f;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
+      VecIO<bf16, 8>::store(&Ys[k * YP + ((sunit ^ ((k >> 2) & 3)) << 3)], v);
+    }
+    if constexpr (!SWB) {
+#pragma unroll
+      for (int i = 0; i < NVX; i++) {
+        const int m = srow + 16 * i;
+        *(bf16x8*)&Xs[m * XP + sunit * 8] = rx[i];   // zeros where m >= Ci or p >= P
+      }
+    }
+  };
+
+  // per-(sample, channel) sums of the SWISH_BWD epilogue
+  float st1[SWB ? ROWS_PT : 1], st2[SWB ? ROWS_PT : 1];
+  if constexpr (SWB) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
+  auto flush_sums = [&](int n) {
+    if constexpr (SWB) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        const float s1 = row16_sum(st1[i]), s2 = row16_sum(st2[i]);
+        const int m = (tid >> 4) + 16 * i;
+        if ((tid & 15) == 0 && m < a.Ci) {
+          double* d = a.nc_sums + ((long long)n * a.Ci + m) * 2;
+          atomic_add_d(d, (double)s1);
+          atomic_add_d(d + 1, (double)s2);
+        }
+        st1[i] = 0.f;
+        st2[i] = 0.f;
+      }
+    }
+  };
+
+  // transposed-read lane geometry (dY tile as B operand): lane -> (row 8*(g16>>1)+q (+4), 4 points)
+  const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_row = 8 * (g16 >> 1) + q;
+  const int tr_unit = wid * 4 + 2 * (g16 & 1) + (pp >> 1);          // logical 16-byte unit of this lane's 8 bytes
+  const int tr_off0 = ((tr_unit ^ ((tr_row >> 2) & 3)) << 3) + (pp & 1) * 4;          // rows kk + tr_row
+  const int tr_off1 = ((tr_unit ^ (((tr_row + 4) >> 2) & 3)) << 3) + (pp & 1) * 4;    // rows kk + tr_row + 4
+  typedef s16x4_f __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+  f32x16 acc_dw[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc_dw[s][j] = 0.f;
+
+  // dW[co][ci] += dY[co][:] . Xh[ci][:] over the 128 points of the tile
+  auto wgrad_mfma = [&]() {
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      int id = wid + 4 * s, kpart = 0;
+      if constexpr (NKS > 1) { id = wid % NT; kpart = wid / NT; }
+      if (id < NT) {
+        const int cot = id / MT, cit = id - cot * MT;
+        const int rowy = cot * 32 + r;
+        const int swz = (rowy >> 2) & 3;
+        const bf16* yrow = Ys + rowy * YP;
+        const bf16* xrow = Xs + (cit * 32 + r) * XP + 8 * half;
+        constexpr int KSTEPS = (BN / 16) / NKS;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+          const int u = (kpart * KSTEPS + ks) * 2 + half;
+          const bf16x8 af = *(const bf16x8*)(yrow + ((u ^ swz) << 3));
+          const bf16x8 bf = *(const bf16x8*)(xrow + (kpart * KSTEPS + ks) * 16);
+          acc_dw[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc_dw[s], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (tile_begin < tile_end) issue(tile_begin);
+  int n_prev = tile_begin < tile_end ? tile_begin / tiles_per_n : 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+    if constexpr (SWB) {
+      if (n != n_prev) flush_sums(n_prev);
+    }
+    n_prev = n;
+    __syncthreads();            // every reader of the previous tile's dY / Xh / slab is done
+    commit(tile);
+    __syncthreads();
+    if (tile + 1 < tile_end) issue(tile + 1);
+
+    // ---- dX tile: acc[s] (rows s*32.., this wave's 32 points) = W^T dY
+    f32x16 acc[MT];
+#pragma unroll
+    for (int s = 0; s < MT; s++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
+    for (int kk = 0; kk < Kp; kk += 16) {
+      const s16x4_f b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Ys[(kk + tr_row) * YP + tr_off0]));
+      const s16x4_f b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Ys[(kk + tr_row + 4) * YP + tr_off1]));
+      const s16x8_f bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bs);
+#pragma unroll
+      for (int s = 0; s < MT; s++) {
+        const bf16x8 afrag = *(const bf16x8*)&Ws[(s * 32 + r) * WP + kk + 8 * half];
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[s], 0, 0, 0);
+      }
+    }
+    if constexpr (!SWB) wgrad_mfma();   // Xh came with the tile: finish with the dY tile before the slab reuses its LDS
+
+    // ---- epilogue in 32-row slabs through LDS: thread owns rows (tid>>4) + 16*ii, 8 points at (tid&15)*8
+    const int oc = (tid & 15) * 8;
+#pragma unroll
+    for (int sl = 0; sl < MT; sl++) {
+      if constexpr (!HALF_SLAB) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) Os[((j & 3) + 8 * (j >> 2) + 4 * half) * OP + wid * 32 + r] = acc[sl][j];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ii++) {
+        if constexpr (HALF_SLAB) {   // rows 16*ii .. 16*ii+15 of the tile are accumulator registers 8*ii .. 8*ii+7
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 8; j++) Os[((j & 3) + 8 * (j >> 2) + 4 * half) * OP + wid * 32 + r] = acc[sl][8 * ii + j];
+          __syncthreads();
+        }
+        const int i = sl * 2 + ii;
+        const int row = HALF_SLAB ? (tid >> 4) : (tid >> 4) + 16 * ii;   // row inside the slab
+        const int m = sl * 32 + (tid >> 4) + 16 * ii;
+        const long long p = p0 + oc;
+        if (m >= a.Ci || p >= a.P) continue;
+        float val[8];
+        {
+          const f32x4 v0 = *(const f32x4*)&Os[row * OP + oc], v1 = *(const f32x4*)&Os[row * OP + oc + 4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
+        }
+        const long long o = ((long long)n * a.Ci + m) * a.P + p;   // P % 8 == 0: the 8 points are all inside
+        if constexpr (EPI == X3D_EPI_ADD) {
+          float ad[8];
+          VecIO<T, 8>::load((const T*)a.add + o, ad);
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] += ad[e];
+        } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
+          const long long hw = (long long)a.eH * a.eW;
+          const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+          const long long T_ = a.P / hw;
+          if ((a.eW & 7) == 0) {
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int h = rem / a.eW, w = rem - h * a.eW;
+            if ((h & 1) == 0) {
+              const long long oa = ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
+              float ad[4];
+              VecIO<T, 4>::load((const T*)a.add + oa, ad);
+#pragma unroll
+              for (int e = 0; e < 4; e++) val[2 * e] += ad[e];
+            }
+          } else {
+            for (int e = 0; e < 8; e++) {
+              const long long pe = p + e;
+              const long long t = pe / hw;
+              const int rem = (int)(pe - t * hw);
+              const int h = rem / a.eW, w = rem - h * a.eW;
+              if (((h | w) & 1) == 0) {
+                const long long oa = ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
+                val[e] += to_f<T>(((const T*)a.add)[oa]);
+              }
+            }
+          }
+        } else if constexpr (SWB) {
+          float b[8], xh[8];
+          VecIO<T, 8>::load((const T*)a.braw + o, b);
+          const float sb = a.b_ss[m * 2], tb = a.b_ss[m * 2 + 1];
+          const float gt = a.egate ? a.egate[(long long)n * a.Ci + m] : 1.0f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float u = (sb * b[e] + tb) * gt;
+            const float sg = sigmoidf_(u);
+            xh[e] = u * sg;                                        // conv input of the forward pass
+            const float dv = val[e] * (sg * (1.0f + u * (1.0f - sg)));
+            val[e] = dv;
+            st1[i] += dv;
+            st2[i] += dv * b[e];
+          }
+          VecIO<bf16, 8>::store(&Xs[m * XP + oc], xh);
+        }
+        VecIO<T, 8>::store((T*)a.dx + o, val);
+      }
+    }
+    if constexpr (SWB) {
+      __syncthreads();   // Xh tile complete
+      wgrad_mfma();
+    }
+  }
+  if (tile_begin < tile_end) flush_sums(n_prev);
+
+  // ---- dW partial -> global (fp32 atomics)
+  if (tile_begin < tile_end) {
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      int id = wid + 4 * s;
+      if constexpr (NKS > 1) id = wid % NT;
+      if (id < NT) {
+        const int cot = id / MT, cit = id - cot * MT;
+        const int ci = cit * 32 + r;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const int co = cot * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+          if (co < a.Co && ci < a.Ci) atomicAdd(&a.dw[(long long)co * a.Ci + ci], acc_dw[s][j]);
+        }
+      }
+    }
+  }
+}
+
+static inline size_t fb_lds_bytes(int MT, int KT, int Kp, bool swb) {
+  return (size_t)KT * 32 * FB_YP * 2 + (size_t)MT * 32 * FB_XP * 2 + (size_t)MT * 32 * (Kp + 8) * 2 +
+         (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0);
+}
+
+template <int MT, int KT, int EPI>
+static int fb_launch(PwBwdArgs& a, hipStream_t st) {
+  const size_t lds = fb_lds_bytes(MT, KT, a.Kp, EPI == X3D_EPI_SWISH_BWD);
+  X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd: needs %zu B of LDS", lds);
+  auto kern = pw_bwd_fused_kernel<MT, KT, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  static size_t occ_lds[8];
+  static int occ_slots[8], occ_n = 0;
+  int slots = 0;
+  for (int i = 0; i < occ_n; i++) if (occ_lds[i] == lds) slots = occ_slots[i];
+  if (slots == 0) {
+    int nb = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    slots = nb * cus;
+    if (occ_n < 8) { occ_lds[occ_n] = lds; occ_slots[occ_n] = slots; occ_n++; }
+  }
+  const long long total_tiles = ceil_div_ll(a.P, FB_BN) * a.N;
+  X3D_REQUIRE(total_tiles < (1ll << 31), "pw_bwd: too many tiles");
+  long long tpb = ceil_div_ll(total_tiles, slots);   // one balanced round
+  if (tpb < 4) tpb = 4;                               // keeps the dW atomics (<= 32 KB) small against the streamed tiles
+  a.tiles_per_block = (int)tpb;
+  const long long gx = ceil_div_ll(total_tiles, tpb);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_bwd_fused");
+  return X3D_OK;
+}
+
+template <int EPI>
+static int fb_pick(PwBwdArgs& a, hipStream_t st) {
+  const int mt = ceil_div(a.Ci, 32), kt = ceil_div(a.Co, 32);
+  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+#define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<M_, K_, EPI>(a, st);
+  FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 4) FB_CASE(4, 1) FB_CASE(4, 2)
+#undef FB_CASE
+  x3d_set_error("pw_bwd: unsupported tile shape");
+  return X3D_ERR_INVALID;
+}
+
+// eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
+static bool fb_supported(const x3d_pw_bwd_args* b) {
+  if (b->dtype != X3D_BF16 || !b->w_panel || !b->coef || !b->yraw) return false;
+  const int mt = ceil_div(b->Cin, 32), kt = ceil_div(b->Cout, 32);
+  if (mt > 4 || kt > 4 || mt * kt > 8) return false;
+  const long long P = (long long)b->T * b->H * b->W;
+  if (P % 8) return false;
+  const void* ps[] = {b->g, b->yraw, b->dx, b->w_panel, b->epi == X3D_EPI_SWISH_BWD ? b->braw : b->x,
+                      b->epi == X3D_EPI_ADD ? b->add : nullptr};
+  for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;
+  if (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8)) return false;
+  if (b->epi != X3D_EPI_ADD && b->epi != X3D_EPI_ADD_STRIDED && b->epi != X3D_EPI_SWISH_BWD) return false;
+  const int Kp = (b->Cout + 15) & ~15;
+  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  return fb_lds_bytes(MT, KT, Kp, b->epi == X3D_EPI_SWISH_BWD) <= 160 * 1024;
+}
+
+extern "C" int x3d_pw_bwd_supported(const x3d_pw_bwd_args* b) { return (b && fb_supported(b)) ? 1 : 0; }
+
+extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
+  X3D_REQUIRE(b && b->g && b->yraw && b->coef && b->dx && b->dw, "pw_bwd: null pointer");
+  X3D_REQUIRE(b->N > 0 && b->Cin > 0 && b->Cout > 0 && b->T > 0 && b->H > 0 && b->W > 0, "pw_bwd: bad extents");
+  X3D_REQUIRE(fb_supported(b), "pw_bwd: shape / alignment / epilogue not covered by the fused kernel "
+                               "(x3d_pw_bwd_supported() == 0): use x3d_pw_dgrad + x3d_pw_wgrad");
+  if (b->epi == X3D_EPI_SWISH_BWD)
+    X3D_REQUIRE(b->braw && b->b_scale_shift && b->nc_sums, "pw_bwd: SWISH_BWD needs braw/b_scale_shift/nc_sums");
+  else
+    X3D_REQUIRE(b->x && b->add, "pw_bwd: ADD epilogues need x (conv input) and add");
+  PwBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
+  a.wp = b->w_panel; a.wp_rows = (b->Cin + 31) & ~31;
+  a.dx = b->dx; a.add = b->add; a.braw = b->braw; a.b_ss = b->b_scale_shift; a.egate = b->gate; a.nc_sums = b->nc_sums;
+  a.eH = b->H; a.eW = b->W;
+  a.x = b->x; a.dw = b->dw;
+  a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin; a.Kp = (b->Cout + 15) & ~15;
+  a.P = (long long)b->T * b->H * b->W;
+  hipStream_t st = (hipStream_t)stream;
+  switch (b->epi) {
+    case X3D_EPI_ADD: return fb_pick<X3D_EPI_ADD>(a, st);
+    case X3D_EPI_ADD_STRIDED: return fb_pick<X3D_EPI_ADD_STRIDED>(a, st);
+    default: return fb_pick<X3D_EPI_SWISH_BWD>(a, st);
+  }
+}

@@ -35,6 +35,13 @@ class PwDgradArgs(C.Structure):
                 ("w_panel", _vp)]
 
 
+class PwBwdArgs(C.Structure):
+    _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("w_panel", _vp), ("dx", _vp), ("epi", _i),
+                ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
+                ("x", _vp), ("dw", _vp),
+                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+
+
 class PwPackItem(C.Structure):
     _fields_ = [("w", _vp), ("fwd_panel", _vp), ("dgrad_panel", _vp), ("Cout", _i), ("Cin", _i)]
 
@@ -78,6 +85,8 @@ _SIGS = {
     "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
     "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
+    "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
+    "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
     "x3d_pw_panel_elems": ([_i, _i], _ll),
     "x3d_pw_pack_weights": ([_vp, _i, _vp], _i),
     "x3d_dw3d_fwd": ([C.POINTER(Dw3dFwdArgs), _vp], _i),

@@ -201,6 +201,9 @@ class X3D:
         self._build_layers()
         self._dropout_mask_override = None
         self.last_loss = None
+        # fused dgrad + wgrad of the pointwise convs (x3d_pw_bwd) where it applies; X3D_NO_FUSED_PW_BWD=1 records
+        # the separate kernels instead (A/B measurements)
+        self._fuse_pw_bwd = os.environ.get("X3D_NO_FUSED_PW_BWD", "0") != "1"
 
     # ---------------------------------------------------------------------------------------------
     # parameters: one flat fp32 buffer (trainable first, then BN moving statistics), one flat
@@ -639,14 +642,21 @@ class X3D:
             # c
             wc = hip.PwWgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate),
                                  ACT_SWISH, _p(g[f"{q}/c/kernel"]), n, b.inner, b.cout, t, B.ho, B.wo, 1, dt)
-            pl.rec(Bk, "x3d_pw_wgrad", wc)
             B.nc_sums = pl.acc64(n, b.inner, 2)
             dvv = pl.dv[:B.b_raw.numel()]
             dc = hip.PwDgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(p[f"{q}/c/kernel"]), _p(dvv),
                                  EPI_SWISH_BWD, None, _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, n, b.inner,
                                  b.cout, t, B.ho, B.wo, dt)
             dc.w_panel = self._wp(f"{q}/c/kernel", True)
-            pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
+            # one pass over g / c_raw / b_raw for both gradients where the fused kernel covers the layer
+            fc = hip.PwBwdArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), dc.w_panel, _p(dvv), EPI_SWISH_BWD, None,
+                               _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, None, _p(g[f"{q}/c/kernel"]), n, b.inner,
+                               b.cout, t, B.ho, B.wo, dt)
+            if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fc)):
+                pl.rec(Bk, "x3d_pw_bwd", ("field", fc, {"nc_sums": B.nc_sums}))
+            else:
+                pl.rec(Bk, "x3d_pw_wgrad", wc)
+                pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
             # SE + BN_b backward from the per-(n,c) sums
             se = hip.SeBnbBwdArgs(
                 None, None, float(P_out), _p(B.bn_b.ss), _p(B.bn_b.mi), _p(p[f"{q}/bn_b/gamma"]),
@@ -667,7 +677,6 @@ class X3D:
             # a
             wa = hip.PwWgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(B.x), None, None, ACT_NONE,
                                  _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, 1, dt)
-            pl.rec(Bk, "x3d_pw_wgrad", wa)
             nxt = pl.gbuf[1 - cur][:B.x.numel()]
             if b.has_shortcut_conv:
                 pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_r.bsums), float(n * P_out), B.bn_r.mi,
@@ -687,7 +696,13 @@ class X3D:
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt), EPI_ADD,
                                      _p(gten), None, None, None, None, n, b.cin, b.inner, t, B.hh, B.ww, dt)
             da.w_panel = self._wp(f"{q}/a/kernel", True)
-            pl.rec(Bk, "x3d_pw_dgrad", da)
+            fa = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
+                               _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt)
+            if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
+                pl.rec(Bk, "x3d_pw_bwd", fa)
+            else:
+                pl.rec(Bk, "x3d_pw_wgrad", wa)
+                pl.rec(Bk, "x3d_pw_dgrad", da)
             cur = 1 - cur
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt

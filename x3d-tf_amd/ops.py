@@ -125,6 +125,21 @@ def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None
     return dx
 
 
+def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_ss=None, gate=None, nc_sums=None):
+    """Fused dgrad + wgrad (x3d_pw_bwd).  g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]; dw: [Cout,Cin] +=.
+    Returns False (nothing launched) when the fused kernel does not cover the call."""
+    _chk(g, yraw, coef, w_panel, dx, dw, x, add, braw, b_ss, gate, nc_sums)
+    n, cout, t, h, ww = g.shape
+    cin = dx.shape[1]
+    a = hip.PwBwdArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w_panel), ptr(dx), epi, ptr(add), ptr(braw), ptr(b_ss),
+                      ptr(gate), ptr(nc_sums), ptr(x), ptr(dw), n, cin, cout, t, h, ww, hip.dtype_code(g.dtype))
+    import ctypes as C
+    if not hip.load().x3d_pw_bwd_supported(C.byref(a)):
+        return False
+    hip.call_struct("x3d_pw_bwd", a)
+    return True
+
+
 def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
     """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points."""
     _chk(g, yraw, coef, x, dw, in_ss, in_gate)
