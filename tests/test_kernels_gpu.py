@@ -65,6 +65,8 @@ def _affine(x, ss, gate=None, act=0):
     (1, 216, 96, 2, 7, 7, 1, "swish"),     # K chunking (does not fit LDS resident)
     (1, 24, 24, 2, 9, 11, 2, None),        # odd extents with stride 2
     (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
+    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
+    (1, 24, 24, 2, 32, 32, 2, None),       # Wo % 8 == 0
 ])
 def test_pw_fwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
@@ -266,6 +268,7 @@ def test_pw_dgrad(gpu, dtype, shape, epi):
     (2, 24, 54, 4, 12, 12, 1, None), (2, 54, 24, 3, 10, 10, 1, "swish"), (2, 24, 48, 4, 12, 12, 2, None),
     (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
     (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),
+    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
 ])
 def test_pw_wgrad(gpu, dtype, shape):
     ops = _ops()

@@ -139,6 +139,50 @@ static inline int pick_vec(int elem_bytes, long long extent, const void* p0, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// stride-(1,2,2) 'valid' 1x1x1 shortcut conv: 8 consecutive OUTPUT points (t, ho, wo..) need the even elements of
+// their input rows.  The outputs are taken in groups of GV (GV | Wo, so a group never crosses an output row):
+// one aligned load of 2*GV input elements per group (16 / 8 / 4 bytes for GV = 4 / 2 / 1).  lo | hi hold the 16
+// gathered elements in order, so output j of the vector is element 2*j whatever GV is.
+// Caller guarantees: W % (2*GV) == 0, Wo % GV == 0, base 4*GV-byte aligned, all 8 outputs inside the tensor.
+// ---------------------------------------------------------------------------------------------
+template <int GV>
+__device__ __forceinline__ void strided_gather16(const bf16* base, long long p, int H, int W, int Ho, int Wo,
+                                                 bf16x8& lo, bf16x8& hi) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  const long long hw = (long long)Ho * Wo;
+  long long t = p / hw;
+  const int rem = (int)(p - t * hw);
+  int ho = rem / Wo, wo = rem - ho * Wo;
+  unsigned int w[8];
+#pragma unroll
+  for (int gi = 0; gi < 8 / GV; gi++) {
+    const bf16* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2;
+    if constexpr (GV == 4) {
+      const u32x4 v = *(const u32x4*)src;
+      w[gi * 4] = v[0]; w[gi * 4 + 1] = v[1]; w[gi * 4 + 2] = v[2]; w[gi * 4 + 3] = v[3];
+    } else if constexpr (GV == 2) {
+      const u32x2 v = *(const u32x2*)src;
+      w[gi * 2] = v[0]; w[gi * 2 + 1] = v[1];
+    } else {
+      w[gi] = *(const unsigned int*)src;
+    }
+    wo += GV;
+    if (wo >= Wo) { wo = 0; if (++ho >= Ho) { ho = 0; ++t; } }
+  }
+  const u32x4 l = {w[0], w[1], w[2], w[3]}, h = {w[4], w[5], w[6], w[7]};
+  lo = __builtin_bit_cast(bf16x8, l);
+  hi = __builtin_bit_cast(bf16x8, h);
+}
+// largest group size the gather supports for a stride-2 source of row length W sampled to Wo (0: use the scalar path)
+static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
+  if ((P % 8) != 0) return 0;
+  for (int gv = 4; gv >= 1; gv >>= 1)
+    if ((Wo % gv) == 0 && (W % (2 * gv)) == 0 && ((uintptr_t)x % (4 * gv)) == 0) return gv;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // activations
 // ---------------------------------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence `1.0f / x` compiles to:

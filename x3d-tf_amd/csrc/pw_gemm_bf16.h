@@ -30,7 +30,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define PWB_XP (PWB_BN + 32)   // X pitch (elements)
 #define PWB_OP (PWB_BN + 4)    // output-tile pitch (floats)
 
-template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
+template <int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
@@ -130,15 +130,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         if constexpr (STRIDED) yr[i] = z;
         if (ok) {
           if constexpr (STRIDED) {
-            // stride-(1,2,2) 'valid' 1x1x1 conv: 8 output points of one output row are the even elements
-            // of 16 contiguous input elements -> two 16-byte loads (Wo % 8 == 0 checked by the host)
-            const long long hw = (long long)a.Ho * a.Wo;
-            const long long t = p / hw;
-            const int rem = (int)(p - t * hw);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            const long long o = ((long long)n * a.K + gk) * a.Pin + (t * a.H + (long long)ho * 2) * a.W + (long long)wo * 2;
-            xr[i] = *(const bf16x8*)((const T*)a.x + o);
-            yr[i] = *(const bf16x8*)((const T*)a.x + o + 8);
+            // strided shortcut: gather the even input elements, STRIDED = outputs per aligned load (common.h)
+            strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.K + gk) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, xr[i], yr[i]);
           } else {
             // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
             const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
@@ -432,7 +425,7 @@ static inline int pw_bf16_pick_mt(int M, int K) {
   return 2;
 }
 
-template <int VEC, int MT, int PRO, int EPI, bool STRIDED, int OVEC>
+template <int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, BN = PWB_BN;
   a.KC = (a.K + 15) & ~15;
@@ -488,7 +481,7 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <int VEC, int PRO, int EPI, bool STRIDED, int OVEC>
+template <int VEC, int PRO, int EPI, int STRIDED, int OVEC>
 static int pw_bf16_launch_tile(PwGemmArgs& a, hipStream_t st) {
   int mt = pw_bf16_pick_mt(a.M, a.K);
   if constexpr (VEC == 1) mt = mt > 2 ? 2 : mt;   // scalar fallback path: 32 staging registers per chunk, keep the panel small
@@ -506,15 +499,17 @@ template <int PRO, int EPI>
 static int pw_bf16_launch_vec(PwGemmArgs& a, int vec, int ovec, hipStream_t st) {
   if (a.stride > 1) {
     if constexpr (PRO == PRO_NONE && EPI == EPI_STATS) {
-      const bool vgather = a.stride == 2 && (a.Wo % 8) == 0 && (a.W % 8) == 0 && vec >= 8;
-      if (vgather && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, true, 8>(a, st);
-      if (ovec >= 8) return pw_bf16_launch_tile<1, PRO, EPI, true, 8>(a, st);
-      return pw_bf16_launch_tile<1, PRO, EPI, true, 1>(a, st);
+      const int gv = (a.stride == 2 && vec >= 1 && ovec >= 8) ? strided_gather_gv(a.W, a.Wo, a.P, a.x) : 0;
+      if (gv == 4) return pw_bf16_launch_tile<8, PRO, EPI, 4, 8>(a, st);
+      if (gv == 2) return pw_bf16_launch_tile<8, PRO, EPI, 2, 8>(a, st);
+      if (gv == 1) return pw_bf16_launch_tile<8, PRO, EPI, 1, 8>(a, st);
+      if (ovec >= 8) return pw_bf16_launch_tile<1, PRO, EPI, 1, 8>(a, st);
+      return pw_bf16_launch_tile<1, PRO, EPI, 1, 1>(a, st);
     } else {
       x3d_set_error("pw: strided gather only in forward");
       return X3D_ERR_INVALID;
     }
   }
-  if (vec >= 8 && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, false, 8>(a, st);
-  return pw_bf16_launch_tile<1, PRO, EPI, false, 1>(a, st);
+  if (vec >= 8 && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, 0, 8>(a, st);
+  return pw_bf16_launch_tile<1, PRO, EPI, 0, 1>(a, st);
 }

@@ -201,7 +201,7 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
 //  * strided shortcut (1x1x1, stride (1,2,2), valid): an output row segment of 8 points is the even
 //    elements of 16 contiguous input elements -> two 16-byte loads, no scalar gather.
 // ================================================================================================
-template <int MG, int NG, bool XPRO, bool STRIDED>
+template <int MG, int NG, bool XPRO, int STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
@@ -252,14 +252,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
       if constexpr (STRIDED) rx2[i] = z;
       if (ci < a.Cin && p < a.P) {
         if constexpr (STRIDED) {
-          // 8 output points of one output row = even elements of 16 contiguous input elements
-          const long long hw = (long long)a.Ho * a.Wo;
-          const long long t = p / hw;
-          const int rem = (int)(p - t * hw);
-          const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-          const long long src = ((long long)n * a.Cin + ci) * a.Pin + (t * a.H + (long long)ho * 2) * a.W + (long long)wo * 2;
-          rx[i] = *(const bf16x8*)((const T*)a.x + src);
-          if (wo * 2 + 8 < a.W) rx2[i] = *(const bf16x8*)((const T*)a.x + src + 8);
+          // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
+          strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[i], rx2[i]);
         } else {
           rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
         }
@@ -357,7 +351,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
   }
 }
 
-template <int MG, int NG, bool XPRO, bool STRIDED>
+template <int MG, int NG, bool XPRO, int STRIDED>
 static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
@@ -386,7 +380,7 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <bool XPRO, bool STRIDED>
+template <bool XPRO, int STRIDED>
 static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   // X rows may carry the swish prologue: prefer few M-groups (each re-stages every X row of its N-group)
@@ -400,8 +394,13 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
 static int pw_wgrad_v2_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
   if (vec < 8) return -1;
   if (a.stride > 1) {
-    if (a.stride != 2 || xpro || (a.Wo % 8) != 0 || (a.W % 8) != 0) return -1;
-    return pw_wgrad_v2_pick<false, true>(a, st);
+    if (a.stride != 2 || xpro) return -1;
+    switch (strided_gather_gv(a.W, a.Wo, a.P, a.x)) {
+      case 4: return pw_wgrad_v2_pick<false, 4>(a, st);
+      case 2: return pw_wgrad_v2_pick<false, 2>(a, st);
+      case 1: return pw_wgrad_v2_pick<false, 1>(a, st);
+      default: return -1;
+    }
   }
-  return xpro ? pw_wgrad_v2_pick<true, false>(a, st) : pw_wgrad_v2_pick<false, false>(a, st);
+  return xpro ? pw_wgrad_v2_pick<true, 0>(a, st) : pw_wgrad_v2_pick<false, 0>(a, st);
 }
