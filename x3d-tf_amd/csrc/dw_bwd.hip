@@ -204,21 +204,17 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < SW; i++) dBo[i] = winB[1][i + 1];
 
-      // ---- weight gradient
+      // ---- weight gradient (accumulated straight into dW: a separate partial sum costs one v_add per tap)
 #pragma unroll
       for (int kh = 0; kh < 3; kh++)
 #pragma unroll
         for (int kw = 0; kw < 3; kw++) {
-          float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
           for (int i = 0; i < SW; i++) {
-            d1 += dBo[i] * winA[kh][i * S + kw];          // kt = 1: dB[t] * act[t]
-            d2 += dB_prev[i] * winA[kh][i * S + kw];      // kt = 2: dB[t-1] * act[t]
-            d0 += dBo[i] * winA_prev[kh][i * S + kw];     // kt = 0: dB[t] * act[t-1]
+            dW[9 + kh * 3 + kw] += dBo[i] * winA[kh][i * S + kw];           // kt = 1: dB[t] * act[t]
+            dW[18 + kh * 3 + kw] += dB_prev[i] * winA[kh][i * S + kw];      // kt = 2: dB[t-1] * act[t]
+            dW[kh * 3 + kw] += dBo[i] * winA_prev[kh][i * S + kw];          // kt = 0: dB[t] * act[t-1]
           }
-          dW[kh * 3 + kw] += d0;
-          dW[9 + kh * 3 + kw] += d1;
-          dW[18 + kh * 3 + kw] += d2;
         }
 
       // ---- data gradient: plane dB[t] feeds dA[t-1] (kt=0), dA[t] (kt=1), dA[t+1] (kt=2)
