@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
   constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
   constexpr int NS = NSV > 0 ? NSV : 1;
+  // deferred emit (see the plane loop): costs NR*NA registers -- the 2x2-quad stride-2 variant would drop a wave
+  constexpr bool DEFER = (S == 1);
   const int aplane = g.RIN * g.LP;
   const int bplane = a.RB * a.LPB;
   float* Al = lds;
@@ -85,11 +87,11 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
     issue(0);
   }
 
-  float dA0[NR][NA], dA1[NR][NA], dA2[NR][NA];
+  float dA0[NR][NA], dA1[NR][NA], dA2[NR][NA], fin[NR][NA];   // fin: finished plane waiting for its deferred emit
 #pragma unroll
   for (int q = 0; q < NR; q++)
 #pragma unroll
-    for (int i = 0; i < NA; i++) { dA0[q][i] = 0.f; dA1[q][i] = 0.f; dA2[q][i] = 0.f; }
+    for (int i = 0; i < NA; i++) { dA0[q][i] = 0.f; dA1[q][i] = 0.f; dA2[q][i] = 0.f; fin[q][i] = 0.f; }
   float dW[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) dW[k] = 0.f;
@@ -184,6 +186,10 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
     }
     __syncthreads();
     if (t + 1 < g.T) issue(t + 1);
+    // plane t-2 is emitted here, one iteration after it was completed, with the araw strip loaded during the
+    // previous iteration: the store and the strip load then have a whole plane of arithmetic to retire before
+    // the in-order vmcnt wait for the prefetched planes at the top of the next iteration
+    if constexpr (DEFER) { if (t >= 2) emit(t - 2, fin); }
     if (t >= 1) load_own(t - 1);
     if (active) {
       float winA[3][WIN], winB[BR][BW];
@@ -256,12 +262,16 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < SW; i++) dB_prev[i] = dBo[i];
     }
-    if (t >= 1) emit(t - 1, dA0);
+    if constexpr (!DEFER) { if (t >= 1) emit(t - 1, dA0); }
 #pragma unroll
     for (int q = 0; q < NR; q++)
 #pragma unroll
-      for (int i = 0; i < NA; i++) { dA0[q][i] = dA1[q][i]; dA1[q][i] = dA2[q][i]; dA2[q][i] = 0.f; }
+      for (int i = 0; i < NA; i++) {
+        if constexpr (DEFER) fin[q][i] = dA0[q][i];
+        dA0[q][i] = dA1[q][i]; dA1[q][i] = dA2[q][i]; dA2[q][i] = 0.f;
+      }
   }
+  if constexpr (DEFER) { if (g.T >= 2) emit(g.T - 2, fin); }
   load_own(g.T - 1);
   emit(g.T - 1, dA0);
 

@@ -12,6 +12,8 @@
 // Per-channel BatchNorm statistics and the squeeze-excite pool are reduced in the epilogue
 // (wave shuffles -> LDS -> one fp64 atomic per workgroup).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 struct DwGeom {
@@ -125,7 +127,11 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
   return 0;
 }
 
-static int dw_pick_sw(int Wo) { return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1); }
+static int dw_pick_sw(int Wo) {
+  static const char* e = getenv("X3D_DW_SW14");   // experiment hook: strip width for 10 <= Wo < 20
+  if (e && Wo >= 10 && Wo < 20) return atoi(e);
+  return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1);
+}
 
 // staging vectors per thread for a [rows][W] plane tile
 static int dw_nsv(int rows, int W, int vec, int bd) { return ceil_div(rows * (W / vec), bd); }

@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 #pragma unroll
   for (int i = 0; i < SW; i++) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
   float s1 = 0.f, s2 = 0.f;
+  float fin[SW];   // finished output plane waiting for its (deferred) store
+#pragma unroll
+  for (int i = 0; i < SW; i++) fin[i] = 0.f;
 
   // every strip is full and SW-aligned when Wo % SW == 0: one 8/16-byte store per thread and plane instead
   // of SW two-byte stores (the scalar stores, not HBM, were the limiter of the stride-1 layers)
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
         for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + (t + 1) * iplane + map.goff[i], vec);
       }
     }
+    if (t >= 2) store_plane(t - 2, fin);
     if (active) {
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
@@ -129,10 +133,13 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
         }
       }
     }
-    if (t >= 1) store_plane(t - 1, acc0);
+    // acc0 now holds output plane t-1 complete.  Its store is DEFERRED to the start of the next iteration's
+    // arithmetic: vmcnt retires in order, so a store issued here would sit in front of the wait for the
+    // prefetched plane at the top of the next iteration and expose its full write latency every plane.
 #pragma unroll
-    for (int i = 0; i < SW; i++) { acc0[i] = acc1[i]; acc1[i] = acc2[i]; acc2[i] = 0.f; }
+    for (int i = 0; i < SW; i++) { fin[i] = acc0[i]; acc0[i] = acc1[i]; acc1[i] = acc2[i]; acc2[i] = 0.f; }
   }
+  if (g.T >= 2) store_plane(g.T - 2, fin);
   store_plane(g.T - 1, acc0);
 
   if (a.stats || a.pool) {
