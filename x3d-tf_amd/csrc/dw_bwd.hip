@@ -262,7 +262,13 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < SW; i++) dB_prev[i] = dBo[i];
     }
-    if constexpr (!DEFER) { if (t >= 1) emit(t - 1, dA0); }
+    if constexpr (!DEFER) {
+      // retire every outstanding load (the prefetched planes were issued a whole plane of arithmetic ago) BEFORE the
+      // store goes out: the wait at the top of the next iteration then has nothing to wait for, and the store's
+      // write latency is never on the critical path (vmcnt retires in order, stores included)
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
+      if (t >= 1) emit(t - 1, dA0);
+    }
 #pragma unroll
     for (int q = 0; q < NR; q++)
 #pragma unroll

@@ -291,6 +291,59 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     // ---- accumulators -> LDS output slab (col = lane&31 -> point, rows in registers) -> row-wise epilogue pass:
     // thread owns rows (tid>>4) + 16*i of the slab, an 8-point column chunk (tid&15)
     const int oc = (tid & 15) * 8;
+    // Every global load of the epilogue is issued HERE, before any store of this tile.  vmcnt retires in order
+    // (stores included) and the compiler must assume vmcnt(0) around the conditional stores, so a load issued
+    // after a store would wait for that store's write latency (once per row), and the first use of the next
+    // tile's prefetched registers would wait for the last stores.  With the loads first, their wait also covers
+    // the (older) prefetch, and nothing ever waits on a store.
+    constexpr bool EPL8 = (OVEC == 8) && (EPI == X3D_EPI_ADD || EPI == X3D_EPI_SWISH_BWD);
+    constexpr bool EPL4 = (OVEC == 8) && (EPI == X3D_EPI_ADD_STRIDED);
+    bf16x8 epl8[EPL8 ? ROWS_PT : 1];
+    bf16x4 epl4[EPL4 ? ROWS_PT : 1];
+    const bool epl4_vec = EPL4 && (a.eW & 7) == 0;
+    constexpr bool SWB_ = (EPI == X3D_EPI_SWISH_BWD);
+    float esb[SWB_ ? ROWS_PT : 1], etb[SWB_ ? ROWS_PT : 1], egt[SWB_ ? ROWS_PT : 1];   // per-row BN_b scale/shift, SE gate
+    if constexpr (SWB_) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        const int m = m0 + (tid >> 4) + 16 * i;
+        const bool ok = m < a.M;
+        esb[i] = ok ? a.b_ss[m * 2] : 0.f;
+        etb[i] = ok ? a.b_ss[m * 2 + 1] : 0.f;
+        egt[i] = (ok && a.egate) ? a.egate[(long long)n * a.M + m] : 1.0f;
+      }
+    }
+    if constexpr (EPL8 || EPL4) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        const int m = m0 + (tid >> 4) + 16 * i;
+        const long long p = p0 + oc;
+        if constexpr (EPL8) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) epl8[i][e] = (bf16)0.f;
+          if (m < a.M && p < a.P) {
+            const long long o = ((long long)n * a.M + m) * a.P + p;
+            epl8[i] = *(const bf16x8*)((const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
+          if (epl4_vec && m < a.M && p < a.P) {
+            // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
+            const long long hw = (long long)a.eH * a.eW;
+            const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+            const long long T_ = a.P / hw;
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int h = rem / a.eW, w = rem - h * a.eW;
+            if ((h & 1) == 0)
+              epl4[i] = *(const bf16x4*)((const T*)a.add + ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
+          }
+        }
+      }
+    }
+    // (forward / plain-store epilogues have no loads to hoist; an explicit vmcnt(0) before their stores was measured
+    // slower -- it exposes the just-issued prefetch of the next tile when K is one chunk)
 #pragma unroll
     for (int sl = 0; sl < NSLAB; sl++) {
     __syncthreads();   // Os aliases Xs: every wave is done with the last chunk's fragments / the previous slab
@@ -317,10 +370,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const int nvalid = (OVEC == 8) ? 8 : (int)min((long long)8, a.P - p);
       if constexpr (EPI == X3D_EPI_ADD) {
         if constexpr (OVEC == 8) {
-          float ad[8];
-          VecIO<T, 8>::load((const T*)a.add + o, ad);
 #pragma unroll
-          for (int e = 0; e < 8; e++) val[e] += ad[e];
+          for (int e = 0; e < 8; e++) val[e] += (float)epl8[i][e];
         } else {
           for (int e = 0; e < nvalid; e++) val[e] += to_f<T>(((const T*)a.add)[o + e]);
         }
@@ -328,18 +379,10 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         const long long hw = (long long)a.eH * a.eW;
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
         const long long T_ = a.P / hw;
-        if (OVEC == 8 && (a.eW & 7) == 0) {
-          // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution
-          // values (one 8-byte load)
-          const long long t = p / hw;
-          const int rem = (int)(p - t * hw);
-          const int h = rem / a.eW, w = rem - h * a.eW;
-          if ((h & 1) == 0) {
-            const long long oa = ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
-            float ad[4];
-            VecIO<T, 4>::load((const T*)a.add + oa, ad);
+        if (epl4_vec) {
+          if constexpr (EPL4) {   // loaded above (zeros on odd rows)
 #pragma unroll
-            for (int e = 0; e < 4; e++) val[2 * e] += ad[e];
+            for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           }
         } else
         for (int e = 0; e < nvalid; e++) {
@@ -355,12 +398,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
         float b[8];
         if constexpr (OVEC == 8) {
-          VecIO<T, 8>::load((const T*)a.braw + o, b);
+#pragma unroll
+          for (int e = 0; e < 8; e++) b[e] = (float)epl8[i][e];
         } else {
           for (int e = 0; e < 8; e++) b[e] = (e < nvalid) ? to_f<T>(((const T*)a.braw)[o + e]) : 0.f;
         }
-        const float sb = a.b_ss[m * 2], tb = a.b_ss[m * 2 + 1];
-        const float g = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+        const float sb = esb[i], tb = etb[i], g = egt[i];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const float dv = val[e] * swish_grad_((sb * b[e] + tb) * g);
