@@ -234,6 +234,47 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 
     // ---- epilogue in 32-row slabs through LDS: thread owns rows (tid>>4) + 16*ii, 8 points at (tid&15)*8
     const int oc = (tid & 15) * 8;
+    // every global load of the epilogue before its first store (vmcnt retires in order, stores included: a load
+    // issued behind a store waits for the store's write latency)
+    constexpr bool EPL8 = (EPI == X3D_EPI_ADD) || SWB;
+    bf16x8 epl8[EPL8 ? ROWS_PT : 1];
+    bf16x4 epl4[EPL8 ? 1 : ROWS_PT];
+    float esb[SWB ? ROWS_PT : 1], etb[SWB ? ROWS_PT : 1], egt[SWB ? ROWS_PT : 1];
+    const bool epl4_vec = (a.eW & 7) == 0;
+    // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills)
+    constexpr bool HOIST = MT <= 2;
+    auto epi_load = [&](int i) {
+      const int m = (tid >> 4) + 16 * i;
+      const long long p = p0 + oc;
+      const bool ok = m < a.Ci && p < a.P;
+      if constexpr (EPL8) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) epl8[i][e] = (bf16)0.f;
+        if (ok) epl8[i] = *(const bf16x8*)((const T*)(SWB ? a.braw : a.add) + ((long long)n * a.Ci + m) * a.P + p);
+        if constexpr (SWB) {
+          esb[i] = m < a.Ci ? a.b_ss[m * 2] : 0.f;
+          etb[i] = m < a.Ci ? a.b_ss[m * 2 + 1] : 0.f;
+          egt[i] = (m < a.Ci && a.egate) ? a.egate[(long long)n * a.Ci + m] : 1.0f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
+        if (ok && epl4_vec) {
+          const long long hw = (long long)a.eH * a.eW;
+          const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+          const long long T_ = a.P / hw;
+          const long long t = p / hw;
+          const int rem = (int)(p - t * hw);
+          const int h = rem / a.eW, w = rem - h * a.eW;
+          if ((h & 1) == 0)
+            epl4[i] = *(const bf16x4*)((const T*)a.add + ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
+        }
+      }
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) epi_load(i);
+    }
 #pragma unroll
     for (int sl = 0; sl < MT; sl++) {
       if constexpr (!HALF_SLAB) {
@@ -262,26 +303,17 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
           for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
         }
         const long long o = ((long long)n * a.Ci + m) * a.P + p;   // P % 8 == 0: the 8 points are all inside
+        if constexpr (!HOIST) epi_load(i);
         if constexpr (EPI == X3D_EPI_ADD) {
-          float ad[8];
-          VecIO<T, 8>::load((const T*)a.add + o, ad);
 #pragma unroll
-          for (int e = 0; e < 8; e++) val[e] += ad[e];
+          for (int e = 0; e < 8; e++) val[e] += (float)epl8[i][e];
         } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
           const long long hw = (long long)a.eH * a.eW;
           const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
           const long long T_ = a.P / hw;
-          if ((a.eW & 7) == 0) {
-            const long long t = p / hw;
-            const int rem = (int)(p - t * hw);
-            const int h = rem / a.eW, w = rem - h * a.eW;
-            if ((h & 1) == 0) {
-              const long long oa = ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
-              float ad[4];
-              VecIO<T, 4>::load((const T*)a.add + oa, ad);
+          if (epl4_vec) {   // loaded above (zeros on odd rows)
 #pragma unroll
-              for (int e = 0; e < 4; e++) val[2 * e] += ad[e];
-            }
+            for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           } else {
             for (int e = 0; e < 8; e++) {
               const long long pe = p + e;
@@ -296,9 +328,9 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
           }
         } else if constexpr (SWB) {
           float b[8], xh[8];
-          VecIO<T, 8>::load((const T*)a.braw + o, b);
-          const float sb = a.b_ss[m * 2], tb = a.b_ss[m * 2 + 1];
-          const float gt = a.egate ? a.egate[(long long)n * a.Ci + m] : 1.0f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) b[e] = (float)epl8[i][e];
+          const float sb = esb[i], tb = etb[i], gt = egt[i];
 #pragma unroll
           for (int e = 0; e < 8; e++) {
             const float u = (sb * b[e] + tb) * gt;
