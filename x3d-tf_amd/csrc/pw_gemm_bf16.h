@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   typedef bf16 T;
   constexpr int BM = MT * 32, BN = PWB_BN, XP = PWB_XP, OP = PWB_OP, KCH = PWB_KCH;
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
+  // buffer stores with a static count per tile (see the epilogue); M*P*2 < 2^31 bytes is checked by the host
+  constexpr bool BSTORE = (OVEC == 8);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
   constexpr int VPR = BN / VEC;                       // staging vectors per row
   constexpr int NSV = (KCH * VPR + 255) / 256;        // staging vectors per thread per chunk
   constexpr int ROWS_PT = BM / 16;                    // output rows owned per thread in the epilogue passes
@@ -225,6 +228,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 
   f32x16 acc[MT];
   if (tile_begin < tile_end) issue_loads(tile_begin, 0);
+  if constexpr (BSTORE) {
+    // ROWS_PT discarded stores behind the first prefetch: the loop-carried path has exactly ROWS_PT stores behind
+    // every prefetch, and the waitcnt pass only emits vmcnt(ROWS_PT) if the entry path looks the same
+    __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((T*)a.y, 0, 0, 0x00020000);
+    u32x4_ z0 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) __builtin_amdgcn_raw_buffer_store_b128(z0, r0, 0x80000000u, 0, 0);
+  }
 
   // reduce the row sums over the 16 threads that share a row and publish them (fp64 atomics)
   auto flush_sums = [&](int n) {
@@ -291,6 +302,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     // ---- accumulators -> LDS output slab (col = lane&31 -> point, rows in registers) -> row-wise epilogue pass:
     // thread owns rows (tid>>4) + 16*i of the slab, an 8-point column chunk (tid&15)
     const int oc = (tid & 15) * 8;
+    __amdgpu_buffer_rsrc_t yrsrc;
+    if constexpr (BSTORE)
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc((T*)a.y + (long long)n * a.M * a.P, 0, (int)((long long)a.M * a.P * 2), 0x00020000);
     // Every global load of the epilogue is issued HERE, before any store of this tile.  vmcnt retires in order
     // (stores included) and the compiler must assume vmcnt(0) around the conditional stores, so a load issued
     // after a store would wait for that store's write latency (once per row), and the first use of the next
@@ -359,7 +373,11 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const int row = (tid >> 4) + 16 * ii;            // row inside the slab
       const int m = m0 + sl * SLAB * 32 + row;
       const long long p = p0 + oc;
-      if (m >= a.M || p >= a.P) continue;
+      // OVEC == 8: no branch around the row -- invalid rows / points run the arithmetic on zeros and their store
+      // is dropped by the buffer bounds check, so the number of stores per tile is static and the compiler can
+      // count them in s_waitcnt vmcnt(N) instead of waiting for every one of them (BSTORE below)
+      const bool rvalid = (m < a.M) && (p < a.P);
+      if constexpr (!BSTORE) { if (!rvalid) continue; }
       float val[8];
       {
         const f32x4 v0 = *(const f32x4*)&Os[row * OP + oc], v1 = *(const f32x4*)&Os[row * OP + oc + 4];
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         for (int e = 0; e < 8; e++) {
           const float dv = val[e] * swish_grad_((sb * b[e] + tb) * g);
           val[e] = dv;
-          if (e < nvalid) {   // sums of the fp32 values: equal to the sums of the stored (rounded) ones to ~2^-9/sqrt(count)
+          if (e < nvalid && rvalid) {   // sums of the fp32 values: equal to the sums of the stored (rounded) ones to ~2^-9/sqrt(count)
             st1[i] += dv;
             st2[i] += dv * b[e];
           }
@@ -417,13 +435,20 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       if constexpr (EPI == EPI_STATS) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          if (e < nvalid) {
+          if (e < nvalid && rvalid) {
             st1[i] += val[e];
             st2[i] += val[e] * val[e];
           }
         }
       }
-      if constexpr (OVEC == 8) {
+      if constexpr (BSTORE) {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ov[e] = (bf16)val[e];
+        // byte offset inside sample n's [M][P] matrix; 0x80000000 is past num_records -> the store is discarded
+        const unsigned off = rvalid ? (unsigned)(((long long)m * a.P + p) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), yrsrc, off, 0, 0);
+      } else if constexpr (OVEC == 8) {
         VecIO<T, 8>::store((T*)a.y + o, val);
       } else {
         for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
@@ -477,6 +502,7 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
+  X3D_REQUIRE((long long)a.M * a.P * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
   auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
