@@ -1,2 +1,3 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python -m pytest tests/test_kernels_gpu.py -x -q -k "pw" 2>&1 | tail -2
+python tools/bench_layers.py M 64 > gpurun_out/exp_cs.txt 2>&1
+grep "sum of" gpurun_out/exp_cs.txt

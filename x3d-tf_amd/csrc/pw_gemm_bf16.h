@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   bf16* Xs = (bf16*)smem_raw;                         // [KCH][XP]
   float* Os = (float*)smem_raw;                       // [SLAB * 32][OP]   (aliases Xs)
   bf16* Ws = (bf16*)(smem_raw + XO_BYTES);            // [BM][WP]
+  // per-row prologue coefficients in LDS ([Kp][4] floats, zero for padded rows): AFFINE {s*gate, t*gate}, BNBWD
+  // {A, B, C}.  Read from global inside the prologue they cost an exposed L2 round trip per chunk.
+  float* Cs = (float*)(smem_raw + XO_BYTES + (size_t)BM * (a.KC + 8) * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
@@ -108,6 +111,30 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       }
     }
   }
+
+  // AFFINE rows are 2 floats (table always in LDS), BNBWD rows 4 floats (in LDS unless it costs a resident workgroup: K >= 320)
+  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
+  const bool use_cs = (PRO == PRO_AFFINE) || a.K < 320;
+  auto fill_coef = [&](int n) {
+    if (!use_cs) return;
+    if constexpr (PRO != PRO_NONE) {
+      for (int k = tid; k < Kp; k += 256) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K) {
+          if constexpr (PRO == PRO_AFFINE) {
+            const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
+            c[0] = a.coef[k * 2] * g;       // (s*x + t) * g
+            c[1] = a.coef[k * 2 + 1] * g;
+          } else {
+            c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2];
+          }
+        }
+        if constexpr (CSW == 2) *(float2*)&Cs[k * 2] = make_float2(c[0], c[1]);
+        else *(f32x4*)&Cs[k * 4] = c;
+      }
+    }
+  };
+  if (tile_begin < tile_end) fill_coef(tile_begin / tiles_per_n);
 
   // ---- register-staged prefetch of one [kc][BN] chunk
   bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
@@ -189,24 +216,33 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         } else {
           val[0] = xs1[i];
         }
-        const bool inb = gk < a.K;   // padded rows stay exactly zero (the affine shift must not leak in)
+        f32x4 cf;
+        if (use_cs) {
+          if constexpr (CSW == 2) { const float2 t2 = *(const float2*)&Cs[gk * 2]; cf[0] = t2.x; cf[1] = t2.y; cf[2] = 0.f; cf[3] = 0.f; }
+          else cf = *(const f32x4*)&Cs[gk * 4];   // zeros for padded rows: they stay exactly zero
+        } else {   // wide-K layers: the table would cost the third resident workgroup (48 -> 55 KB of LDS)
+          const bool inb = gk < a.K;
+          cf[3] = 0.f;
+          if constexpr (PRO == PRO_AFFINE) {
+            const float g = (inb && a.gate) ? a.gate[(long long)n * a.K + gk] : 1.0f;
+            cf[0] = inb ? a.coef[gk * 2] * g : 0.f; cf[1] = inb ? a.coef[gk * 2 + 1] * g : 0.f; cf[2] = 0.f;
+          } else {
+            cf[0] = inb ? a.coef[gk * 4] : 0.f; cf[1] = inb ? a.coef[gk * 4 + 1] : 0.f; cf[2] = inb ? a.coef[gk * 4 + 2] : 0.f;
+          }
+        }
         if constexpr (PRO == PRO_AFFINE) {
-          const float s = inb ? a.coef[gk * 2] : 0.f, t = inb ? a.coef[gk * 2 + 1] : 0.f;
-          const float g = (inb && a.gate) ? a.gate[(long long)n * a.K + gk] : 1.0f;
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
-            float u = (s * val[e] + t) * g;
+            float u = cf[0] * val[e] + cf[1];
             if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
             else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
             val[e] = u;
           }
         } else {  // PRO_BNBWD
-          const float A = inb ? a.coef[gk * 4] : 0.f, B = inb ? a.coef[gk * 4 + 1] : 0.f,
-                      C = inb ? a.coef[gk * 4 + 2] : 0.f;
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
             const float y2 = (VEC == 8) ? (float)yr[i][e] : ys1[i];
-            val[e] = A * val[e] + B * y2 + C;
+            val[e] = cf[0] * val[e] + cf[1] * y2 + cf[2];
           }
         }
         VecIO<bf16, VEC>::store(dst, val);
@@ -270,6 +306,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     if constexpr (EPI == X3D_EPI_SWISH_BWD) {
       if (n != n_prev) flush_sums(n_prev);     // the sums are per (sample, channel)
+    }
+    if constexpr (PRO == PRO_AFFINE) {
+      if (n != n_prev && a.gate) fill_coef(n);  // the SE gate is per sample; every reader of the old table is past its last barrier
     }
     n_prev = n;
 #pragma unroll
@@ -464,7 +503,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 static inline size_t pw_bf16_lds_bytes(int mt, int K) {
   const int slab = mt <= 2 ? mt : 1;
   const size_t xb = (size_t)PWB_KCH * PWB_XP * 2, ob = (size_t)slab * 32 * PWB_OP * 4;
-  return (xb > ob ? xb : ob) + (size_t)mt * 32 * (((K + 15) & ~15) + 8) * 2;
+  return (xb > ob ? xb : ob) + (size_t)mt * 32 * (((K + 15) & ~15) + 8) * 2 + (K < 320 ? (size_t)((K + 15) & ~15) * 16 : (size_t)((K + 15) & ~15) * 8);
 }
 
 // rows of 32 output channels per workgroup.  Every extra row block (gy > 1) re-stages the activation tile and
