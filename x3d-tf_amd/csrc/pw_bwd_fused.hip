@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
   bf16* Xs = (bf16*)(smem_raw + YS_B);
   bf16* Ws = (bf16*)(smem_raw + YS_B + XS_B);
   float* Os = SWB ? (float*)(smem_raw + YS_B + XS_B + (size_t)MT * 32 * WP * 2) : (float*)smem_raw;
+  // BN-backward coefficients {A, B, C, 0} per dY row in LDS (zeros for padded rows), read once per tile and row
+  float* Cs = (float*)(smem_raw + YS_B + XS_B + (size_t)MT * 32 * WP * 2 + (SWB ? OS_B : 0));
   static_assert(SWB || OS_B <= YS_B + XS_B, "slab must fit the dY + Xh tiles it aliases (both are rewritten by every commit)");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
     const int lim = min(MT * 32, a.wp_rows) * WP / 8;
 #pragma unroll 4
     for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
+    for (int k = tid; k < KT * 32; k += 256) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if (k < a.Co) { c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2]; }
+      *(f32x4*)&Cs[k * 4] = c;
+    }
   }
 
   // ---- register-staged prefetch of the next tile: row (tid>>4) + 16*i, 8 points at unit (tid&15)
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
     for (int i = 0; i < NVY; i++) {
       const int k = srow + 16 * i;
       if (k >= Kp) continue;                      // rows Kp.. stay zero
-      const bool inb = (k < a.Co) && pin;         // padded rows / points are exactly zero (C must not leak in)
-      const float A = inb ? a.coef[k * 4] : 0.f, B = inb ? a.coef[k * 4 + 1] : 0.f, C = inb ? a.coef[k * 4 + 2] : 0.f;
+      const f32x4 cf = *(const f32x4*)&Cs[k * 4];   // zeros for padded rows
+      const float A = pin ? cf[0] : 0.f, B = pin ? cf[1] : 0.f, C = pin ? cf[2] : 0.f;   // padded points exactly zero (C must not leak in)
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 
 static inline size_t fb_lds_bytes(int MT, int KT, int Kp, bool swb) {
   return (size_t)KT * 32 * FB_YP * 2 + (size_t)MT * 32 * FB_XP * 2 + (size_t)MT * 32 * (Kp + 8) * 2 +
-         (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0);
+         (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0) + (size_t)KT * 32 * 16;
 }
 
 template <int MT, int KT, int EPI>
