@@ -1,3 +1,3 @@
-python -m pytest tests/test_kernels_gpu.py -x -q -k "fused" 2>&1 | tail -2
-python tools/bench_layers.py M 64 > gpurun_out/exp_cs2.txt 2>&1
-grep "sum of" gpurun_out/exp_cs2.txt
+python -m pytest tests/test_kernels_gpu.py -x -q -k "wgrad" 2>&1 | tail -2
+python tools/bench_layers.py M 64 > gpurun_out/exp_cs3.txt 2>&1
+grep "sum of" gpurun_out/exp_cs3.txt

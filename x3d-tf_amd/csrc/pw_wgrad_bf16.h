@@ -229,6 +229,29 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
     for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
 
   bf16x8 rg[MG], ry[MG], rx[NG], rx2[STRIDED ? NG : 1];
+  // per-row coefficients are loop invariants of this thread (rows co0 + i*32 + srow / ci0 + i*32 + srow): loaded
+  // once here instead of from global inside every step's prologue (an exposed L2 round trip per 64-point step);
+  // only the SE gate depends on the sample and is re-read when the step crosses into the next sample
+  float cA[MG], cB[MG], cC[MG], xs_[XPRO ? NG : 1], xt_[XPRO ? NG : 1], xg_[XPRO ? NG : 1];
+#pragma unroll
+  for (int i = 0; i < MG; i++) {
+    const int co = co0 + i * 32 + srow;
+    const bool ok = a.coef && co < a.Cout;
+    cA[i] = ok ? a.coef[co * 4] : 1.f; cB[i] = ok ? a.coef[co * 4 + 1] : 0.f; cC[i] = ok ? a.coef[co * 4 + 2] : 0.f;
+  }
+  int n_gate = -1;
+  auto load_gate = [&](int n) {
+    if constexpr (XPRO) {
+#pragma unroll
+      for (int i = 0; i < NG; i++) {
+        const int ci = ci0 + i * 32 + srow;
+        const bool inb = ci < a.Cin;
+        xs_[i] = inb ? a.xcoef[ci * 2] : 0.f; xt_[i] = inb ? a.xcoef[ci * 2 + 1] : 0.f;
+        xg_[i] = (inb && a.xgate) ? a.xgate[(long long)n * a.Cin + ci] : 1.0f;
+      }
+    }
+    n_gate = n;
+  };
   auto issue = [&](int step) {
     const int n = step / steps_per_n;
     const long long p = (long long)(step - n * steps_per_n) * BP + sp;
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
       const int co = co0 + i * 32 + srow;
       bf16* dst = &As[(i * 32 + srow) * LP + sp];
       if (a.coef && co < a.Cout) {
-        const float A = a.coef[co * 4], B = a.coef[co * 4 + 1], C = a.coef[co * 4 + 2];
+        const float A = cA[i], B = cB[i], C = cC[i];
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
@@ -293,9 +316,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
         *(bf16x8*)dst = o;
       } else if constexpr (XPRO) {
         float v[8];
-        const bool inb = ci < a.Cin;
-        const float s = inb ? a.xcoef[ci * 2] : 0.f, t = inb ? a.xcoef[ci * 2 + 1] : 0.f;
-        const float g = (inb && a.xgate) ? a.xgate[(long long)n * a.Cin + ci] : 1.0f;
+        if (n != n_gate) load_gate(n);
+        const float s = xs_[i], t = xt_[i], g = xg_[i];
         const long long p = (long long)(step - n * steps_per_n) * BP + sp;
         const bool pin = p < a.P;
 #pragma unroll
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
     }
   };
 
-  if (s_begin < s_end) issue(s_begin);
+  if (s_begin < s_end) { load_gate(s_begin / steps_per_n); issue(s_begin); }
   for (int step = s_begin; step < s_end; ++step) {
     __syncthreads();
     commit(step);
