@@ -252,9 +252,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
     }
     n_gate = n;
   };
-  auto issue = [&](int step) {
-    const int n = step / steps_per_n;
-    const long long p = (long long)(step - n * steps_per_n) * BP + sp;
+  // (n, stp) = (sample, 64-point step inside the sample) are carried incrementally: a division per step and lambda
+  // was ~100 scalar instructions of the 380-860 in the loop
+  auto issue = [&](int n, int stp) {
+    const long long p = (long long)stp * BP + sp;
     bf16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
@@ -283,8 +284,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
       }
     }
   };
-  auto commit = [&](int step) {
-    const int n = step / steps_per_n;
+  auto commit = [&](int n, int stp) {
 #pragma unroll
     for (int i = 0; i < MG; i++) {
       const int co = co0 + i * 32 + srow;
@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
-        const int stp = step - n * steps_per_n;
         const long long p = (long long)stp * BP + sp;
         if (p >= a.P) {
 #pragma unroll
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
         float v[8];
         if (n != n_gate) load_gate(n);
         const float s = xs_[i], t = xt_[i], g = xg_[i];
-        const long long p = (long long)(step - n * steps_per_n) * BP + sp;
+        const long long p = (long long)stp * BP + sp;
         const bool pin = p < a.P;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -334,12 +333,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
     }
   };
 
-  if (s_begin < s_end) { load_gate(s_begin / steps_per_n); issue(s_begin); }
+  int n_c = s_begin / steps_per_n, stp_c = s_begin - n_c * steps_per_n;   // step being consumed
+  int n_i = n_c, stp_i = stp_c;                                           // step being loaded
+  if (s_begin < s_end) { load_gate(n_c); issue(n_i, stp_i); }
   for (int step = s_begin; step < s_end; ++step) {
     __syncthreads();
-    commit(step);
+    commit(n_c, stp_c);
     __syncthreads();
-    if (step + 1 < s_end) issue(step + 1);
+    if (++stp_i == steps_per_n) { stp_i = 0; ++n_i; }
+    if (step + 1 < s_end) issue(n_i, stp_i);
+    n_c = n_i; stp_c = stp_i;
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       int id = wid + 4 * s, kpart = 0;
