@@ -314,6 +314,24 @@ int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int dst_dtype,
                        long long P, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * eval-side view construction: decoded video -> the views x crops clips eval.py feeds the model
+ *     reference transforms.py:48-65 (temporal looping sampler), :112-147 (short side -> `size`, bilinear, cast
+ *     back to uint8), :149-190 (uniform crop, ceil offsets), utils.py:42-72 (x/255 - mean, / std),
+ *     dataloader.py:107-116 (clip order: crops major, then views).
+ *     video [F][H][W][3] uint8 (device) -> out [crops*views][T][size][size][3] (X3D_F32 / X3D_BF16), channels-last
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const unsigned char* video;
+  void* out;
+  int F, H, W;
+  int T, views, crops, size;
+  float mean[3];
+  float std[3];
+  int dtype;
+} x3d_eval_views_args;
+int x3d_eval_views(const x3d_eval_views_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * host helper: CRC32C (Castagnoli), the checksum of TF tensor-bundle checkpoints
  *     (reference train.py:151-158 / utils.py restore path reads such files through tf.train.Checkpoint)
  * ------------------------------------------------------------------------------------------ */

@@ -279,3 +279,35 @@ def test_checkpoint_roundtrip_through_model(gpu, tmp_path):
     for k in m.grads:                                  # momentum slots travel too (alignment gaps excluded)
         o, nel = m._offsets[k], m.params[k].numel()
         assert torch.equal(m.flat_velocity[o:o + nel], m2.flat_velocity[o:o + nel]), k
+
+
+def test_trainer_checkpoint_resume(gpu, tmp_path):
+    """Trainer.save_checkpoint writes the reference's `ckpt-<epoch>` + `checkpoint` state file (utils.py:128-132);
+    Trainer.resume finds it like train.py:131-136 and restores weights and momentum bit for bit."""
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.train import Trainer
+    cfg, arch, params = _setup("XS", ["NETWORK.NUM_CLASSES", 7])
+    m = X3D(cfg, dtype=torch.float32, device=gpu, seed=5)
+    tr = Trainer(m, cfg)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 64, 64, 3, generator=g).to(gpu)
+    y = torch.randint(0, 7, (2,), generator=g).to(gpu)
+    m.set_dropout_mask(torch.ones(2, arch.fc1_out))
+    tr.step(x, y, 0.05)
+    prefix = tr.save_checkpoint(str(tmp_path / "run"), epoch=3)
+    assert prefix.endswith("ckpt-3") and (tmp_path / "run" / "checkpoint").exists()
+    m2 = X3D(cfg, dtype=torch.float32, device=gpu, seed=99)
+    tr2 = Trainer(m2, cfg)
+    assert tr2.resume(str(tmp_path / "run")) == 3 and tr2.epoch == 3
+    assert Trainer(X3D(cfg, dtype=torch.float32, device=gpu, seed=1), cfg).resume(str(tmp_path / "empty")) == 0
+    for k in m.grads:                                  # restored state is bit-identical (weights and momentum)
+        o, nel = m._offsets[k], m.params[k].numel()
+        assert torch.equal(m.params[k], m2.params[k]), k
+        assert torch.equal(m.flat_velocity[o:o + nel], m2.flat_velocity[o:o + nel]), k
+    m2.set_dropout_mask(torch.ones(2, arch.fc1_out))
+    tr.step(x, y, 0.05)
+    tr2.step(x, y, 0.05)
+    torch.cuda.synchronize()
+    for k in m.grads:   # the continued step agrees to fp32 atomic-summation order (weight gradients use fp32 atomics)
+        d = (m.params[k] - m2.params[k]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, m.params[k].abs().max().item()), (k, d)

@@ -375,6 +375,8 @@ def read_checkpoint(path: str, specs: Dict[str, object], expect_partial: bool = 
     if missing:
         raise KeyError(f"{len(missing)} model variables missing from {prefix}: {missing[:4]}...")
     owned = {n + SUFFIX for n in specs}
+    if with_momentum:   # train.py:135 loads the optimizer slots too
+        owned |= {f"{n}/.OPTIMIZER_SLOT/optimizer/momentum{SUFFIX}" for n in specs}
     extra = [k for k in entries if k not in owned]
     if extra and not expect_partial:
         raise KeyError(f"{len(extra)} checkpoint keys unused by the model: {extra[:4]}...")

@@ -42,6 +42,11 @@ class PwBwdArgs(C.Structure):
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
 
 
+class EvalViewsArgs(C.Structure):
+    _fields_ = [("video", _vp), ("out", _vp), ("F", _i), ("H", _i), ("W", _i), ("T", _i), ("views", _i),
+                ("crops", _i), ("size", _i), ("mean", _f * 3), ("std", _f * 3), ("dtype", _i)]
+
+
 class PwPackItem(C.Structure):
     _fields_ = [("w", _vp), ("fwd_panel", _vp), ("dgrad_panel", _vp), ("Cout", _i), ("Cin", _i)]
 
@@ -105,6 +110,7 @@ _SIGS = {
     "x3d_sgd_nesterov": ([_vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp], _i),
     "x3d_l2_sumsq": ([_vp, _vp, _vp, _ll, _vp], _i),
     "x3d_nthwc_to_ncthw": ([_vp, _i, _vp, _i, _i, _i, _ll, _vp], _i),
+    "x3d_eval_views": ([C.POINTER(EvalViewsArgs), _vp], _i),
     "x3d_crc32c": ([C.c_char_p, C.c_size_t, C.c_uint32], C.c_uint32),
 }
 

@@ -55,6 +55,28 @@ class Trainer:
         m.apply_sgd(lr, self.momentum)
         return pl
 
+    # -- checkpoints in the reference's layout (utils.py:128-132 ModelCheckpoint 'ckpt-{epoch:d}', train.py:131-136) --
+    def save_checkpoint(self, model_dir: str, epoch: int) -> str:
+        """Writes `<model_dir>/ckpt-<epoch>` as a TF tensor bundle (weights + SGD momentum slots) and the
+        `checkpoint` state file, so that the reference's `tf.train.latest_checkpoint(model_dir)` finds it."""
+        import os
+        os.makedirs(model_dir, exist_ok=True)
+        prefix = os.path.join(model_dir, f"ckpt-{int(epoch)}")
+        self.model.save_weights(prefix)
+        return prefix
+
+    def resume(self, model_dir: str) -> int:
+        """train.py:131-136: load the latest `ckpt-<epoch>` of `model_dir` if there is one; returns the epoch to
+        continue from (0 without a checkpoint) and sets `self.epoch`."""
+        import os
+        from .checkpoint import latest_checkpoint
+        path = latest_checkpoint(model_dir)
+        if not path:
+            return 0
+        self.model.load_weights(path)   # weights + momentum slots; unknown keys tolerated as Keras does (warning only)
+        self.epoch = int(os.path.basename(path).split("-")[1])
+        return self.epoch
+
     def loss(self, pl):
         """global-batch mean cross-entropy + L2 term (what Keras reports as `loss`)."""
         ce = pl.loss_rows.sum() / (pl.n * self.world)
