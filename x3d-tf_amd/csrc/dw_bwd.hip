@@ -196,14 +196,12 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
         const float* row = Al + (r * S + kh) * g.LP + wo0 * S;
-#pragma unroll
-        for (int j = 0; j < WIN; j++) winA[kh][j] = row[j];
+        lds_window<WIN, (SW * S >= 4 ? 4 : SW * S)>(row, winA[kh]);
       }
 #pragma unroll
       for (int q = 0; q < BR; q++) {
         const float* row = Bl + (r + q) * a.LPB + wo0;
-#pragma unroll
-        for (int j = 0; j < BW; j++) winB[q][j] = row[j];
+        lds_window<BW, (SW >= 4 ? 4 : SW)>(row, winB[q]);
       }
       // own dB strip: window row of output row `ho` is index 1 in both layouts; col wo0+i is index i+1
       float dBo[SW];
@@ -337,7 +335,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     return X3D_ERR_INVALID;
   }
   a.RB = (S == 1) ? a.g.TH + 2 : a.g.TH + 1;
-  a.LPB = a.g.nstrips * SW + ((S == 1) ? 2 : 1);
+  a.LPB = (a.g.nstrips * SW + ((S == 1) ? 2 : 1) + 3) & ~3;   // multiple of 4 floats (aligned window reads)
   a.vecB = pick_vec(sizeof(T), a.g.Wo, f->dv, f->braw);
   const size_t lds = (ldsf + (size_t)a.RB * a.LPB + 29 * 4 + 8) * sizeof(float);
   X3D_REQUIRE(lds <= 64 * 1024, "dw3d_bwd: tile needs %zu B of LDS", lds);

@@ -101,6 +101,30 @@ __device__ __forceinline__ void stage_direct2(const T* s0, const T* s1, float* l
 }
 
 
+// A thread's window of N consecutive LDS floats starting at a multiple of AL floats (AL = 4, 2 or 1; the pitches
+// are multiples of 4).  Read as aligned ds_read_b128 / b64 pieces: with scalar ds_read_b32 the lanes of a wave sit
+// 4*SW bytes apart and collide 4-way on the 32 banks (SW = 4), which made the stage-2/3 depthwise kernels LDS bound.
+template <int N, int AL>
+__device__ __forceinline__ void lds_window(const float* __restrict__ p, float (&w)[N]) {
+  int i = 0;
+  if constexpr (AL >= 4) {
+#pragma unroll
+    for (; i + 4 <= N; i += 4) {
+      const f32x4 v = *(const f32x4*)(p + i);
+      w[i] = v[0]; w[i + 1] = v[1]; w[i + 2] = v[2]; w[i + 3] = v[3];
+    }
+  }
+  if constexpr (AL >= 2) {
+#pragma unroll
+    for (; i + 2 <= N; i += 2) {
+      const float2 v = *(const float2*)(p + i);
+      w[i] = v.x; w[i + 1] = v.y;
+    }
+  }
+#pragma unroll
+  for (; i < N; i++) w[i] = p[i];
+}
+
 // tile geometry shared by forward and backward
 static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int SW, int elem_bytes,
                    const void* p0, const void* p1, const void* p2, int* block_dim, size_t* lds_floats) {
@@ -120,7 +144,7 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
   g.ntile_h = ceil_div(g.Ho, th);
   g.TH = ceil_div(g.Ho, g.ntile_h);
   g.RIN = (g.TH - 1) * stride + 3;
-  g.LP = (g.nstrips * SW - 1) * stride + 3;
+  g.LP = ((g.nstrips * SW - 1) * stride + 3 + 3) & ~3;   // multiple of 4 floats: window reads are 16/8-byte aligned vectors
   g.vec = pick_vec(elem_bytes, W, p0, p1, p2);
   *block_dim = bd;
   *lds_floats = (size_t)g.RIN * g.LP;

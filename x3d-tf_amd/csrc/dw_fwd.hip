@@ -118,9 +118,8 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
         float win[WIN];
-        const float* row = lds + (r * S + kh) * g.LP + wo0 * S;
-#pragma unroll
-        for (int j = 0; j < WIN; j++) win[j] = row[j];
+        const float* row = lds + (r * S + kh) * g.LP + wo0 * S;   // wo0 * S is a multiple of SW * S floats
+        lds_window<WIN, (SW * S >= 4 ? 4 : SW * S)>(row, win);
 #pragma unroll
         for (int kw = 0; kw < 3; kw++) {
 #pragma unroll
