@@ -157,7 +157,13 @@ def test_train_matches_committed_golden_vector(gpu):
         assert abs(g.norm().item() - nrm) < 5e-2 * nrm, f"{k}: |g| {g.norm().item()} vs {nrm}"
 
 
-def test_train_step_bf16_block_by_block(gpu):
+@pytest.mark.parametrize("name,n,t,s", [
+    ("S", 3, 5, 96),      # odd point counts: scalar / generic kernel paths
+    ("M", 2, 4, 128),     # every P a multiple of 8, 16-byte aligned rows: the fast paths (vector GEMMs, fused pointwise
+                          # backward, packed panels, vector depthwise staging) -- the ones the benchmark runs
+    ("XL", 2, 4, 64),     # XL widths (72/162/306/630...: off the 32-grid, K > 432), 55 blocks, SE parity across stages
+])
+def test_train_step_bf16_block_by_block(gpu, name, n, t, s):
     """bf16 activation storage (fp32 arithmetic), checked with TEACHER FORCING: every residual block of the
     device run is replayed on the oracle from the device's own stored block input (forward) and the device's
     own stored upstream gradient (backward), with the oracle rounding to bf16 at the tensors the device
@@ -167,8 +173,7 @@ def test_train_step_bf16_block_by_block(gpu):
     stated tolerance 2 % of each tensor's max for activations/gradients; weight gradients (whose GEMM operands
     are rounded to bf16 for the matrix cores) 6 % relative L2 worst case, 1.5 % median."""
     from oracle import x3d_oracle as O
-    cfg, arch, params = _setup("S")
-    n, t, s = 3, 5, 96
+    cfg, arch, params = _setup(name)
     torch.manual_seed(2)
     x = torch.randn(n, t, s, s, 3).bfloat16().float()
     labels = torch.randint(0, arch.num_classes, (n,))
