@@ -74,3 +74,21 @@ def test_dw3d_kernel_name_dry_run():
     with pytest.raises(hip.X3DHipError):
         hip.dw3d_kernel_name(f)
     assert hip.load().x3d_crc32c(b"123456789", 9, 0) == 0xE3069283
+
+
+def test_cpp_client_links_against_the_c_abi(tmp_path):
+    """tools/bench_dw3d.cpp is a C++ client of include/x3d_hip.h with no Python / torch in the loop: it must compile
+    and link against libx3d_hip.so (run on a GPU box: profiles/r01e_bench_dw3d_cabi.txt)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    out = tmp_path / "bench_dw3d"
+    libdir = os.path.join(ROOT, "x3d-tf_amd")
+    r = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", os.path.join(ROOT, "tools", "bench_dw3d.cpp"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lx3d_hip", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists()
