@@ -1,6 +1,7 @@
 // X3D stem (reference model.py:134-210): conv_s = 1x3x3 stride (1,2,2) conv with symmetric pad
 // (0,1,1), Cin=3 -> C1; conv_t = KTx1x1 temporal depthwise conv with pad (KT/2,0,0).  Cin = 3 and
-// K = 27 are not MFMA shapes in the forward direction; both are HBM-bound direct kernels.
+// K = 27 pad to one 32x32 MFMA tile: bf16 storage runs conv_s forward and its weight gradient on the matrix cores
+// (im2col tile built in LDS from 16-byte loads); fp32 storage and odd widths use the direct kernels.
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -43,6 +44,146 @@ __global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x
   }
 }
 
+
+// ---- bf16 fast path of the stem forward on the matrix cores -----------------------------------------------
+// The direct kernel above is VALU bound (648 FMAs + 27 two-byte loads per output position: 0.56 ms on X3D-M B=64
+// against ~0.23 ms of HBM time).  Here the im2col tile [tap][point] is built in LDS exactly as in the weight-gradient
+// kernel below (16-byte loads of the input rows, even/odd de-interleave = the three kw taps) and
+//   Y[co][p] = sum_tap W[co][tap] * im2col[tap][p]
+// is two k-steps of v_mfma_f32_32x32x16_bf16 per 32 points: A = the 32x32 weight tile (bf16, held in registers for
+// the whole kernel), B = the im2col tile read transposed (ds_read_b64_tr_b16).  One wave = one 64-column segment of
+// an output row; its 24x64 result goes through a private LDS slab so that the stores are 16-byte row pieces.
+template <int SEGS>
+__global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                              bf16* __restrict__ y, int Cin, int Cout, int Tn, int H,
+                                                              int W, int Ho, int Wo, int nws, long long total_segs,
+                                                              int segs_per_block) {
+  static_assert(SEGS == 4, "one wave per segment");
+  constexpr int LP = SEGS * 64 + 32;        // 576 B pitch = 64 mod 256: the transposed read is conflict-free
+  constexpr int OP = 64 + 4;                // fp32 slab pitch
+  __shared__ __attribute__((aligned(16))) bf16 Bs[32 * LP];        // im2col [tap][point]
+  __shared__ __attribute__((aligned(16))) float Os[SEGS * 32 * OP]; // per-wave output slab [co][64 points]
+  typedef __attribute__((ext_vector_type(4))) short s16x4_s;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_s;
+  typedef s16x4_s __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int ntap = Cin * 9;
+  const long long seg_begin = (long long)blockIdx.x * segs_per_block;
+  const long long seg_end = min(seg_begin + segs_per_block, total_segs);
+  for (int i = tid; i < 32 * LP / 8; i += 256) {
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+    ((bf16x8*)Bs)[i] = z;
+  }
+  // A operand: row co = lane & 31, taps 8*half + 16*ks .. +7 (zero beyond Cout / ntap)
+  bf16x8 afrag[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int tap = ks * 16 + 8 * half + e;
+      afrag[ks][e] = (bf16)((r < Cout && tap < ntap) ? w[r * ntap + tap] : 0.f);
+    }
+
+  const int xrow = tid >> 4, xv = tid & 15;
+  const int xci = xrow / 3, xkh = xrow - xci * 3;
+  const bool xrow_ok = xrow < Cin * 3;
+  bf16x8 rx[SEGS];
+  bf16 rl[SEGS];
+  auto issue = [&](long long s0) {
+#pragma unroll
+    for (int q = 0; q < SEGS; q++) {
+      const long long seg = s0 + q;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+      rx[q] = z; rl[q] = (bf16)0.f;
+      if (seg >= seg_end) continue;
+      const int ws = (int)(seg % nws);
+      long long tmp = seg / nws;
+      const int ho = (int)(tmp % Ho); tmp /= Ho;
+      const int t = (int)(tmp % Tn);
+      const int n = (int)(tmp / Tn);
+      const int wo0 = ws * 64;
+      const int hi = 2 * ho + xkh - 1;
+      if (xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
+        const bf16* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
+        rx[q] = *(const bf16x8*)src;
+        if (xv == 0 && wo0 > 0) rl[q] = src[-1];
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < SEGS; q++) {
+      if (xrow_ok) {
+        const int tap1 = xci * 9 + xkh * 3 + 1;
+        bf16x4 ev, od;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { ev[e] = rx[q][2 * e]; od[e] = rx[q][2 * e + 1]; }
+        *(bf16x4*)&Bs[tap1 * LP + q * 64 + 4 * xv] = ev;          // kw = 1: wi = 2wo
+        *(bf16x4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * xv] = od;    // kw = 2: wi = 2wo + 1
+        bf16* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * xv + 1];    // kw = 0: wi = 2wo - 1  (one point later)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (4 * xv + 1 + e < 64) k0[e] = od[e];
+        if (xv == 0) Bs[(tap1 - 1) * LP + q * 64] = rl[q];
+      }
+    }
+  };
+
+  // transposed-read geometry: lane -> (tap row 8*(g16>>1)+q4 (+4), 4 points)
+  const int g16 = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_row = 8 * (g16 >> 1) + q4;
+  const int tr_col = wid * 64 + 16 * (g16 & 1) + 4 * pp;   // + 32 for the segment's second point tile
+  float* myOs = Os + wid * 32 * OP;
+
+  if (seg_begin < seg_end) issue(seg_begin);
+  for (long long s0 = seg_begin; s0 < seg_end; s0 += SEGS) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (s0 + SEGS < seg_end) issue(s0 + SEGS);
+    const long long seg = s0 + wid;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[nt][j] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const s16x4_s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[(ks * 16 + tr_row) * LP + tr_col + nt * 32]));
+        const s16x4_s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[(ks * 16 + tr_row + 4) * LP + tr_col + nt * 32]));
+        const s16x8_s bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], __builtin_bit_cast(bf16x8, bs), acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) myOs[((j & 3) + 8 * (j >> 2) + 4 * half) * OP + nt * 32 + r] = acc[nt][j];
+    }
+    // the slab is private to the wave: its own LDS writes are visible to it after the wait the compiler inserts
+    if (seg < seg_end) {
+      const int ws = (int)(seg % nws);
+      long long tmp = seg / nws;
+      const int ho = (int)(tmp % Ho); tmp /= Ho;
+      const int t = (int)(tmp % Tn);
+      const int n = (int)(tmp / Tn);
+      const int wo0 = ws * 64;
+      // 32 rows x 8 vectors of 8 points = 256 vectors per wave, 4 per lane: row = i*8 + lane/8, vector = lane & 7
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int co = i * 8 + (lane >> 3), v = lane & 7;
+        if (co < Cout && wo0 + 8 * v < Wo) {
+          const f32x4 v0 = *(const f32x4*)&myOs[co * OP + 8 * v], v1 = *(const f32x4*)&myOs[co * OP + 8 * v + 4];
+          float val[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          VecIO<bf16, 8>::store(y + ((((long long)n * Cout + co) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v, val);
+        }
+      }
+    }
+  }
+}
+
 extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int Cin, int T, int H, int W,
                               int Cout, int dtype, void* stream) {
   X3D_REQUIRE(x && w && y && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_fwd: bad args");
@@ -52,6 +193,29 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   dim3 grid(ceil_div(Ho * Wo, 256), T, N);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == X3D_BF16 && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
+    // matrix-core path (weights rounded to bf16 like every pointwise conv): rows of x / y 16-byte aligned
+    constexpr int SEGS = 4;
+    const int nws = ceil_div(Wo, 64);
+    const long long total_segs = (long long)N * T * Ho * nws;
+    static int slots = 0;
+    if (slots == 0) {
+      int nb = 0, dev = 0, cus = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_fwd_bf16_kernel<SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+      slots = nb * cus;
+    }
+    long long spb2 = ceil_div_ll(total_segs, slots);
+    if (spb2 < 4 * SEGS) spb2 = 4 * SEGS;
+    spb2 = ceil_div_ll(spb2, SEGS) * SEGS;
+    const long long gx2 = ceil_div_ll(total_segs, spb2);
+    X3D_REQUIRE(gx2 < (1ll << 31), "stem_s_fwd: grid too large");
+    hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x, w, (bf16*)y,
+                       Cin, Cout, T, H, W, Ho, Wo, nws, total_segs, (int)spb2);
+    X3D_LAUNCH_CHECK("stem_s_fwd");
+    return X3D_OK;
+  }
 #define LAUNCH(TT, CO) \
   hipLaunchKernelGGL((stem_s_fwd_kernel<TT, 3, CO>), grid, dim3(256), 0, st, (const TT*)x, w, (TT*)y, T, H, W, Ho, Wo)
 #define BY_CO(TT)                      \
