@@ -13,6 +13,7 @@ __global__ __launch_bounds__(64) void dense_fwd_kernel(const float* __restrict__
   float acc[DENSE_NT];
 #pragma unroll
   for (int i = 0; i < DENSE_NT; i++) acc[i] = 0.f;
+#pragma unroll 4
   for (int k = lane; k < K; k += 64) {
     const float wv = w[(long long)m * K + k];
 #pragma unroll
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void dense_bwd_dx_kernel(const float* __restri
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
   float acc = 0.f;
-  for (int m = 0; m < M; m++) acc += dz[m] * w[(long long)m * K + k];
+#pragma unroll 16
+  for (int m = 0; m < M; m++) acc += dz[m] * w[(long long)m * K + k];   // 16 independent loads in flight
   if (mask) acc *= mask[(long long)n * K + k] * mask_scale;
   dx[(long long)n * K + k] = acc;
 }
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restri
   const int m = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f, accb = 0.f;
+#pragma unroll 8
   for (int n = 0; n < N; n++) {
     float d = dy[(long long)n * M + m];
     if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
