@@ -102,6 +102,8 @@ def test_pw_fwd(gpu, dtype, shape):
     (2, 24, 54, 2, 28, 28, "add_strided"),
     (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
     (1, 96, 32, 2, 10, 12, "swish_bwd"),
+    (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv: Cin sliced over blockIdx.y (4 slices of 64)
+    (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
 ])
 def test_pw_bwd_fused(gpu, shape):
     """x3d_pw_bwd (one pass over dY) against x3d_pw_dgrad + x3d_pw_wgrad: dx bit-identical (same bf16 operands,

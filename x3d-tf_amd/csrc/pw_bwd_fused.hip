@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
   const int r = lane & 31, half = lane >> 5;
   const int tiles_per_n = (int)((a.P + BN - 1) / BN);
   const int total_tiles = tiles_per_n * a.N;
+  // blockIdx.y selects a slice of MT*32 input channels (dX rows / dW columns) when Ci is wider than one panel:
+  // the dY tile is then staged once per slice (as x3d_pw_dgrad does per row block) but still feeds both products
+  const int m0 = blockIdx.y * MT * 32;
   const int tile_begin = blockIdx.x * a.tiles_per_block;
   const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
 
@@ -81,9 +84,9 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 #pragma unroll
     for (int e = 0; e < 8; e++) zero[e] = (bf16)0.f;
     for (int i = tid; i < (int)((YS_B + XS_B) / 16); i += 256) ((bf16x8*)smem_raw)[i] = zero;
-    const bf16x8* src = (const bf16x8*)a.wp;
+    const bf16x8* src = (const bf16x8*)((const bf16*)a.wp + (long long)m0 * WP);
     const int nvec = MT * 32 * WP / 8;
-    const int lim = min(MT * 32, a.wp_rows) * WP / 8;
+    const int lim = max(0, min(MT * 32, a.wp_rows - m0)) * WP / 8;
 #pragma unroll 4
     for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
     for (int k = tid; k < KT * 32; k += 256) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
     if constexpr (!SWB) {
 #pragma unroll
       for (int i = 0; i < NVX; i++) {
-        const int m = srow + 16 * i;
+        const int m = m0 + srow + 16 * i;
         rx[i] = z;
         if (m < a.Ci && p < a.P) rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Ci + m) * a.P + p);
       }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 #pragma unroll
       for (int i = 0; i < ROWS_PT; i++) {
         const float s1 = row16_sum(st1[i]), s2 = row16_sum(st2[i]);
-        const int m = (tid >> 4) + 16 * i;
+        const int m = m0 + (tid >> 4) + 16 * i;
         if ((tid & 15) == 0 && m < a.Ci) {
           double* d = a.nc_sums + ((long long)n * a.Ci + m) * 2;
           atomic_add_d(d, (double)s1);
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
     // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills)
     constexpr bool HOIST = MT <= 2;
     auto epi_load = [&](int i) {
-      const int m = (tid >> 4) + 16 * i;
+      const int m = m0 + (tid >> 4) + 16 * i;
       const long long p = p0 + oc;
       const bool ok = m < a.Ci && p < a.P;
       if constexpr (EPL8) {
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
         }
         const int i = sl * 2 + ii;
         const int row = HALF_SLAB ? (tid >> 4) : (tid >> 4) + 16 * ii;   // row inside the slab
-        const int m = sl * 32 + (tid >> 4) + 16 * ii;
+        const int ml = sl * 32 + (tid >> 4) + 16 * ii;   // row inside this workgroup's slice
+        const int m = m0 + ml;
         const long long p = p0 + oc;
         if (m >= a.Ci || p >= a.P) continue;
         float val[8];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
             st1[i] += dv;
             st2[i] += dv * b[e];
           }
-          VecIO<bf16, 8>::store(&Xs[m * XP + oc], xh);
+          VecIO<bf16, 8>::store(&Xs[ml * XP + oc], xh);
         }
         VecIO<T, 8>::store((T*)a.dx + o, val);
       }
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
       if constexpr (NKS > 1) id = wid % NT;
       if (id < NT) {
         const int cot = id / MT, cit = id - cot * MT;
-        const int ci = cit * 32 + r;
+        const int ci = m0 + cit * 32 + r;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           const int co = cot * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
@@ -408,19 +412,34 @@ static int fb_launch(PwBwdArgs& a, hipStream_t st) {
   }
   const long long total_tiles = ceil_div_ll(a.P, FB_BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_bwd: too many tiles");
-  long long tpb = ceil_div_ll(total_tiles, slots);   // one balanced round
+  const int gy = ceil_div(ceil_div(a.Ci, 32), MT);    // slices of MT*32 input channels
+  long long tpb = ceil_div_ll(total_tiles * gy, slots);   // one balanced round
   if (tpb < 4) tpb = 4;                               // keeps the dW atomics (<= 32 KB) small against the streamed tiles
   a.tiles_per_block = (int)tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_fused");
   return X3D_OK;
 }
 
+// panel shape: KT covers all of Co (<= 128); MT covers Ci when MT*KT <= 8 dW tiles fit the accumulators, else Ci is
+// sliced over blockIdx.y in panels of MT = 8 / KT row tiles
+static inline bool fb_shape(int Ci, int Co, int* MT, int* KT) {
+  const int mt = ceil_div(Ci, 32), kt = ceil_div(Co, 32);
+  if (kt > 4) return false;
+  *KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  const int cap = 8 / *KT;                      // 8, 4, 2 row tiles
+  int m = mt <= 1 ? 1 : (mt == 2 ? 2 : 4);
+  if (m > cap) m = cap;
+  if (m > 4) m = 4;
+  *MT = m;
+  return true;
+}
+
 template <int EPI>
 static int fb_pick(PwBwdArgs& a, hipStream_t st) {
-  const int mt = ceil_div(a.Ci, 32), kt = ceil_div(a.Co, 32);
-  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  int MT = 0, KT = 0;
+  if (!fb_shape(a.Ci, a.Co, &MT, &KT)) { x3d_set_error("pw_bwd: unsupported tile shape"); return X3D_ERR_INVALID; }
 #define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<M_, K_, EPI>(a, st);
   FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 4) FB_CASE(4, 1) FB_CASE(4, 2)
 #undef FB_CASE
@@ -431,8 +450,10 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
 // eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
 static bool fb_supported(const x3d_pw_bwd_args* b) {
   if (b->dtype != X3D_BF16 || !b->w_panel || !b->coef || !b->yraw) return false;
-  const int mt = ceil_div(b->Cin, 32), kt = ceil_div(b->Cout, 32);
-  if (mt > 4 || kt > 4 || mt * kt > 8) return false;
+  int MT = 0, KT = 0;
+  if (!fb_shape(b->Cin, b->Cout, &MT, &KT)) return false;
+  // slicing Ci re-stages the dY tile once per slice: worth it up to ~4 slices (x3d_pw_dgrad does the same per row block)
+  if (ceil_div(ceil_div(b->Cin, 32), MT) > 4) return false;
   const long long P = (long long)b->T * b->H * b->W;
   if (P % 8) return false;
   const void* ps[] = {b->g, b->yraw, b->dx, b->w_panel, b->epi == X3D_EPI_SWISH_BWD ? b->braw : b->x,
@@ -441,7 +462,6 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
   if (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8)) return false;
   if (b->epi != X3D_EPI_ADD && b->epi != X3D_EPI_ADD_STRIDED && b->epi != X3D_EPI_SWISH_BWD) return false;
   const int Kp = (b->Cout + 15) & ~15;
-  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
   return fb_lds_bytes(MT, KT, Kp, b->epi == X3D_EPI_SWISH_BWD) <= 160 * 1024;
 }
 
