@@ -427,8 +427,8 @@ static int fb_launch(PwBwdArgs& a, hipStream_t st) {
 static inline bool fb_shape(int Ci, int Co, int* MT, int* KT) {
   const int mt = ceil_div(Ci, 32), kt = ceil_div(Co, 32);
   if (kt > 4) return false;
-  *KT = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
-  const int cap = 8 / *KT;                      // 8, 4, 2 row tiles
+  *KT = kt;                                     // 1..4 (3: 96-channel dY tiles keep two workgroups per CU)
+  const int cap = 8 / *KT;                      // 8, 4, 2, 2 row tiles
   int m = mt <= 1 ? 1 : (mt == 2 ? 2 : 4);
   if (m > cap) m = cap;
   if (m > 4) m = 4;
@@ -441,7 +441,8 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
   int MT = 0, KT = 0;
   if (!fb_shape(a.Ci, a.Co, &MT, &KT)) { x3d_set_error("pw_bwd: unsupported tile shape"); return X3D_ERR_INVALID; }
 #define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<M_, K_, EPI>(a, st);
-  FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 4) FB_CASE(4, 1) FB_CASE(4, 2)
+  FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 3) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 3) FB_CASE(2, 4)
+  FB_CASE(4, 1) FB_CASE(4, 2)
 #undef FB_CASE
   x3d_set_error("pw_bwd: unsupported tile shape");
   return X3D_ERR_INVALID;
