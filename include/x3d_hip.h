@@ -86,6 +86,15 @@ int x3d_bn_finalize(const double* stats, double count, const float* gamma, const
 int x3d_bn_eval_coef(const float* gamma, const float* beta, const float* moving_mean,
                      const float* moving_var, float eps, float* scale_shift, float* mean_invstd,
                      int C, void* stream);
+/* all BatchNorm layers of a model in ONE launch (inference: 84-171 layers, else one ~5 us launch each per forward).
+ * `items` is an array in DEVICE memory. */
+typedef struct {
+  const float* gamma; const float* beta; const float* moving_mean; const float* moving_var;
+  float* scale_shift;          /* out [C][2] */
+  float* mean_invstd;          /* out [C][2] */
+  int C;
+} x3d_bn_eval_item;
+int x3d_bn_eval_coef_batched(const x3d_bn_eval_item* items, int n_items, float eps, void* stream);
 int x3d_bn_bwd_finalize(const double* sums, double count, const float* mean_invstd,
                         const float* gamma, float* coef, float* dgamma, float* dbeta, int C,
                         void* stream);

@@ -86,6 +86,25 @@ extern "C" int x3d_bn_eval_coef(const float* gamma, const float* beta, const flo
   return X3D_OK;
 }
 
+__global__ __launch_bounds__(64) void bn_eval_coef_batched_kernel(const x3d_bn_eval_item* __restrict__ items, float eps) {
+  const x3d_bn_eval_item it = items[blockIdx.x];
+  for (int c = threadIdx.x; c < it.C; c += 64) {
+    const float invstd = 1.0f / sqrtf(it.moving_var[c] + eps);
+    const float sc = it.gamma[c] * invstd;
+    it.scale_shift[c * 2] = sc;
+    it.scale_shift[c * 2 + 1] = it.beta[c] - it.moving_mean[c] * sc;
+    it.mean_invstd[c * 2] = it.moving_mean[c];
+    it.mean_invstd[c * 2 + 1] = invstd;
+  }
+}
+
+extern "C" int x3d_bn_eval_coef_batched(const x3d_bn_eval_item* items, int n_items, float eps, void* stream) {
+  X3D_REQUIRE(items && n_items > 0, "bn_eval_coef_batched: no items");
+  hipLaunchKernelGGL(bn_eval_coef_batched_kernel, dim3(n_items), dim3(64), 0, (hipStream_t)stream, items, eps);
+  X3D_LAUNCH_CHECK("bn_eval_coef_batched");
+  return X3D_OK;
+}
+
 extern "C" int x3d_bn_bwd_finalize(const double* sums, double count, const float* mean_invstd,
                                    const float* gamma, float* coef, float* dgamma, float* dbeta, int C,
                                    void* stream) {

@@ -47,6 +47,11 @@ class EvalViewsArgs(C.Structure):
                 ("crops", _i), ("size", _i), ("mean", _f * 3), ("std", _f * 3), ("dtype", _i)]
 
 
+class BnEvalItem(C.Structure):
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("moving_mean", _vp), ("moving_var", _vp), ("scale_shift", _vp),
+                ("mean_invstd", _vp), ("C", _i)]
+
+
 class PwPackItem(C.Structure):
     _fields_ = [("w", _vp), ("fwd_panel", _vp), ("dgrad_panel", _vp), ("Cout", _i), ("Cin", _i)]
 
@@ -86,6 +91,7 @@ _SIGS = {
     "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_bn_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "x3d_bn_eval_coef": ([_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], _i),
+    "x3d_bn_eval_coef_batched": ([_vp, _i, _f, _vp], _i),
     "x3d_bn_bwd_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
     "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),

@@ -424,9 +424,12 @@ class X3D:
             if training:
                 pl.rec(F, "x3d_bn_finalize", ("acc", b.stats), float(count), g, be, mm, mv, float(eps), float(mom), 1,
                        b.ss, b.mi, b.c)
-            else:
-                pl.rec(F, "x3d_bn_eval_coef", g, be, mm, mv, float(eps), b.ss, b.mi, b.c)
+            else:   # inference: every layer's coefficients in ONE launch at the head of the forward list (below)
+                pl.bn_eval_items.append(hip.BnEvalItem(_p(g), _p(be), _p(mm), _p(mv), _p(b.ss), _p(b.mi), b.c))
 
+        pl.bn_eval_items = []
+        if not training:
+            F.append(None)   # slot 0: x3d_bn_eval_coef_batched, filled in once every BN layer is known
         # ---- input + stem --------------------------------------------------------------------
         pl.x_in = None  # bound at run time (NTHWC user tensor)
         pl.x = pl.act(n, self.in_channels, t, h, w)
@@ -542,6 +545,11 @@ class X3D:
             pl.out = pl.f32(n // a.num_preds, a.num_classes)
             pl.rec(F, "x3d_view_mean", pl.probs, pl.out, n // a.num_preds, a.num_preds, a.num_classes)
 
+        if not training:
+            items = (hip.BnEvalItem * len(pl.bn_eval_items))(*pl.bn_eval_items)
+            pl.bn_eval_table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+            F[0] = ("x3d_bn_eval_coef_batched", pl.lib.x3d_bn_eval_coef_batched,
+                    (pl.bn_eval_table.data_ptr(), len(pl.bn_eval_items), float(eps)))
         # resolve fp64 accumulator handles into pointers
         pl.finalize_acc()
         self._resolve(pl, pl.fwd)
