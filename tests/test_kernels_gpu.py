@@ -67,6 +67,7 @@ def _affine(x, ss, gate=None, act=0):
     (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
     (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
     (1, 24, 24, 2, 32, 32, 2, None),       # Wo % 8 == 0
+    (2, 432, 192, 2, 8, 8, 1, "swish"), (2, 192, 432, 2, 8, 8, 1, None), (1, 440, 200, 1, 8, 5, 1, "relu"),  # weights-streamed path
 ])
 def test_pw_fwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
@@ -148,6 +149,48 @@ def test_pw_bwd_fused(gpu, shape):
     report("dw", dw1, dw0.double().cpu(), 2e-3, 2e-3 * scale)
     if epi == "swish_bwd":
         report("nc_sums", nc1, nc0.cpu(), 1e-4, 1e-4 * max(1.0, nc0.abs().max().item()))
+
+
+@pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6)])
+def test_pw_weights_streamed_path(gpu, shape):
+    """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
+    (pw_gemm_ws.h); without a panel the same call runs the resident-panel kernel.  Same bf16 operands and the same
+    accumulation order over K: outputs bit-identical; statistics / per-(n,c) sums to summation-order tolerance."""
+    ops = _ops()
+    n, cin, cout, t, h, w = shape
+    g_ = _gen(41)
+    bf = torch.bfloat16
+    wt = (torch.randn((cout, cin), generator=g_) * 0.1).to(gpu)
+    (fp, dp), = ops.pw_pack_weights([wt])
+    x = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+    ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
+    gate = torch.rand((n, cin), generator=g_).to(gpu)
+    for kw in (dict(), dict(in_ss=ss, in_gate=gate, in_act=2), dict(in_ss=ss, in_act=1)):
+        s0 = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+        s1 = torch.zeros_like(s0)
+        y0 = ops.pw_fwd(x, wt, stats=s0, **kw)
+        y1 = ops.pw_fwd(x, wt, stats=s1, w_panel=fp, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-4)
+    gy = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
+    yraw = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
+    coef = (torch.randn((cout, 4), generator=g_) * 0.5).to(gpu)
+    add = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+    braw = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
+    bss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
+    for kw in (dict(), dict(epi=ops.EPI_ADD, add=add), dict(epi=ops.EPI_SWISH_BWD, braw=braw, b_ss=bss, gate=gate)):
+        dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+        extra0, extra1 = {}, {}
+        if "braw" in kw:
+            extra0["nc_sums"] = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+            extra1["nc_sums"] = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+        ops.pw_dgrad(gy, yraw, coef, wt, dx0, **kw, **extra0)
+        ops.pw_dgrad(gy, yraw, coef, wt, dx1, w_panel=dp, **kw, **extra1)
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1)
+        if extra0:
+            assert torch.allclose(extra0["nc_sums"], extra1["nc_sums"], rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 54, 4, 16, 16), (1, 96, 216, 2, 14, 14), (2, 200, 72, 2, 7, 7), (1, 432, 192, 3, 7, 7)])

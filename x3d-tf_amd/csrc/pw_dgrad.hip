@@ -1,5 +1,5 @@
 // x3d_pw_dgrad: pointwise convolution data gradient (see pw_gemm.h)
-#include "pw_gemm_bf16.h"
+#include "pw_gemm_ws.h"
 
 template <typename T>
 static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
@@ -39,6 +39,13 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == X3D_F32) return pw_dgrad_dispatch<float>(a, d->epi, vec, st);
   const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
+  if (d->epi != X3D_EPI_ADD_STRIDED && pw_ws_applies(a, vec, ovec)) {   // deep, narrow layers (stage 5)
+    switch (d->epi) {
+      case X3D_EPI_STORE: return pw_ws_launch<PRO_BNBWD, X3D_EPI_STORE>(a, st);
+      case X3D_EPI_ADD: return pw_ws_launch<PRO_BNBWD, X3D_EPI_ADD>(a, st);
+      case X3D_EPI_SWISH_BWD: return pw_ws_launch<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st);
+    }
+  }
   switch (d->epi) {  // bf16 storage: bf16 matrix cores
     case X3D_EPI_STORE: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_STORE>(a, vec, ovec, st);
     case X3D_EPI_ADD: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_ADD>(a, vec, ovec, st);
