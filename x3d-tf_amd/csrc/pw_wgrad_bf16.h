@@ -205,7 +205,9 @@ template <int MG, int NG, bool XPRO, int STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
-  constexpr int BP = 64, LP = BP + 8;
+  // U sub-steps of 64 points are staged and multiplied per barrier pair: half the barriers and twice the loads in
+  // flight per thread (a 64-point step is ~400 instructions between two barriers: the waves mostly wait)
+  constexpr int BP = 64, U = 2, LP = U * BP + 8;
   constexpr int TPW = (MG * NG + 3) / 4;
   bf16* As = (bf16*)smem_raw;              // [MG*32][LP]  dYraw
   bf16* Bs = As + MG * 32 * LP;            // [NG*32][LP]  f(X)
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
   const int mt_here = min(MG, (a.Cout - co0 + 31) / 32), nt_here = min(NG, (a.Cin - ci0 + 31) / 32);
   const int ntiles = mt_here * nt_here;
   const int nks = (TPW == 1 && ntiles <= 2) ? 4 / ntiles : 1;
-  const int ksteps = (BP / 16) / nks;
+  const int ksteps = (U * BP / 16) / nks;
 
   f32x16 acc[TPW];
 #pragma unroll
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
 
-  bf16x8 rg[MG], ry[MG], rx[NG], rx2[STRIDED ? NG : 1];
+  bf16x8 rg[U][MG], ry[U][MG], rx[U][NG], rx2[U][STRIDED ? NG : 1];
   // per-row coefficients are loop invariants of this thread (rows co0 + i*32 + srow / ci0 + i*32 + srow): loaded
   // once here instead of from global inside every step's prologue (an exposed L2 round trip per 64-point step);
   // only the SE gate depends on the sample and is re-read when the step crosses into the next sample
@@ -254,95 +256,119 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
   };
   // (n, stp) = (sample, 64-point step inside the sample) are carried incrementally: a division per step and lambda
   // was ~100 scalar instructions of the 380-860 in the loop
-  auto issue = [&](int n, int stp) {
-    const long long p = (long long)stp * BP + sp;
+  auto issue = [&](int u, int n, int stp, bool live) {
+    const long long p = live ? (long long)stp * BP + sp : a.P;   // a dead sub-step (past s_end) stages zeros
     bf16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
 #pragma unroll
     for (int i = 0; i < MG; i++) {
       const int co = co0 + i * 32 + srow;
-      rg[i] = z; ry[i] = z;
+      rg[u][i] = z; ry[u][i] = z;
       if (co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
-        rg[i] = *(const bf16x8*)((const T*)a.g + o);
-        if (a.coef) ry[i] = *(const bf16x8*)((const T*)a.yraw + o);
+        rg[u][i] = *(const bf16x8*)((const T*)a.g + o);
+        if (a.coef) ry[u][i] = *(const bf16x8*)((const T*)a.yraw + o);
       }
     }
 #pragma unroll
     for (int i = 0; i < NG; i++) {
       const int ci = ci0 + i * 32 + srow;
-      rx[i] = z;
-      if constexpr (STRIDED) rx2[i] = z;
+      rx[u][i] = z;
+      if constexpr (STRIDED) rx2[u][i] = z;
       if (ci < a.Cin && p < a.P) {
         if constexpr (STRIDED) {
           // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
-          strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[i], rx2[i]);
+          strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
         } else {
-          rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
+          rx[u][i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
         }
       }
     }
   };
-  auto commit = [&](int n, int stp) {
+  auto commit = [&](int u, int n, int stp, bool live) {
 #pragma unroll
     for (int i = 0; i < MG; i++) {
       const int co = co0 + i * 32 + srow;
-      bf16* dst = &As[(i * 32 + srow) * LP + sp];
+      bf16* dst = &As[(i * 32 + srow) * LP + u * BP + sp];
       if (a.coef && co < a.Cout) {
         const float A = cA[i], B = cB[i], C = cC[i];
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
+        for (int e = 0; e < 8; e++) v[e] = A * (float)rg[u][i][e] + B * (float)ry[u][i][e] + C;
         const long long p = (long long)stp * BP + sp;
-        if (p >= a.P) {
+        if (p >= a.P || !live) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = 0.f;      // C must not leak into padded points
         }
         VecIO<bf16, 8>::store(dst, v);
       } else {
-        *(bf16x8*)dst = rg[i];
+        *(bf16x8*)dst = rg[u][i];
       }
     }
 #pragma unroll
     for (int i = 0; i < NG; i++) {
       const int ci = ci0 + i * 32 + srow;
-      bf16* dst = &Bs[(i * 32 + srow) * LP + sp];
+      bf16* dst = &Bs[(i * 32 + srow) * LP + u * BP + sp];
       if constexpr (STRIDED) {
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { o[e] = rx[i][2 * e]; o[4 + e] = rx2[i][2 * e]; }
+        for (int e = 0; e < 4; e++) { o[e] = rx[u][i][2 * e]; o[4 + e] = rx2[u][i][2 * e]; }
         *(bf16x8*)dst = o;
       } else if constexpr (XPRO) {
         float v[8];
-        if (n != n_gate) load_gate(n);
+        if (live && n != n_gate) load_gate(n);
         const float s = xs_[i], t = xt_[i], g = xg_[i];
         const long long p = (long long)stp * BP + sp;
-        const bool pin = p < a.P;
+        const bool pin = live && p < a.P;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          float u = (s * (float)rx[i][e] + t) * g;
-          if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-          else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
-          v[e] = pin ? u : 0.f;
+          float uu = (s * (float)rx[u][i][e] + t) * g;
+          if (a.xact == X3D_ACT_RELU) uu = fmaxf(uu, 0.f);
+          else if (a.xact == X3D_ACT_SWISH) uu = swishf_(uu);
+          v[e] = pin ? uu : 0.f;
         }
         VecIO<bf16, 8>::store(dst, v);
       } else {
-        *(bf16x8*)dst = rx[i];
+        *(bf16x8*)dst = rx[u][i];
       }
     }
   };
 
-  int n_c = s_begin / steps_per_n, stp_c = s_begin - n_c * steps_per_n;   // step being consumed
-  int n_i = n_c, stp_i = stp_c;                                           // step being loaded
-  if (s_begin < s_end) { load_gate(n_c); issue(n_i, stp_i); }
-  for (int step = s_begin; step < s_end; ++step) {
+  // (sample, step-in-sample) of the sub-steps being consumed (c) and being loaded (i), advanced incrementally
+  int n_c[U], stp_c[U], n_i[U], stp_i[U];
+  {
+    int n0 = s_begin / steps_per_n, st0 = s_begin - n0 * steps_per_n;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      n_c[u] = n0; stp_c[u] = st0;
+      if (++st0 == steps_per_n) { st0 = 0; ++n0; }
+    }
+  }
+  if (s_begin < s_end) {
+    load_gate(n_c[0]);
+#pragma unroll
+    for (int u = 0; u < U; u++) issue(u, n_c[u], stp_c[u], s_begin + u < s_end);
+  }
+  for (int step = s_begin; step < s_end; step += U) {
     __syncthreads();
-    commit(n_c, stp_c);
+#pragma unroll
+    for (int u = 0; u < U; u++) commit(u, n_c[u], stp_c[u], step + u < s_end);
     __syncthreads();
-    if (++stp_i == steps_per_n) { stp_i = 0; ++n_i; }
-    if (step + 1 < s_end) issue(n_i, stp_i);
-    n_c = n_i; stp_c = stp_i;
+    {
+      int n0 = n_c[U - 1], st0 = stp_c[U - 1];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (++st0 == steps_per_n) { st0 = 0; ++n0; }
+        n_i[u] = n0; stp_i[u] = st0;
+      }
+    }
+    if (step + U < s_end) {
+#pragma unroll
+      for (int u = 0; u < U; u++) issue(u, n_i[u], stp_i[u], step + U + u < s_end);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) { n_c[u] = n_i[u]; stp_c[u] = stp_i[u]; }
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       int id = wid + 4 * s, kpart = 0;
@@ -382,7 +408,7 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
   const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
-  const size_t lds = (size_t)(MG + NG) * 32 * 72 * 2;
+  const size_t lds = (size_t)(MG + NG) * 32 * (2 * 64 + 8) * 2;
   auto kern = pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>;
   // one balanced round: as many workgroups as the chip holds at once (occupancy x CUs), the 64-point steps split
   // evenly among them.  A fixed steps-per-block left e.g. 1568 workgroups on 1280 slots: a second round at 22 %.
