@@ -232,6 +232,8 @@ def test_pw_packed_panels(gpu, shape):
     (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),     # X3D-M stage-2 planes, SW=4, H-tiled
     (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1),        # T=1 / non-square / odd widths
     (1, 2, 16, 28, 28, 1),                            # vec 4 path for bf16
+    (2, 3, 16, 14, 14, 1), (1, 2, 6, 7, 7, 1),        # deep-prefetch variants (dw_pd.hip): T = 4k, T % 4 != 0,
+    (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),         #   T < depth, stride 2
 ])
 def test_dw3d_fwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
@@ -352,6 +354,7 @@ def test_pw_wgrad(gpu, dtype, shape):
     (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2), (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),
     (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1), (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),
     (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1), (1, 2, 16, 28, 28, 1),
+    (2, 3, 16, 14, 14, 1), (1, 2, 6, 7, 7, 1), (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),   # deep-prefetch variants
 ])
 def test_dw3d_bwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()

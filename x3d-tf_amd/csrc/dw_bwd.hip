@@ -10,14 +10,6 @@
 // Planes of act and dB are streamed through LDS once (prefetched one plane ahead); the temporal taps are
 // handled with rotating register accumulators (dA) and a one-plane-old register window (dW).
 // ================================================================================================
-struct DwBwdArgs {
-  DwGeom g;
-  const void* dv; const void* braw; const float* coef_nc;
-  const void* araw; const float* ss_a; const float* w;
-  void* ga; double* a_sums; float* dw;
-  int LPB, RB;  // dB plane pitch / rows
-  int vecB;     // staging vector width for the dv / braw planes
-};
 
 template <typename T, int S, int SW, int NSV, int CV>
 __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
@@ -354,6 +346,16 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   }
   const int nsvA = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd), nsvB = dw_nsv(a.RB, a.g.Wo, a.vecB, bd);
   const int nsv = nsvA > nsvB ? nsvA : nsvB;
+  // small planes (strips of 1 / 2 outputs, stride 1): deep-prefetch variant (dw_pd.hip) when one staging vector per
+  // thread and tensor covers the tile
+  const int pd = dw_pick_pd(SW);
+  if (S == 1 && pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
+    if (dw_bwd_pd_launch(a, (int)sizeof(T), S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
+      if (x3d_describe.out) return X3D_OK;
+      X3D_LAUNCH_CHECK("dw3d_bwd");
+      return X3D_OK;
+    }
+  }
   switch (SW) {
     case 4:
       if constexpr (S == 1) { dw_bwd_launch_nsv<T, S, 4>(a, nsv, cv, (unsigned)grid, bd, lds, st); break; }

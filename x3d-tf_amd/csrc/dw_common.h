@@ -43,6 +43,68 @@ template <> __device__ __forceinline__ float raw_get<float>(const Raw& r, int e)
 template <> __device__ __forceinline__ float raw_get<bf16>(const Raw& r, int e) {
   return __uint_as_float(((r.w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
 }
+
+// ---- argument blocks shared by the streaming kernels (dw_fwd.hip / dw_bwd.hip) and their deep-prefetch
+// variants for small planes (dw_pd.hip)
+struct DwFwdArgs {
+  DwGeom g;
+  const void* x; const float* w; void* y;
+  const float* ss; int act;
+  double* stats; double* pool;
+};
+struct DwBwdArgs {
+  DwGeom g;
+  const void* dv; const void* braw; const float* coef_nc;
+  const void* araw; const float* ss_a; const float* w;
+  void* ga; double* a_sums; float* dw;
+  int LPB, RB;  // dB plane pitch / rows
+  int vecB;     // staging vector width for the dv / braw planes
+};
+// prefetch depth (planes in flight per workgroup) of the deep-prefetch variants for strips of SW outputs:
+// 4 for SW <= 2 (rows of < 20 outputs), else 1 (one-plane-ahead kernels).  X3D_DW_PD=1 switches them off (A/B hook).
+int dw_pick_pd(int SW);
+// deep-prefetch launchers (dw_pd.hip); return false when the shape is not covered (caller falls back)
+bool dw_fwd_pd_launch(const DwFwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+                      size_t lds, hipStream_t st);
+bool dw_bwd_pd_launch(const DwBwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+                      size_t lds, hipStream_t st);
+
+// ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
+// resource's num_records) loads zeros / drops the store WITHOUT touching memory, so the instruction itself can be
+// unconditional.  That matters for more than the branch: vmcnt retires in order and the compiler must assume a
+// conditional memory operation was not issued, which turns every wait behind one into vmcnt(0).
+typedef __attribute__((ext_vector_type(4))) unsigned int dw_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int dw_u32x2;
+#define DW_OOB 0x40000000
+template <int BYTES>
+__device__ __forceinline__ void raw_bload(Raw& r, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  if constexpr (BYTES == 16) { const dw_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0); r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3]; }
+  else if constexpr (BYTES == 8) { const dw_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); r.w[0] = v[0]; r.w[1] = v[1]; }
+  else if constexpr (BYTES == 4) { r.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
+  else { r.w[0] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
+}
+template <int BYTES>
+__device__ __forceinline__ void raw_bstore(const Raw& r, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  if constexpr (BYTES == 16) { const dw_u32x4 v = {r.w[0], r.w[1], r.w[2], r.w[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0); }
+  else if constexpr (BYTES == 8) { const dw_u32x2 v = {r.w[0], r.w[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, 0); }
+  else if constexpr (BYTES == 4) { __builtin_amdgcn_raw_buffer_store_b32(r.w[0], rs, voff, soff, 0); }
+  else { __builtin_amdgcn_raw_buffer_store_b16((unsigned short)r.w[0], rs, voff, soff, 0); }
+}
+// N fp32 values -> N elements of storage type T packed into a Raw
+template <typename T, int N> __device__ __forceinline__ void raw_pack(Raw& r, const float (&v)[N]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r.w[i] = __float_as_uint(v[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; i++) {
+      const uint32_t lo = __builtin_bit_cast(unsigned short, (bf16)v[2 * i]);
+      const uint32_t hi = (2 * i + 1 < N) ? (uint32_t)__builtin_bit_cast(unsigned short, (bf16)v[2 * i + 1]) : 0u;
+      r.w[i] = lo | (hi << 16);
+    }
+  }
+}
+
 template <typename T> struct MaxVec { static constexpr int v = 16 / sizeof(T); };
 
 // staging map of one plane tile: vector i of this thread reads goff[i] (elements from the plane origin,
@@ -123,6 +185,57 @@ __device__ __forceinline__ void lds_window(const float* __restrict__ p, float (&
   }
 #pragma unroll
   for (; i < N; i++) w[i] = p[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed fp32 arithmetic for the FORWARD tap loop.  v_pk_fma_f32 retires two FMAs per lane and instruction on an
+// even-aligned register pair, op_sel picking either half of each source for each half of the result.  Pairs that
+// need no data movement:
+//   * over the TEMPORAL taps: one staged value feeds three output planes, (out[t-1], out[t]) += (w_kt2, w_kt1) * v
+//     with the weight pair in an SGPR pair and v broadcast -- 3 FMAs in 2 instructions, any strip width;
+//   * the third plane over adjacent outputs (i, i+1) of the strip when the two inputs are an aligned register pair
+//     of the window (stride 1, even i + kw): 2 FMAs in 1 instruction.
+// Every product is added to the same accumulator in the same order as the scalar code: results are bit-identical.
+// Measured (tools/ab_dw.py, r01h): forward stride-1 layers 4-16 % faster.  tools/micro/pk_rate.hip: a packed FMA does
+// not have twice the FMA throughput of v_fma_f32 on MI355X (1.15-1.2x in dependent chains), so the gain is issue
+// slots, not arithmetic rate; in the fused backward the pair constraints cost ~20 VGPRs and a wave of occupancy
+// and it got slower (570 -> 690 us at 56x56), so the backward kernels keep scalar FMAs.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f bc2(float v) { return (v2f){v, v}; }
+
+// One window row: acc01[i] += wp[kw] * x (the pair of planes), acc2[i] += w3[kw] * x (third plane, held as pairs
+// over i), x = win[i*S + kw], kw ascending.
+template <int S, int SW, int WIN>
+__device__ __forceinline__ void dw_taps_row(const float (&win)[WIN], const v2f (&wp)[3], const float (&w3)[3],
+                                            v2f (&acc01)[SW], v2f (&acc2p)[(SW + 1) / 2]) {
+#pragma unroll
+  for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+    for (int i = 0; i < SW; i++) acc01[i] = pk_fma(wp[kw], bc2(win[i * S + kw]), acc01[i]);
+#pragma unroll
+    for (int i = 0; i < SW; i += 2) {
+      const int col = i * S + kw;
+      if (S == 1 && i + 1 < SW && (col & 1) == 0) {
+        acc2p[i / 2] = pk_fma(bc2(w3[kw]), (v2f){win[col], win[col + 1]}, acc2p[i / 2]);
+      } else {
+        acc2p[i / 2].x = __builtin_fmaf(w3[kw], win[col], acc2p[i / 2].x);
+        if (i + 1 < SW) acc2p[i / 2].y = __builtin_fmaf(w3[kw], win[col + S], acc2p[i / 2].y);
+      }
+    }
+  }
+}
+// rotate the three planes after a staged plane: fin <- plane (t-1) (complete), pair <- (plane t, plane t+1), third <- 0
+template <int SW>
+__device__ __forceinline__ void dw_rotate(float (&fin)[SW], v2f (&acc01)[SW], v2f (&acc2p)[(SW + 1) / 2]) {
+#pragma unroll
+  for (int i = 0; i < SW; i++) {
+    fin[i] = acc01[i].x;
+    acc01[i] = (v2f){acc01[i].y, (i & 1) ? acc2p[i / 2].y : acc2p[i / 2].x};
+  }
+#pragma unroll
+  for (int j = 0; j < (SW + 1) / 2; j++) acc2p[j] = (v2f){0.f, 0.f};
 }
 
 // tile geometry shared by forward and backward

@@ -1,12 +1,6 @@
 // x3d_dw3d_fwd: channelwise 3x3x3 convolution forward (design notes in dw_common.h)
 #include "dw_common.h"
 
-struct DwFwdArgs {
-  DwGeom g;
-  const void* x; const float* w; void* y;
-  const float* ss; int act;
-  double* stats; double* pool;
-};
 
 // ================================================================================================
 // forward.  NSV = staging vectors per thread held in registers for the prefetch (0: direct staging)
@@ -34,9 +28,14 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 
   for (int i = threadIdx.x; i < plane_sz; i += blockDim.x) lds[i] = 0.f;
 
-  float wgt[27];
+  // weights as (kt=2, kt=1) pairs for the packed planes (out[t-1], out[t]) and kt=0 for the third (out[t+1])
+  v2f w21[3][3];
+  float w0[3][3];
 #pragma unroll
-  for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  for (int k = 0; k < 9; k++) {
+    w21[k / 3][k % 3] = (v2f){a.w[c * 27 + 18 + k], a.w[c * 27 + 9 + k]};
+    w0[k / 3][k % 3] = a.w[c * 27 + k];
+  }
   const bool affine = a.ss != nullptr;
   const float sc = affine ? a.ss[c * 2] : 1.f, sh = affine ? a.ss[c * 2 + 1] : 0.f;
   const int act = a.act;
@@ -59,9 +58,11 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
     for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + map.goff[i], vec);
   }
 
-  float acc0[SW], acc1[SW], acc2[SW];
+  v2f acc01[SW], acc2p[(SW + 1) / 2];   // (out[t-1], out[t]) per output, out[t+1] as pairs over outputs
 #pragma unroll
-  for (int i = 0; i < SW; i++) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
+  for (int i = 0; i < SW; i++) acc01[i] = (v2f){0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < (SW + 1) / 2; j++) acc2p[j] = (v2f){0.f, 0.f};
   float s1 = 0.f, s2 = 0.f;
   float fin[SW];   // finished output plane waiting for its (deferred) store
 #pragma unroll
@@ -120,26 +121,20 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
         float win[WIN];
         const float* row = lds + (r * S + kh) * g.LP + wo0 * S;   // wo0 * S is a multiple of SW * S floats
         lds_window<WIN, (SW * S >= 4 ? 4 : SW * S)>(row, win);
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-#pragma unroll
-          for (int i = 0; i < SW; i++) {
-            const float v = win[i * S + kw];
-            acc0[i] += wgt[18 + kh * 3 + kw] * v;  // out[t-1] sees this plane through kt = 2
-            acc1[i] += wgt[9 + kh * 3 + kw] * v;   // out[t]   through kt = 1
-            acc2[i] += wgt[kh * 3 + kw] * v;       // out[t+1] through kt = 0
-          }
-        }
+        // out[t-1] sees this plane through kt = 2, out[t] through kt = 1, out[t+1] through kt = 0
+        dw_taps_row<S, SW, WIN>(win, w21[kh], w0[kh], acc01, acc2p);
       }
     }
     // acc0 now holds output plane t-1 complete.  Its store is DEFERRED to the start of the next iteration's
     // arithmetic: vmcnt retires in order, so a store issued here would sit in front of the wait for the
     // prefetched plane at the top of the next iteration and expose its full write latency every plane.
-#pragma unroll
-    for (int i = 0; i < SW; i++) { fin[i] = acc0[i]; acc0[i] = acc1[i]; acc1[i] = acc2[i]; acc2[i] = 0.f; }
+    dw_rotate<SW>(fin, acc01, acc2p);
   }
   if (g.T >= 2) store_plane(g.T - 2, fin);
-  store_plane(g.T - 1, acc0);
+  float last[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) last[i] = acc01[i].x;
+  store_plane(g.T - 1, last);
 
   if (a.stats || a.pool) {
     float red[2] = {s1, s2};
@@ -197,6 +192,15 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   // compile-time staging width when every output strip is whole and SW-aligned (always true for SW == 1)
   const bool strips_ok = (a.g.Wo % SW == 0) && (((uintptr_t)f->y) % (SW * sizeof(T)) == 0);
   const int cv = strips_ok ? a.g.vec : 0;
+  // small planes: deep-prefetch variant (dw_pd.hip) when one staging vector per thread covers the tile
+  const int pd = dw_pick_pd(SW);
+  if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
+    if (dw_fwd_pd_launch(a, (int)sizeof(T), S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
+      if (x3d_describe.out) return X3D_OK;
+      X3D_LAUNCH_CHECK("dw3d_fwd");
+      return X3D_OK;
+    }
+  }
   switch (SW) {
     case 4: dw_fwd_launch_nsv<T, S, 4>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
     case 2: dw_fwd_launch_nsv<T, S, 2>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
