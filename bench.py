@@ -164,7 +164,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device(f"cuda:{xdist.local_device(local_rank)}")
     torch.cuda.set_device(device)
 
     from x3d_tf_amd.model import X3D

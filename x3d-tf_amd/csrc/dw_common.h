@@ -267,6 +267,8 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
 static int dw_pick_sw(int Wo) {
   static const char* e = getenv("X3D_DW_SW14");   // experiment hook: strip width for 10 <= Wo < 20
   if (e && Wo >= 10 && Wo < 20) return atoi(e);
+  static const char* e2 = getenv("X3D_DW_SW28");  // experiment hook: strip width for Wo >= 20
+  if (e2 && Wo >= 20) return atoi(e2);
   return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1);
 }
 

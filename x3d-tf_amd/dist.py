@@ -23,16 +23,28 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def local_device(local_rank: int) -> int:
+    """Device index of a local rank: one GPU per rank; ranks wrap around only in a gloo rehearsal."""
+    n = torch.cuda.device_count()
+    if n == 0:
+        return 0
+    if local_rank >= n and os.environ.get("X3D_DIST_BACKEND") != "gloo":
+        raise RuntimeError(f"LOCAL_RANK {local_rank} but only {n} GPU(s) visible: one process per GPU")
+    return local_rank % n
+
+
 def init_process_group(backend: Optional[str] = None):
     """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE if WORLD_SIZE > 1."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # X3D_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
+            # (RCCL refuses two ranks on one device; gloo stages device tensors through the host)
+            backend = os.environ.get("X3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
