@@ -348,8 +348,11 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   const int nsv = nsvA > nsvB ? nsvA : nsvB;
   // small planes (strips of 1 / 2 outputs, stride 1): deep-prefetch variant (dw_pd.hip) when one staging vector per
   // thread and tensor covers the tile
-  const int pd = dw_pick_pd(SW);
-  if (S == 1 && pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
+  // stride 2: depth 2 (144 VGPRs, 3 waves; no vmcnt(0) drain before the stores: 1066 -> 961 us at 112x112); depth 4 is
+  // 160-190 VGPRs and slower.  X3D_DW_PD_S2=1 / X3D_DW_PD=1 switch back to the one-plane-ahead kernel (A/B hooks).
+  static const char* pd_s2 = getenv("X3D_DW_PD_S2");
+  const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : (pd_s2 ? atoi(pd_s2) : 2));
+  if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
     if (dw_bwd_pd_launch(a, (int)sizeof(T), S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;
       X3D_LAUNCH_CHECK("dw3d_bwd");

@@ -472,8 +472,12 @@ static bool bwd_pd_t(const DwBwdArgs& a, int S, int SW, int cv, int pd, unsigned
     if (SW == 1 && pd == 4) { DW_PD_CV(bwd_go, T, 1, 1, 4) }
     if (SW == 2 && pd == 4) { DW_PD_CV(bwd_go, T, 1, 2, 4) }
     // SW == 4 at depth 2: 220-250 VGPRs (2 waves) -- the one-plane-ahead kernel keeps those planes
+  } else {
+    // stride 2: 2x2 input quads per output put the depth-4 kernel at 160-190 VGPRs (2 waves): measured 0.84x;
+    // depth 2 (136-144 VGPRs, 3 waves) is 1.11x the one-plane-ahead kernel on the 112x112 / 56x56 layers
+    if (SW == 1 && pd == 2) { DW_PD_CV(bwd_go, T, 2, 1, 2) }
+    if (SW == 2 && pd == 2) { DW_PD_CV(bwd_go, T, 2, 2, 2) }
   }
-  // stride 2: 2x2 input quads per output put the depth-4 kernel at 160-190 VGPRs (2 waves): measured 0.84x
   return false;
 }
 
