@@ -341,6 +341,33 @@ typedef struct {
 int x3d_eval_views(const x3d_eval_views_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * train-side clip construction (the device half of the training input pipeline; decoding stays on
+ * the host): decoded video -> one augmented training clip.
+ *     reference transforms.py:31-47 (random start, every `rate`-th frame, the video looped), :112-147
+ *     (random_short_side_resize: short side -> int(jitter), long side floor((long/short) * jitter) in float32,
+ *     bilinear, cast back to uint8), :199-203 (tf.image.random_crop: one (y0, x0) for every frame of the clip),
+ *     :205-206 (flip_left_right on EVERY training clip: `random_hflip` is just `is_training`, dataloader.py:136),
+ *     utils.py:42-72 (x/255 - mean, / std).
+ *     The random draws (start, jitter, y0, x0) are the caller's: TF's generator streams are not reproduced [TF-3p].
+ *     video [F][H][W][3] uint8 (device) -> out [T][size][size][3] (X3D_F32 / X3D_BF16), channels-last
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const unsigned char* video;
+  void* out;
+  int F, H, W;
+  int T, rate, start;          /* frame j of the clip = (start + j * rate) mod F */
+  float jitter;                /* short-side target, uniform in [TRAIN_JITTER_SCALES) */
+  int size, y0, x0;            /* crop size and offsets inside the resized frame */
+  int flip;                    /* 1: mirror left-right (the reference always does in training) */
+  float mean[3];
+  float std[3];
+  int dtype;
+} x3d_train_clip_args;
+int x3d_train_clip(const x3d_train_clip_args* a, void* stream);
+/* extents of a H x W frame after random_short_side_resize with target `jitter` (transforms.py:126-141) */
+int x3d_train_resized_hw(int H, int W, float jitter, int* new_h, int* new_w);
+
+/* ------------------------------------------------------------------------------------------
  * host helper: CRC32C (Castagnoli), the checksum of TF tensor-bundle checkpoints
  *     (reference train.py:151-158 / utils.py restore path reads such files through tf.train.Checkpoint)
  * ------------------------------------------------------------------------------------------ */

@@ -12,6 +12,11 @@ Follows (reference file:line):
   * uniform (left/centre/right or top/centre/bottom) crop, ceil offsets .. transforms.py:149-190, :219-225
   * normalise  x/255 - mean, / std  per channel ........ utils.py:42-72, transforms.py:228
   * flattening order [crops][views] -> clips ........... dataloader.py:107-116
+Training branch (train_clip below):
+  * random start, every rate-th frame, looped video .... transforms.py:31-47
+  * random_short_side_resize with a float target ....... transforms.py:112-147
+  * tf.image.random_crop (one offset per clip) [TF-3p] . transforms.py:199-203
+  * flip_left_right on every training clip ............. transforms.py:205-206, dataloader.py:136
 """
 import math
 
@@ -109,3 +114,44 @@ def eval_views(video_u8, num_frames, num_views, num_crops, crop_size, mean, std)
             cr = fr[:, y:y + crop_size, x:x + crop_size, :].astype(np.float32)
             out[ci, v] = (cr / np.float32(255) - mean) / std   # utils.py:59-66
     return out.reshape(num_crops * num_views, num_frames, crop_size, crop_size, 3)
+
+
+# ---- training branch --------------------------------------------------------------------------------------------
+def train_temporal_indices(num_video_frames: int, num_frames: int, rate: int, start: int):
+    """transforms.py:31-47: end = start + T*rate; the frame list is tiled ceil(end / size) times and sliced
+    [start:end:rate], i.e. frame j = (start + j*rate) mod size."""
+    size = int(num_video_frames)
+    end = start + num_frames * rate
+    loops = int(math.ceil(end / size))
+    idx = np.tile(np.arange(size), loops)[start:end:rate]
+    assert idx.shape[0] == num_frames
+    return idx
+
+
+def train_resized_hw(height: int, width: int, jitter):
+    """transforms.py:124-141 with a NON-integer target: new_width = new_height = size (float32); the long side is
+    floor((long / short) * size); both are then cast to int32 (:140-141), which truncates the short side to int(size)."""
+    h, w, s = np.float32(height), np.float32(width), np.float32(jitter)
+    if (w <= h and w == s) or (h <= w and h == s):
+        return height, width
+    new_h, new_w = s, s
+    if w < h:
+        new_h = np.floor((h / w) * s)
+    else:
+        new_w = np.floor((w / h) * s)
+    return int(new_h), int(new_w)
+
+
+def train_clip(video_u8, num_frames, rate, start, jitter, crop_size, y0, x0, flip, mean, std):
+    """video_u8 [F,H,W,3] uint8 -> float32 clip [T, crop, crop, 3] (the 4-D tensor of transforms.py:199-209 before the
+    expand_dims).  tf.image.random_crop takes ONE offset for the whole [T, H, W, C] tensor [TF-3p]."""
+    idx = train_temporal_indices(video_u8.shape[0], num_frames, rate, start)
+    h, w = video_u8.shape[1:3]
+    nh, nw = train_resized_hw(h, w, jitter)
+    fr = resize_bilinear_u8(video_u8[idx], nh, nw)
+    cr = fr[:, y0:y0 + crop_size, x0:x0 + crop_size, :]
+    if flip:
+        cr = cr[:, :, ::-1, :]                                   # tf.image.flip_left_right: reverse the width axis
+    mean = np.asarray(mean, np.float32)
+    std = np.asarray(std, np.float32)
+    return (cr.astype(np.float32) / np.float32(255) - mean) / std

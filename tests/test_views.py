@@ -61,6 +61,29 @@ def test_eval_views_order_and_normalisation():
     assert np.array_equal(out[3], ref)
 
 
+def test_train_temporal_indices_and_resize():
+    # 30 frames, T=4, rate 5 from frame 22: 22, 27, 32 -> 2, 37 -> 7 (the video loops)
+    assert V.train_temporal_indices(30, 4, 5, 22).tolist() == [22, 27, 2, 7]
+    assert V.train_temporal_indices(3, 5, 2, 1).tolist() == [1, 0, 2, 1, 0]
+    # float target 273.6 on 240x320: short side int(273.6) = 273, long side floor(320/240*273.6) = 364
+    assert V.train_resized_hw(240, 320, 273.6) == (273, 364)
+    assert V.train_resized_hw(320, 240, 273.6) == (364, 273)
+    assert V.train_resized_hw(256, 300, 256.0) == (256, 300)   # short side already there
+
+
+def test_train_clip_crop_flip_normalise():
+    rng = np.random.default_rng(2)
+    vid = rng.integers(0, 256, (11, 24, 30, 3)).astype(np.uint8)
+    mean, std = [0.45, 0.40, 0.35], [0.2, 0.25, 0.3]
+    a = V.train_clip(vid, 4, 2, 9, 26.5, 16, 3, 5, False, mean, std)
+    b = V.train_clip(vid, 4, 2, 9, 26.5, 16, 3, 5, True, mean, std)
+    assert a.shape == (4, 16, 16, 3) and np.array_equal(a[:, :, ::-1], b)
+    nh, nw = V.train_resized_hw(24, 30, 26.5)
+    fr = V.resize_bilinear_u8(vid[[9, 0, 2, 4]], nh, nw)        # (9 + 2j) mod 11
+    ref = (fr[:, 3:19, 5:21].astype(np.float32) / np.float32(255) - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+    assert np.array_equal(a, ref)
+
+
 # ---- HIP kernel (GPU) ----------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
@@ -111,3 +134,44 @@ def test_evaluate_driver(gpu):
     acc = float((probs.argmax(1) == labels).float().mean())
     assert res["videos"] == 3 and abs(res["loss"] - loss) < 1e-5 and abs(res["acc"] - acc) < 1e-6
     assert res["top_5_acc"] >= res["acc"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # F, H, W, T, rate, crop, jitter_lo, jitter_hi
+    (40, 48, 64, 8, 5, 32, 36.0, 44.0),      # landscape, looping sampler
+    (9, 64, 48, 4, 3, 32, 34.0, 40.0),       # portrait, fewer frames than T * rate
+    (6, 37, 53, 4, 1, 24, 24.0, 30.0),       # odd extents
+])
+def test_train_clip_kernel_matches_oracle(gpu, case):
+    import x3d_tf_amd as x3d
+    from x3d_tf_amd.views import draw_train_params, make_train_batch, make_train_clip, train_resized_hw
+    f, h, w, t, rate, crop, jlo, jhi = case
+    cfg = x3d.get_config("XS", ["DATA.TEMP_DURATION", t, "DATA.FRAME_RATE", rate, "DATA.TRAIN_CROP_SIZE", crop,
+                                "DATA.TRAIN_JITTER_SCALES", [jlo, jhi]])
+    rng = np.random.default_rng(f * 1000 + h)
+    vid = rng.integers(0, 256, (f, h, w, 3)).astype(np.uint8)
+    dvid = torch.from_numpy(vid).to(gpu)
+    g = torch.Generator().manual_seed(f)
+    for _ in range(4):
+        p = draw_train_params(f, h, w, cfg, g)
+        assert 0 <= p["start"] < f and jlo <= p["jitter"] < jhi and p["flip"] is True
+        assert train_resized_hw(h, w, p["jitter"]) == V.train_resized_hw(h, w, p["jitter"])
+        ref = V.train_clip(vid, t, rate, p["start"], p["jitter"], crop, p["y0"], p["x0"], p["flip"], cfg.DATA.MEAN, cfg.DATA.STD)
+        got = make_train_clip(dvid, cfg, params=p)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), ref), float(np.abs(got.cpu().numpy() - ref).max())
+        gb = make_train_clip(dvid, cfg, params=p, dtype=torch.bfloat16)
+        assert torch.equal(gb.cpu(), torch.from_numpy(ref).bfloat16())
+    # no flip, and the batch helper: same generator state -> same clips
+    p = dict(draw_train_params(f, h, w, cfg, g), flip=False)
+    ref = V.train_clip(vid, t, rate, p["start"], p["jitter"], crop, p["y0"], p["x0"], False, cfg.DATA.MEAN, cfg.DATA.STD)
+    assert np.array_equal(make_train_clip(dvid, cfg, params=p).cpu().numpy(), ref)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    batch = make_train_batch([dvid, dvid], cfg, generator=g1)
+    assert tuple(batch.shape) == (2, t, crop, crop, 3)
+    for i in range(2):
+        assert torch.equal(batch[i], make_train_clip(dvid, cfg, generator=g2))
+    # bad offsets are refused by the library, not clamped
+    with pytest.raises(x3d.hip.X3DHipError):
+        make_train_clip(dvid, cfg, params=dict(p, y0=10 ** 6))

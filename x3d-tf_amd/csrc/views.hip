@@ -1,4 +1,5 @@
-// x3d_eval_views: eval-side view construction on the GPU.
+// x3d_eval_views / x3d_train_clip: eval-side view construction and train-side clip construction
+// (rank 4, device half) on the GPU.
 //   decoded video [F][H][W][3] uint8  ->  [crops*views][T][size][size][3] normalised clips (channels-last, as the
 //   model boundary takes them), one thread per output pixel.
 // Reference semantics (behaviour restated in oracle/views_oracle.py, which the tests compare against bit for bit):
@@ -13,6 +14,7 @@ struct EvalViewsArgs {
   void* out;
   int F, H, W, nh, nw;       // source extents, resized extents
   int T, views, crops, size, rate;
+  int start, flip;           // first frame of the sweep; mirror left-right (training clips)
   int yoff[3], xoff[3];      // crop offsets in the resized frame per spatial index
   float sy, sx;              // H / nh, W / nw (float32 division)
   float mean[3], std[3];
@@ -32,8 +34,8 @@ __global__ __launch_bounds__(256) void eval_views_kernel(const EvalViewsArgs a) 
   const int v = (int)(r % a.views);
   const int ci = (int)(r / a.views);
   const int sidx = a.crops > 1 ? ci % 3 : 1;
-  const int frame = (int)(((long long)(v * a.T + t) * a.rate) % a.F);
-  const int ry = y + a.yoff[sidx], rx = x + a.xoff[sidx];
+  const int frame = (int)((a.start + (long long)(v * a.T + t) * a.rate) % a.F);
+  const int ry = y + a.yoff[sidx], rx = (a.flip ? a.size - 1 - x : x) + a.xoff[sidx];
   // half-pixel-centre bilinear weights, float32, exactly as the oracle computes them
   const float fy = ((float)ry + 0.5f) * a.sy - 0.5f;
   const float fx = ((float)rx + 0.5f) * a.sx - 0.5f;
@@ -70,6 +72,7 @@ extern "C" int x3d_eval_views(const x3d_eval_views_args* e, void* stream) {
   EvalViewsArgs a;
   a.video = e->video; a.out = e->out; a.F = e->F; a.H = e->H; a.W = e->W;
   a.T = e->T; a.views = e->views; a.crops = e->crops; a.size = e->size;
+  a.start = 0; a.flip = 0;
   a.rate = e->F / e->T > 1 ? e->F / e->T : 1;                      // transforms.py:51
   // short side -> size, the long side floor((long/short) * size) in float32 (transforms.py:129-141)
   const float h = (float)e->H, w = (float)e->W, s = (float)e->size;
@@ -96,5 +99,44 @@ extern "C" int x3d_eval_views(const x3d_eval_views_args* e, void* stream) {
   if (e->dtype == X3D_F32) hipLaunchKernelGGL((eval_views_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((eval_views_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   X3D_LAUNCH_CHECK("eval_views");
+  return X3D_OK;
+}
+
+// random_short_side_resize (transforms.py:126-141), float32 as in the reference: the short side becomes int(jitter)
+// (the float -> int32 cast truncates), the long side floor((long / short) * jitter)
+extern "C" int x3d_train_resized_hw(int H, int W, float jitter, int* new_h, int* new_w) {
+  X3D_REQUIRE(H > 0 && W > 0 && jitter >= 1.0f && new_h && new_w, "train_resized_hw: bad arguments");
+  const float h = (float)H, w = (float)W, s = jitter;
+  *new_h = H; *new_w = W;
+  if ((w <= h && w == s) || (h <= w && h == s)) return X3D_OK;
+  float nh = s, nw = s;
+  if (w < h) nh = floorf((h / w) * s);
+  else nw = floorf((w / h) * s);
+  *new_h = (int)nh; *new_w = (int)nw;
+  return X3D_OK;
+}
+
+extern "C" int x3d_train_clip(const x3d_train_clip_args* e, void* stream) {
+  X3D_REQUIRE(e && e->video && e->out, "train_clip: null pointer");
+  X3D_REQUIRE(e->F > 0 && e->H > 0 && e->W > 0 && e->T > 0 && e->rate > 0 && e->size > 0, "train_clip: bad extents");
+  X3D_REQUIRE(e->start >= 0 && e->start < e->F, "train_clip: start %d outside the %d frames", e->start, e->F);
+  X3D_REQUIRE(e->dtype == X3D_F32 || e->dtype == X3D_BF16, "train_clip: bad dtype");
+  EvalViewsArgs a;
+  a.video = e->video; a.out = e->out; a.F = e->F; a.H = e->H; a.W = e->W;
+  a.T = e->T; a.views = 1; a.crops = 1; a.size = e->size;
+  a.rate = e->rate; a.start = e->start; a.flip = e->flip ? 1 : 0;
+  if (x3d_train_resized_hw(e->H, e->W, e->jitter, &a.nh, &a.nw) != X3D_OK) return X3D_ERR_INVALID;
+  X3D_REQUIRE(a.nh >= e->size && a.nw >= e->size, "train_clip: resized frame %dx%d smaller than the crop %d", a.nh, a.nw, e->size);
+  X3D_REQUIRE(e->y0 >= 0 && e->y0 <= a.nh - e->size && e->x0 >= 0 && e->x0 <= a.nw - e->size,
+              "train_clip: crop offset (%d, %d) outside the %dx%d frame", e->y0, e->x0, a.nh, a.nw);
+  a.sy = (float)e->H / (float)a.nh; a.sx = (float)e->W / (float)a.nw;
+  for (int i = 0; i < 3; i++) { a.yoff[i] = e->y0; a.xoff[i] = e->x0; a.mean[i] = e->mean[i]; a.std[i] = e->std[i]; }
+  const long long total = (long long)e->T * e->size * e->size;
+  const long long blocks = ceil_div_ll(total, 256);
+  X3D_REQUIRE(blocks < (1ll << 31), "train_clip: too many pixels");
+  hipStream_t st = (hipStream_t)stream;
+  if (e->dtype == X3D_F32) hipLaunchKernelGGL((eval_views_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((eval_views_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  X3D_LAUNCH_CHECK("train_clip");
   return X3D_OK;
 }

@@ -47,6 +47,12 @@ class EvalViewsArgs(C.Structure):
                 ("crops", _i), ("size", _i), ("mean", _f * 3), ("std", _f * 3), ("dtype", _i)]
 
 
+class TrainClipArgs(C.Structure):
+    _fields_ = [("video", _vp), ("out", _vp), ("F", _i), ("H", _i), ("W", _i), ("T", _i), ("rate", _i), ("start", _i),
+                ("jitter", _f), ("size", _i), ("y0", _i), ("x0", _i), ("flip", _i), ("mean", _f * 3), ("std", _f * 3),
+                ("dtype", _i)]
+
+
 class BnEvalItem(C.Structure):
     _fields_ = [("gamma", _vp), ("beta", _vp), ("moving_mean", _vp), ("moving_var", _vp), ("scale_shift", _vp),
                 ("mean_invstd", _vp), ("C", _i)]
@@ -117,6 +123,8 @@ _SIGS = {
     "x3d_l2_sumsq": ([_vp, _vp, _vp, _ll, _vp], _i),
     "x3d_nthwc_to_ncthw": ([_vp, _i, _vp, _i, _i, _i, _ll, _vp], _i),
     "x3d_eval_views": ([C.POINTER(EvalViewsArgs), _vp], _i),
+    "x3d_train_clip": ([C.POINTER(TrainClipArgs), _vp], _i),
+    "x3d_train_resized_hw": ([_i, _i, _f, C.POINTER(_i), C.POINTER(_i)], _i),
     "x3d_crc32c": ([C.c_char_p, C.c_size_t, C.c_uint32], C.c_uint32),
 }
 
