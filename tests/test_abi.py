@@ -33,7 +33,8 @@ def test_struct_layouts_match_header():
     pairs = {"x3d_pw_fwd_args": hip.PwFwdArgs, "x3d_pw_dgrad_args": hip.PwDgradArgs,
              "x3d_pw_wgrad_args": hip.PwWgradArgs, "x3d_pw_bwd_args": hip.PwBwdArgs,
              "x3d_pw_pack_item": hip.PwPackItem, "x3d_bn_eval_item": hip.BnEvalItem, "x3d_eval_views_args": hip.EvalViewsArgs, "x3d_dw3d_fwd_args": hip.Dw3dFwdArgs,
-             "x3d_dw3d_bwd_args": hip.Dw3dBwdArgs, "x3d_se_bnb_bwd_args": hip.SeBnbBwdArgs}
+             "x3d_dw3d_bwd_args": hip.Dw3dBwdArgs, "x3d_se_bnb_bwd_args": hip.SeBnbBwdArgs,
+             "x3d_bn_fold": hip.BnFold, "x3d_train_clip_args": hip.TrainClipArgs}
     for cname, cls in pairs.items():
         body = re.search(r"typedef struct \{([^{}]*)\} " + cname + ";", text).group(1)
         fields = []

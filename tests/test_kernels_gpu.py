@@ -700,3 +700,80 @@ def test_sgd_and_layout(gpu):
         dst = torch.empty((2, 3, 3, 5, 7), dtype=dt, device=gpu)
         ops.nthwc_to_ncthw(x.to(gpu), dst)
         report("layout", dst, x.permute(0, 4, 1, 2, 3).to(dt), 0, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm finalize folded into the consumer (x3d_bn_fold): the same bits as x3d_bn_finalize + the plain kernel
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 5, 4, 14, 14, 1), (2, 3, 3, 16, 16, 2), (2, 4, 5, 28, 28, 1), (1, 2, 2, 56, 56, 1)])
+def test_bn_fold_dw3d_fwd(gpu, dtype, shape):
+    ops = _ops()
+    n, c, t, h, w, stride = shape
+    g = _gen(21)
+    x, _ = rnd((n, c, t, h, w), dtype, g)
+    x = x.to(gpu)
+    wt = (torch.randn((c, 3, 3, 3), generator=g) * 0.3).to(gpu)
+    xs = x.float().double()
+    stats = torch.stack([xs.sum((0, 2, 3, 4)), (xs * xs).sum((0, 2, 3, 4))], 1).contiguous()
+    gamma = (1 + 0.3 * torch.randn(c, generator=g)).to(gpu)
+    beta = (0.3 * torch.randn(c, generator=g)).to(gpu)
+    count = n * t * h * w
+
+    def fresh():
+        return (torch.full((c,), 0.25, device=gpu), torch.full((c,), 1.5, device=gpu), torch.zeros((c, 2), device=gpu),
+                torch.zeros((c, 2), device=gpu))
+    mm0, mv0, ss0, mi0 = fresh()
+    ops.bn_finalize(stats, count, gamma, beta, mm0, mv0, 1e-5, 0.9, 1, ss0, mi0)
+    st0 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    y0 = ops.dw3d_fwd(x, wt, stride, in_ss=ss0, in_act=1, stats=st0)
+    mm1, mv1, ss1, mi1 = fresh()
+    fold = ops.bn_fold(stats, count, gamma, beta, mm1, mv1, 1e-5, 0.9, 1, ss1, mi1)
+    st1 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    y1 = ops.dw3d_fwd(x, wt, stride, in_act=1, stats=st1, in_bn=fold)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    for a_, b_ in ((ss0, ss1), (mi0, mi1), (mm0, mm1), (mv0, mv1)):
+        assert torch.equal(a_, b_)
+    assert ss1.abs().sum().item() > 0 and not torch.equal(mm1, torch.full((c,), 0.25, device=gpu))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 6, 3 * 14 * 14, True), (3, 4, 5 * 7 * 7, False), (1, 5, 1000, None)])
+def test_bn_fold_tail_fwd(gpu, dtype, shape):
+    ops = _ops()
+    n, c, pts, conv_shortcut = shape
+    g = _gen(22)
+    craw, _ = rnd((n, c, 1, 1, pts), dtype, g)
+    craw = craw.to(gpu)
+    sh = None
+    if conv_shortcut is not None:
+        sh, _ = rnd((n, c, 1, 1, pts), dtype, g)
+        sh = sh.to(gpu)
+
+    def stats_of(v):
+        d = v.float().double()
+        return torch.stack([d.sum((0, 2, 3, 4)), (d * d).sum((0, 2, 3, 4))], 1).contiguous()
+
+    def bn_set():
+        return dict(gamma=(1 + 0.3 * torch.randn(c, generator=_gen(5))).to(gpu), beta=(0.3 * torch.randn(c, generator=_gen(6))).to(gpu),
+                    mm=torch.full((c,), -0.5, device=gpu), mv=torch.full((c,), 2.0, device=gpu),
+                    ss=torch.zeros((c, 2), device=gpu), mi=torch.zeros((c, 2), device=gpu))
+    count = n * pts
+    ref_c, ref_r, new_c, new_r = bn_set(), bn_set(), bn_set(), bn_set()
+    st_c = stats_of(craw)
+    ops.bn_finalize(st_c, count, ref_c["gamma"], ref_c["beta"], ref_c["mm"], ref_c["mv"], 1e-5, 0.9, 1, ref_c["ss"], ref_c["mi"])
+    fc = ops.bn_fold(st_c, count, new_c["gamma"], new_c["beta"], new_c["mm"], new_c["mv"], 1e-5, 0.9, 1, new_c["ss"], new_c["mi"])
+    fr, r_ss = None, None
+    if conv_shortcut:
+        st_r = stats_of(sh)
+        ops.bn_finalize(st_r, count, ref_r["gamma"], ref_r["beta"], ref_r["mm"], ref_r["mv"], 1e-5, 0.9, 1, ref_r["ss"], ref_r["mi"])
+        fr = ops.bn_fold(st_r, count, new_r["gamma"], new_r["beta"], new_r["mm"], new_r["mv"], 1e-5, 0.9, 1, new_r["ss"], new_r["mi"])
+        r_ss = ref_r["ss"]
+    y0 = ops.tail_fwd(craw, ref_c["ss"], sh, r_ss, torch.empty_like(craw))
+    y1 = ops.tail_fwd_bn(craw, fc, sh, fr, torch.empty_like(craw))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    for k in ("ss", "mi", "mm", "mv"):
+        assert torch.equal(ref_c[k], new_c[k]), k
+        if conv_shortcut:
+            assert torch.equal(ref_r[k], new_r[k]), k

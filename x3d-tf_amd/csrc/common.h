@@ -183,6 +183,38 @@ static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// BatchNorm finalize (training): statistics -> (scale, shift), one channel.  ONE definition, used by
+// bn_finalize_kernel and by the consumers that fold the finalize into their prologue (x3d_bn_fold), so the
+// coefficients are the same bits whichever path computed them.  `writer`: exactly one thread per channel
+// and launch publishes scale_shift / mean_invstd and updates the moving statistics.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, bool writer, float& sc, float& sh) {
+  const double mean = f.stats[c * 2] / f.count;
+  double var = f.stats[c * 2 + 1] / f.count - mean * mean;  // biased batch variance (Keras, training)
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  sc = f.gamma[c] * invstd;
+  sh = f.beta[c] - (float)mean * sc;
+  if (writer) {
+    f.scale_shift[c * 2] = sc;
+    f.scale_shift[c * 2 + 1] = sh;
+    f.mean_invstd[c * 2] = (float)mean;
+    f.mean_invstd[c * 2 + 1] = invstd;
+    if (f.update_moving) {
+      // Keras momentum convention: moving = moving*momentum + batch*(1-momentum); the moving variance
+      // receives the unbiased estimate (TF fused batch norm) [TF-3p]
+      const double unb = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+      f.moving_mean[c] = f.moving_mean[c] * f.momentum + (float)mean * (1.f - f.momentum);
+      f.moving_var[c] = f.moving_var[c] * f.momentum + (float)unb * (1.f - f.momentum);
+    }
+  }
+}
+static inline bool bn_fold_valid(const x3d_bn_fold* f) {
+  return f && f->stats && f->gamma && f->beta && f->scale_shift && f->mean_invstd && f->count > 0 &&
+         (!f->update_moving || (f->moving_mean && f->moving_var));
+}
+
+// ---------------------------------------------------------------------------------------------
 // activations
 // ---------------------------------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence `1.0f / x` compiles to:

@@ -51,6 +51,7 @@ struct DwFwdArgs {
   const void* x; const float* w; void* y;
   const float* ss; int act;
   double* stats; double* pool;
+  x3d_bn_fold bn;   // bn.stats != nullptr: scale/shift of the prologue from these statistics (BN finalize folded in)
 };
 struct DwBwdArgs {
   DwGeom g;

@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
     w21[k / 3][k % 3] = (v2f){a.w[c * 27 + 18 + k], a.w[c * 27 + 9 + k]};
     w0[k / 3][k % 3] = a.w[c * 27 + k];
   }
-  const bool affine = a.ss != nullptr;
-  const float sc = affine ? a.ss[c * 2] : 1.f, sh = affine ? a.ss[c * 2 + 1] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (a.bn.stats) bn_fold_channel(a.bn, c, n == 0 && tile == 0 && threadIdx.x == 0, sc, sh);   // BN finalize folded in
+  else if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
   const int act = a.act;
   auto xf = [=](float v) {
     float u = sc * v + sh;
@@ -177,6 +178,8 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   DwFwdArgs a;
   a.x = f->x; a.w = f->w; a.y = f->y; a.ss = f->in_scale_shift; a.act = f->in_act;
   a.stats = f->stats; a.pool = f->pool;
+  memset(&a.bn, 0, sizeof(a.bn));
+  if (f->in_bn) a.bn = *f->in_bn;
   const int Wo = ceil_div(f->W, S);
   const int SW = dw_pick_sw(Wo);
   int bd; size_t ldsf;
@@ -226,6 +229,7 @@ extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {
   X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_fwd: bad extents");
   X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_fwd: bad dtype");
   X3D_REQUIRE(f->in_act == X3D_ACT_NONE || f->in_act == X3D_ACT_RELU, "dw3d_fwd: prologue act must be none/relu");
+  X3D_REQUIRE(!f->in_bn || bn_fold_valid(f->in_bn), "dw3d_fwd: incomplete x3d_bn_fold");
   hipStream_t st = (hipStream_t)stream;
   if (f->dtype == X3D_F32)
     return f->stride == 1 ? dw_fwd_launch<float, 1>(f, st) : dw_fwd_launch<float, 2>(f, st);

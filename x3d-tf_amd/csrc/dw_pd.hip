@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
     w21[k / 3][k % 3] = (v2f){a.w[c * 27 + 18 + k], a.w[c * 27 + 9 + k]};
     w0[k / 3][k % 3] = a.w[c * 27 + k];
   }
-  const bool affine = a.ss != nullptr;
-  const float sc = affine ? a.ss[c * 2] : 1.f, sh = affine ? a.ss[c * 2 + 1] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (a.bn.stats) bn_fold_channel(a.bn, c, n == 0 && tile == 0 && threadIdx.x == 0, sc, sh);   // BN finalize folded in
+  else if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
   const int act = a.act;
   auto xf = [=](float v) {
     float u = sc * v + sh;

@@ -6,28 +6,11 @@
 // ------------------------------------------------------------------------------------------------
 // BN finalize kernels: one thread per channel (C <= a few hundred)
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* mmean, float* mvar, float eps, float momentum, int update,
-                                   float* ss, float* mi, int C) {
+__global__ void bn_finalize_kernel(const x3d_bn_fold f, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = stats[c * 2] / count;
-  double var = stats[c * 2 + 1] / count - mean * mean;  // biased batch variance (Keras, training)
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
-  ss[c * 2] = sc;
-  ss[c * 2 + 1] = beta[c] - (float)mean * sc;
-  mi[c * 2] = (float)mean;
-  mi[c * 2 + 1] = invstd;
-  if (update) {
-    // Keras momentum convention: moving = moving*momentum + batch*(1-momentum); the moving variance
-    // receives the unbiased estimate (TF fused batch norm) [TF-3p]
-    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    mmean[c] = mmean[c] * momentum + (float)mean * (1.f - momentum);
-    mvar[c] = mvar[c] * momentum + (float)unb * (1.f - momentum);
-  }
+  float sc, sh;
+  bn_fold_channel(f, c, true, sc, sh);
 }
 
 __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -69,9 +52,10 @@ extern "C" int x3d_bn_finalize(const double* stats, double count, const float* g
                                void* stream) {
   X3D_REQUIRE(stats && gamma && beta && scale_shift && mean_invstd && C > 0 && count > 0, "bn_finalize: bad args");
   X3D_REQUIRE(!update_moving || (moving_mean && moving_var), "bn_finalize: moving stats required");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, count,
-                     gamma, beta, moving_mean, moving_var, eps, momentum, update_moving, scale_shift,
-                     mean_invstd, C);
+  x3d_bn_fold f;
+  f.stats = stats; f.count = count; f.gamma = gamma; f.beta = beta; f.moving_mean = moving_mean; f.moving_var = moving_var;
+  f.eps = eps; f.momentum = momentum; f.update_moving = update_moving; f.scale_shift = scale_shift; f.mean_invstd = mean_invstd;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, f, C);
   X3D_LAUNCH_CHECK("bn_finalize");
   return X3D_OK;
 }
@@ -126,15 +110,25 @@ static inline dim3 elem_grid(long long P, int vec, int NC) {
   return dim3((unsigned)ceil_div_ll(P, (long long)ELEM_BLOCK * vec * ELEM_ITERS), (unsigned)NC);
 }
 
-template <typename T, int VEC>
+// FOLD: the BatchNorm finalize of bn_c / bn_r runs here (x3d_bn_fold); the first workgroup of each channel of
+// sample 0 publishes the coefficients and updates the moving statistics
+struct TailFold { x3d_bn_fold c, r; int has_r; };
+template <typename T, int VEC, bool FOLD>
 __global__ __launch_bounds__(ELEM_BLOCK) void tail_fwd_kernel(const T* __restrict__ craw,
                                                              const float* __restrict__ ssc,
                                                              const T* __restrict__ sh,
                                                              const float* __restrict__ ssr, T* __restrict__ y,
-                                                             int C, long long P) {
+                                                             int C, long long P, const TailFold fold) {
   const int nc = blockIdx.y, c = nc % C;
-  const float sc = ssc[c * 2], tc = ssc[c * 2 + 1];
-  const float sr = ssr ? ssr[c * 2] : 1.f, tr = ssr ? ssr[c * 2 + 1] : 0.f;
+  float sc, tc, sr = 1.f, tr = 0.f;
+  if constexpr (FOLD) {
+    const bool writer = (nc < C) && blockIdx.x == 0 && threadIdx.x == 0;
+    bn_fold_channel(fold.c, c, writer, sc, tc);
+    if (fold.has_r) bn_fold_channel(fold.r, c, writer, sr, tr);
+  } else {
+    sc = ssc[c * 2]; tc = ssc[c * 2 + 1];
+    if (ssr) { sr = ssr[c * 2]; tr = ssr[c * 2 + 1]; }
+  }
   const long long base = (long long)nc * P;
   long long p = ((long long)blockIdx.x * ELEM_ITERS * ELEM_BLOCK + threadIdx.x) * VEC;
 #pragma unroll
@@ -271,16 +265,45 @@ extern "C" int x3d_tail_fwd(const void* c_raw, const float* c_scale_shift, const
   const int vec = norm_vec(dtype, pick_vec(eb, P, c_raw, shortcut, y));
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = elem_grid(P, vec, N * C);
-#define ARGS(T) (const T*)c_raw, c_scale_shift, (const T*)shortcut, r_scale_shift, (T*)y, C, P
+  TailFold nofold;
+  memset(&nofold, 0, sizeof(nofold));
+#define ARGS(T) (const T*)c_raw, c_scale_shift, (const T*)shortcut, r_scale_shift, (T*)y, C, P, nofold
   if (dtype == X3D_F32) {
-    if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
-    else hipLaunchKernelGGL((tail_fwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((tail_fwd_kernel<float, 1, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
   } else {
-    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
-    else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
   }
 #undef ARGS
   X3D_LAUNCH_CHECK("tail_fwd");
+  return X3D_OK;
+}
+
+extern "C" int x3d_tail_fwd_bn(const void* c_raw, const x3d_bn_fold* c_bn, const void* shortcut, const x3d_bn_fold* r_bn,
+                               void* y, int N, int C, long long P, int dtype, void* stream) {
+  X3D_REQUIRE(c_raw && y && N > 0 && C > 0 && P > 0, "tail_fwd_bn: bad args");
+  X3D_REQUIRE(bn_fold_valid(c_bn), "tail_fwd_bn: incomplete x3d_bn_fold for bn_c");
+  X3D_REQUIRE(!r_bn || (shortcut && bn_fold_valid(r_bn)), "tail_fwd_bn: incomplete x3d_bn_fold for bn_r");
+  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_fwd_bn: bad dtype");
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const int vec = norm_vec(dtype, pick_vec(eb, P, c_raw, shortcut, y));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid = elem_grid(P, vec, N * C);
+  TailFold fold;
+  memset(&fold, 0, sizeof(fold));
+  fold.c = *c_bn;
+  if (r_bn) { fold.r = *r_bn; fold.has_r = 1; }
+#define ARGS(T) (const T*)c_raw, (const float*)nullptr, (const T*)shortcut, (const float*)nullptr, (T*)y, C, P, fold
+  if (dtype == X3D_F32) {
+    if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+    else hipLaunchKernelGGL((tail_fwd_kernel<float, 1, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+    else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
+  }
+#undef ARGS
+  X3D_LAUNCH_CHECK("tail_fwd_bn");
   return X3D_OK;
 }
 

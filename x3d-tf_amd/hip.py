@@ -68,10 +68,15 @@ class PwWgradArgs(C.Structure):
                 ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
 
 
+class BnFold(C.Structure):
+    _fields_ = [("stats", _vp), ("count", _d), ("gamma", _vp), ("beta", _vp), ("moving_mean", _vp), ("moving_var", _vp),
+                ("eps", _f), ("momentum", _f), ("update_moving", _i), ("scale_shift", _vp), ("mean_invstd", _vp)]
+
+
 class Dw3dFwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("in_scale_shift", _vp), ("in_act", _i),
                 ("stats", _vp), ("pool", _vp), ("N", _i), ("C", _i), ("T", _i), ("H", _i), ("W", _i),
-                ("stride", _i), ("dtype", _i)]
+                ("stride", _i), ("dtype", _i), ("in_bn", C.POINTER(BnFold))]
 
 
 class Dw3dBwdArgs(C.Structure):
@@ -112,6 +117,7 @@ _SIGS = {
     "x3d_se_fwd": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_se_bnb_bwd": ([C.POINTER(SeBnbBwdArgs), _vp], _i),
     "x3d_tail_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_tail_fwd_bn": ([_vp, C.POINTER(BnFold), _vp, C.POINTER(BnFold), _vp, _i, _i, _ll, _i, _vp], _i),
     "x3d_tail_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
     "x3d_relu_bn_bwd_reduce": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
     "x3d_pool_fwd": ([_vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),

@@ -3,6 +3,8 @@
 Every function launches hand-written HIP kernels from libx3d_hip.so on the current stream.  Tensors
 are NCTHW activations (fp32 or bf16) and fp32 parameters / coefficient vectors, all on the GPU.
 """
+import ctypes
+
 import torch
 
 from . import hip
@@ -64,6 +66,13 @@ def bn_finalize(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, s
     _chk(stats, gamma, beta, mmean, mvar, ss, mi)
     hip.call("x3d_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar),
              float(eps), float(momentum), int(update), ptr(ss), ptr(mi), gamma.numel())
+
+
+def bn_fold(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, ss, mi):
+    """x3d_bn_fold for a consumer that runs the finalize itself (x3d_dw3d_fwd in_bn / x3d_tail_fwd_bn)."""
+    _chk(stats, gamma, beta, mmean, mvar, ss, mi)
+    return hip.BnFold(ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar), float(eps), float(momentum),
+                      int(update), ptr(ss), ptr(mi))
 
 
 def bn_eval_coef(gamma, beta, mmean, mvar, eps, ss, mi):
@@ -151,14 +160,15 @@ def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, st
 
 
 # ---- depthwise ----------------------------------------------------------------------------------
-def dw3d_fwd(x, w, stride, y=None, in_ss=None, in_act=ACT_NONE, stats=None, pool=None):
+def dw3d_fwd(x, w, stride, y=None, in_ss=None, in_act=ACT_NONE, stats=None, pool=None, in_bn=None):
+    """in_bn: an ops.bn_fold(...) struct -- the prologue's BatchNorm finalize runs inside the kernel (in_ss unused)."""
     _chk(x, w, y, in_ss, stats, pool)
     n, c, t, h, ww = x.shape
     ho, wo = _out_hw(h, ww, stride)
     if y is None:
         y = torch.empty((n, c, t, ho, wo), dtype=x.dtype, device=x.device)
     a = hip.Dw3dFwdArgs(ptr(x), ptr(w), ptr(y), ptr(in_ss), in_act, ptr(stats), ptr(pool), n, c, t, h,
-                        ww, stride, hip.dtype_code(x.dtype))
+                        ww, stride, hip.dtype_code(x.dtype), None if in_bn is None else ctypes.pointer(in_bn))
     hip.call_struct("x3d_dw3d_fwd", a)
     return y
 
@@ -197,6 +207,15 @@ def tail_fwd(c_raw, c_ss, shortcut, r_ss, y):
     n, c = c_raw.shape[:2]
     hip.call("x3d_tail_fwd", ptr(c_raw), ptr(c_ss), ptr(shortcut), ptr(r_ss), ptr(y), n, c,
              c_raw[0, 0].numel(), hip.dtype_code(c_raw.dtype))
+    return y
+
+
+def tail_fwd_bn(c_raw, c_bn, shortcut, r_bn, y):
+    """tail_fwd with the finalize of bn_c (and bn_r) folded in; c_bn / r_bn: ops.bn_fold(...) structs."""
+    _chk(c_raw, shortcut, y)
+    n, c = c_raw.shape[:2]
+    hip.call("x3d_tail_fwd_bn", ptr(c_raw), ctypes.byref(c_bn), ptr(shortcut), None if r_bn is None else ctypes.byref(r_bn),
+             ptr(y), n, c, c_raw[0, 0].numel(), hip.dtype_code(c_raw.dtype))
     return y
 
 
