@@ -2,6 +2,8 @@
 // (0,1,1), Cin=3 -> C1; conv_t = KTx1x1 temporal depthwise conv with pad (KT/2,0,0).  Cin = 3 and
 // K = 27 pad to one 32x32 MFMA tile: bf16 storage runs conv_s forward and its weight gradient on the matrix cores
 // (im2col tile built in LDS from 16-byte loads); fp32 storage and odd widths use the direct kernels.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +538,48 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, c
 }
 
 // backward: dY[t] = A*g[t] + B*yraw[t] + C ; dx[t] = sum_k w[k]*dY[t + R - k] ; dw[k] += sum dY[t]*x[t+k-R]
+// The three planes of step tau+1 are loaded while step tau is computed.  Every global access of the loop is an
+// unconditional bounds-checked buffer instruction (planes past T / steps before the first complete dx: out of range,
+// zero / dropped): the store then never sits behind a conservative vmcnt(0) in front of the prefetched planes
+// (vmcnt retires in order and conditional memory operations cannot be counted).
+typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int stem_u32x2;
+template <typename T, int VEC> struct BufVec {
+  static constexpr int BYTES = VEC * (int)sizeof(T);
+  static_assert(BYTES == 2 || BYTES == 4 || BYTES == 8 || BYTES == 16, "buffer vector of 2 / 4 / 8 / 16 bytes");
+  static constexpr int NW = BYTES >= 4 ? BYTES / 4 : 1;
+  unsigned int w[NW];
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int off) {
+    if constexpr (BYTES == 16) { const stem_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3]; }
+    else if constexpr (BYTES == 8) { const stem_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0); w[0] = v[0]; w[1] = v[1]; }
+    else if constexpr (BYTES == 4) w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+    else w[0] = __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0);
+  }
+  __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int off) const {
+    if constexpr (BYTES == 16) { const stem_u32x4 v = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
+    else if constexpr (BYTES == 8) { const stem_u32x2 v = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
+    else if constexpr (BYTES == 4) __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w[0], rs, off, 0, 0);
+  }
+  __device__ __forceinline__ float get(int e) const {
+    if constexpr (sizeof(T) == 4) return __uint_as_float(w[e]);
+    else return __uint_as_float(((w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
+  }
+  __device__ __forceinline__ void set(const float (&v)[VEC]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) w[e] = __float_as_uint(v[e]);
+    } else if constexpr (VEC == 1) {
+      w[0] = (unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[0]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC / 2; e++)
+        w[e] = (unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[2 * e]) |
+               ((unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[2 * e + 1]) << 16);
+    }
+  }
+};
+
 template <typename T, int VEC, int KT>
 __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ yraw,
                                                       const float* __restrict__ coef, const T* __restrict__ x,
@@ -545,52 +589,64 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, c
   const int nc = blockIdx.y, c = nc % C;
   const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   constexpr int R = KT / 2;
+  constexpr int OOB = 0x40000000;
   float wk[KT], dwk[KT];
 #pragma unroll
   for (int k = 0; k < KT; k++) { wk[k] = w[c * KT + k]; dwk[k] = 0.f; }
   const float A = coef[c * 4], B = coef[c * 4 + 1], Cc = coef[c * 4 + 2];
-  if (q < HW) {
-    const long long base = (long long)nc * Tn * HW + q;
-    // step tau brings in dY[tau] and x[tau]; then dx[tau-R] = sum_k w[k]*dY[tau-k] is complete and
-    // dY[tau-R] meets its whole x window x[tau-2R .. tau].
-    float dwin[KT][VEC], xwin[KT][VEC];  // dwin[k] = dY[tau - (KT-1) + k], same for xwin
+  // one (n, c) slab of T planes per resource: < 2^30 bytes (host check)
+  const long long slab = (long long)nc * Tn * HW;
+  const int slab_bytes = (int)(Tn * HW * (long long)sizeof(T)), plane_bytes = (int)(HW * (long long)sizeof(T));
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((T*)g + slab, 0, slab_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((T*)yraw + slab, 0, slab_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((T*)x + slab, 0, slab_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dx + slab, 0, slab_bytes, 0x00020000);
+  const bool live = q < HW;
+  const int qoff = live ? (int)(q * (long long)sizeof(T)) : OOB;
+  // step tau brings in dY[tau] and x[tau]; then dx[tau-R] = sum_k w[k]*dY[tau-k] is complete and
+  // dY[tau-R] meets its whole x window x[tau-2R .. tau].
+  float dwin[KT][VEC], xwin[KT][VEC];  // dwin[k] = dY[tau - (KT-1) + k], same for xwin
 #pragma unroll
-    for (int k = 0; k < KT; k++)
+  for (int k = 0; k < KT; k++)
 #pragma unroll
-      for (int e = 0; e < VEC; e++) { dwin[k][e] = 0.f; xwin[k][e] = 0.f; }
-    for (int tau = 0; tau < Tn + R; tau++) {
+    for (int e = 0; e < VEC; e++) { dwin[k][e] = 0.f; xwin[k][e] = 0.f; }
+  BufVec<T, VEC> bg, by, bx;
+  bg.load(rg, qoff); by.load(ry, qoff); bx.load(rx, qoff);
+  {  // a dropped store behind the first prefetch, as in every iteration of the loop
+    BufVec<T, VEC> z;
 #pragma unroll
-      for (int k = 0; k < KT - 1; k++)
+    for (int i = 0; i < BufVec<T, VEC>::NW; i++) z.w[i] = 0u;
+    z.store(rd, OOB);
+  }
+  for (int tau = 0; tau < Tn + R; tau++) {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) { dwin[k][e] = dwin[k + 1][e]; xwin[k][e] = xwin[k + 1][e]; }
-      if (tau < Tn) {
-        float gg[VEC], yy[VEC];
-        VecIO<T, VEC>::load(g + base + (long long)tau * HW, gg);
-        VecIO<T, VEC>::load(yraw + base + (long long)tau * HW, yy);
-        VecIO<T, VEC>::load(x + base + (long long)tau * HW, xwin[KT - 1]);
+    for (int k = 0; k < KT - 1; k++)
 #pragma unroll
-        for (int e = 0; e < VEC; e++) dwin[KT - 1][e] = A * gg[e] + B * yy[e] + Cc;
-      } else {
+      for (int e = 0; e < VEC; e++) { dwin[k][e] = dwin[k + 1][e]; xwin[k][e] = xwin[k + 1][e]; }
+    const bool in = live && tau < Tn;   // past T the loads returned zeros: dY must be 0 there, not C
 #pragma unroll
-        for (int e = 0; e < VEC; e++) { dwin[KT - 1][e] = 0.f; xwin[KT - 1][e] = 0.f; }
-      }
-      const int t = tau - R;
-      if (t >= 0) {
-        float o[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; e++) {
-          float acc = 0.f;
-          // dx[t] = sum_k w[k]*dY[t+R-k] = sum_k w[k]*dwin[KT-1-k]
-#pragma unroll
-          for (int k = 0; k < KT; k++) acc += wk[k] * dwin[KT - 1 - k][e];
-          o[e] = acc;
-          // dY[t] = dwin[KT-1-R]; x[t+k-R] = xwin[KT-1-2R+k] = xwin[k]
-#pragma unroll
-          for (int k = 0; k < KT; k++) dwk[k] += dwin[KT - 1 - R][e] * xwin[k][e];
-        }
-        VecIO<T, VEC>::store(dx + base + (long long)t * HW, o);
-      }
+    for (int e = 0; e < VEC; e++) {
+      dwin[KT - 1][e] = in ? A * bg.get(e) + B * by.get(e) + Cc : 0.f;
+      xwin[KT - 1][e] = bx.get(e);
     }
+    const int noff = qoff + (tau + 1) * plane_bytes;   // tau + 1 >= Tn: past the slab -> zeros, no traffic
+    bg.load(rg, noff); by.load(ry, noff); bx.load(rx, noff);
+    const int t = tau - R;
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float acc = 0.f;
+      // dx[t] = sum_k w[k]*dY[t+R-k] = sum_k w[k]*dwin[KT-1-k]
+#pragma unroll
+      for (int k = 0; k < KT; k++) acc += wk[k] * dwin[KT - 1 - k][e];
+      o[e] = acc;
+      // dY[t] = dwin[KT-1-R]; x[t+k-R] = xwin[KT-1-2R+k] = xwin[k]   (t < 0: dwin[KT-1-R] is still zero)
+#pragma unroll
+      for (int k = 0; k < KT; k++) dwk[k] += dwin[KT - 1 - R][e] * xwin[k][e];
+    }
+    BufVec<T, VEC> ob;
+    ob.set(o);
+    ob.store(rd, t >= 0 ? qoff + t * plane_bytes : OOB);
   }
   block_sum<KT>(dwk, scratch);
   if (threadIdx.x == 0) {
@@ -651,10 +707,15 @@ extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, c
   X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "dwt_bwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int eb = dtype == X3D_F32 ? 4 : 2;
+  X3D_REQUIRE((long long)T * HW * eb < (1ll << 30), "dwt_bwd: one channel slab exceeds the 1 GB buffer window");
   const int vec = pick_vec(eb, HW, g, yraw, x, dx);
+  static const char* vec_env = getenv("X3D_DWT_BWD_VEC");   // experiment hook: elements per thread (bf16: 2 or 4)
+  const int want = vec_env ? atoi(vec_env) : 4;
   if (dtype == X3D_F32)
     return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
                     : dwt_bwd_kt<float, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  if (vec >= 8 && want >= 8) return dwt_bwd_kt<bf16, 8>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  if (vec >= 4 && want >= 4) return dwt_bwd_kt<bf16, 4>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
   return vec >= 2 ? dwt_bwd_kt<bf16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
                   : dwt_bwd_kt<bf16, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
 }
