@@ -410,6 +410,13 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
   const size_t lds = (size_t)(MG + NG) * 32 * (2 * 64 + 8) * 2;
   auto kern = pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+  }
   // one balanced round: as many workgroups as the chip holds at once (occupancy x CUs), the 64-point steps split
   // evenly among them.  A fixed steps-per-block left e.g. 1568 workgroups on 1280 slots: a second round at 22 %.
   static int slots = 0;
@@ -436,6 +443,13 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   // X rows may carry the swish prologue: prefer few M-groups (each re-stages every X row of its N-group)
   const int MG = mt >= 3 ? 4 : mt, NG = nt >= 2 ? 2 : 1;
+  if constexpr (STRIDED == 0) {
+    // experiment hook X3D_PW_WG_NG4=1: 128 x 128 tiles for the wide layers (stage 5: 192 x 432) halve the re-reads of
+    // every dY / X row by the other tile groups, but need 232-252 VGPRs + 64 AGPRs (one workgroup per CU):
+    // measured slower (80 -> 100 us), so 128 x 64 stays the default
+    static const char* e = getenv("X3D_PW_WG_NG4");
+    if (MG == 4 && nt >= 4 && e && atoi(e) == 1) return pw_wgrad_v2_launch<4, 4, XPRO, STRIDED>(a, st);
+  }
   if (MG == 1) return NG == 1 ? pw_wgrad_v2_launch<1, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<1, 2, XPRO, STRIDED>(a, st);
   if (MG == 2) return NG == 1 ? pw_wgrad_v2_launch<2, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<2, 2, XPRO, STRIDED>(a, st);
   return NG == 1 ? pw_wgrad_v2_launch<4, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<4, 2, XPRO, STRIDED>(a, st);
