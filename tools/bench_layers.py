@@ -99,6 +99,10 @@ def main():
     for lname, i, name, desc, us, by in rows:
         if by:
             print(f"{lname} {i:4d} {name:14s} {desc:34s} {us:9.1f} us {by / 1e6:9.1f} MB {by / (us * 1e-6) / 1e9:8.1f} GB/s")
+    print("# per launch (other kernels above 25 us)")
+    for lname, i, name, desc, us, by in rows:
+        if not by and us > 25.0:
+            print(f"{lname} {i:4d} {name:24s} {us:9.1f} us")
 
 
 if __name__ == "__main__":

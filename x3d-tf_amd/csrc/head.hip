@@ -3,91 +3,200 @@
 #include "common.h"
 
 // y[n][m] = act(sum_k xm[n][k]*w[m][k] + b[m]), xm = x * (mask ? mask*mask_scale : 1).
-// One wave per output feature m and tile of NTILE samples: lanes split K, coalesced on w[m][:] and x[n][:].
+// One wave per DENSE_MT output features and DENSE_NT samples: lanes split K, coalesced on w[m][:] and x[n][:].
+// The x rows are the traffic (every feature block re-reads them from L2: M/MT * N * K floats), so a wave keeps
+// MT features: with one feature per wave fc2 (2048 -> 400, 64 samples) moved 210 MB through L1 in 105 us.
 #define DENSE_NT 8
+#define DENSE_MT 4
 __global__ __launch_bounds__(64) void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                        float mask_scale, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* y, int act, int N, int K,
                                                        int M) {
-  const int m = blockIdx.x, n0 = blockIdx.y * DENSE_NT, lane = threadIdx.x;
-  float acc[DENSE_NT];
+  const int m0 = blockIdx.x * DENSE_MT, n0 = blockIdx.y * DENSE_NT, lane = threadIdx.x;
+  float acc[DENSE_MT][DENSE_NT];
 #pragma unroll
-  for (int i = 0; i < DENSE_NT; i++) acc[i] = 0.f;
-#pragma unroll 4
-  for (int k = lane; k < K; k += 64) {
-    const float wv = w[(long long)m * K + k];
+  for (int j = 0; j < DENSE_MT; j++)
 #pragma unroll
-    for (int i = 0; i < DENSE_NT; i++) {
-      const int n = n0 + i;
-      if (n < N) {
-        float xv = x[(long long)n * K + k];
-        if (mask) xv *= mask[(long long)n * K + k] * mask_scale;
-        acc[i] += wv * xv;
-      }
-    }
-  }
+    for (int i = 0; i < DENSE_NT; i++) acc[j][i] = 0.f;
+  // rows past M / N are clamped (computed twice, never stored): every load of the loop is unconditional, so the
+  // MT + NT (+ NT mask) loads of an iteration are in flight together instead of one branch at a time
+  const float* wr[DENSE_MT];
+  const float* xr[DENSE_NT];
+  const float* mr[DENSE_NT];
+#pragma unroll
+  for (int j = 0; j < DENSE_MT; j++) wr[j] = w + (long long)min(m0 + j, M - 1) * K;
 #pragma unroll
   for (int i = 0; i < DENSE_NT; i++) {
-    const float s = wave_sum(acc[i]);
-    const int n = n0 + i;
-    if (lane == 0 && n < N) {
-      float v = s + (b ? b[m] : 0.f);
-      if (act == X3D_ACT_RELU) v = fmaxf(v, 0.f);
-      y[(long long)n * M + m] = v;
+    xr[i] = x + (long long)min(n0 + i, N - 1) * K;
+    mr[i] = mask ? mask + (long long)min(n0 + i, N - 1) * K : nullptr;
+  }
+  if (mask) {
+#pragma unroll 2
+    for (int k = lane; k < K; k += 64) {
+      float wv[DENSE_MT], xv[DENSE_NT], mv[DENSE_NT];
+#pragma unroll
+      for (int j = 0; j < DENSE_MT; j++) wv[j] = wr[j][k];
+#pragma unroll
+      for (int i = 0; i < DENSE_NT; i++) { xv[i] = xr[i][k]; mv[i] = mr[i][k]; }
+#pragma unroll
+      for (int i = 0; i < DENSE_NT; i++) xv[i] *= mv[i] * mask_scale;
+#pragma unroll
+      for (int j = 0; j < DENSE_MT; j++)
+#pragma unroll
+        for (int i = 0; i < DENSE_NT; i++) acc[j][i] += wv[j] * xv[i];
+    }
+  } else {
+#pragma unroll 2
+    for (int k = lane; k < K; k += 64) {
+      float wv[DENSE_MT], xv[DENSE_NT];
+#pragma unroll
+      for (int j = 0; j < DENSE_MT; j++) wv[j] = wr[j][k];
+#pragma unroll
+      for (int i = 0; i < DENSE_NT; i++) xv[i] = xr[i][k];
+#pragma unroll
+      for (int j = 0; j < DENSE_MT; j++)
+#pragma unroll
+        for (int i = 0; i < DENSE_NT; i++) acc[j][i] += wv[j] * xv[i];
     }
   }
+#pragma unroll
+  for (int j = 0; j < DENSE_MT; j++)
+#pragma unroll
+    for (int i = 0; i < DENSE_NT; i++) {
+      const float s = wave_sum(acc[j][i]);
+      const int n = n0 + i, m = m0 + j;
+      if (lane == 0 && n < N && m < M) {
+        float v = s + (b ? b[m] : 0.f);
+        if (act == X3D_ACT_RELU) v = fmaxf(v, 0.f);
+        y[(long long)n * M + m] = v;
+      }
+    }
 }
 
-// dx[n][k] = (sum_m dz[n][m]*w[m][k]) * (mask ? mask*scale : 1); dz = dy*[y>0] for ReLU
+// dx[n][k] = (sum_m dz[n][m]*w[m][k]) * (mask ? mask*scale : 1); dz = dy*[y>0] for ReLU.
+// A workgroup owns 64 inputs k (the lanes) and DENSE_BN samples; its four waves split M (the long, latency-bound
+// loop: 2048 features for fc1) and meet in LDS.  w[m][k] is read once per DENSE_BN samples.
+#define DENSE_BN 4
 __global__ __launch_bounds__(256) void dense_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            int act, const float* __restrict__ mask, float mask_scale,
                                                            const float* __restrict__ w, float* dx, int N, int K, int M) {
-  extern __shared__ float dz[];  // [M]
-  const int n = blockIdx.y;
-  for (int m = threadIdx.x; m < M; m += 256) {
-    float d = dy[(long long)n * M + m];
-    if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
-    dz[m] = d;
+  extern __shared__ float dz[];  // [DENSE_BN][M], then the partial sums [4 waves][DENSE_BN][64]
+  const int n0 = blockIdx.y * DENSE_BN;
+  for (int i = threadIdx.x; i < DENSE_BN * M; i += 256) {
+    const int nn = i / M, m = i - nn * M, n = n0 + nn;
+    float d = 0.f;
+    if (n < N) {
+      d = dy[(long long)n * M + m];
+      if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
+    }
+    dz[i] = d;
   }
   __syncthreads();
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  float acc = 0.f;
-#pragma unroll 16
-  for (int m = 0; m < M; m++) acc += dz[m] * w[(long long)m * K + k];   // 16 independent loads in flight
-  if (mask) acc *= mask[(long long)n * K + k] * mask_scale;
-  dx[(long long)n * K + k] = acc;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int kc = k < K ? k : K - 1;   // clamped: every lane loads, only k < K is stored
+  float acc[DENSE_BN];
+#pragma unroll
+  for (int i = 0; i < DENSE_BN; i++) acc[i] = 0.f;
+  // batches of 16 loads issued together (written out: left to the unroller, every load was followed by vmcnt(0))
+  constexpr int DXB = 16;
+  int m = wid;
+  for (; m + 4 * (DXB - 1) < M; m += 4 * DXB) {
+    float wv[DXB];
+#pragma unroll
+    for (int j = 0; j < DXB; j++) wv[j] = w[(long long)(m + 4 * j) * K + kc];
+#pragma unroll
+    for (int j = 0; j < DXB; j++)
+#pragma unroll
+      for (int i = 0; i < DENSE_BN; i++) acc[i] += dz[i * M + m + 4 * j] * wv[j];   // dz: LDS broadcast reads
+  }
+  for (; m < M; m += 4) {
+    const float wv = w[(long long)m * K + kc];
+#pragma unroll
+    for (int i = 0; i < DENSE_BN; i++) acc[i] += dz[i * M + m] * wv;
+  }
+  __syncthreads();   // everyone is done with dz
+#pragma unroll
+  for (int i = 0; i < DENSE_BN; i++) dz[(wid * DENSE_BN + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (wid == 0 && k < K) {
+#pragma unroll
+    for (int i = 0; i < DENSE_BN; i++) {
+      const int n = n0 + i;
+      if (n < N) {
+        float v = dz[i * 64 + lane] + dz[(DENSE_BN + i) * 64 + lane] + dz[(2 * DENSE_BN + i) * 64 + lane] +
+                  dz[(3 * DENSE_BN + i) * 64 + lane];
+        if (mask) v *= mask[(long long)n * K + k] * mask_scale;
+        dx[(long long)n * K + k] = v;
+      }
+    }
+  }
 }
 
-// dw[m][k] += sum_n dz[n][m]*xm[n][k] ; db[m] += sum_n dz[n][m]
+// dw[m][k] += sum_n dz[n][m]*xm[n][k] ; db[m] += sum_n dz[n][m].
+// A workgroup owns 256 inputs k and DENSE_BM features: xm[n][k] is read once per DENSE_BM features.
+#define DENSE_BM 8
 __global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            int act, const float* __restrict__ x,
                                                            const float* __restrict__ mask, float mask_scale, float* dw,
                                                            float* db, int N, int K, int M) {
-  const int m = blockIdx.y;
+  extern __shared__ float dzs[];   // [N rounded up to 8][DENSE_BM]: dz of this workgroup's features, ReLU mask applied, 0 past N
+  const int m0 = blockIdx.y * DENSE_BM;
+  const int Np = (N + 7) & ~7;
+  for (int i = threadIdx.x; i < Np * DENSE_BM; i += 256) {
+    const int n = i / DENSE_BM, m = m0 + (i - n * DENSE_BM);
+    float d = 0.f;
+    if (m < M && n < N) {
+      d = dy[(long long)n * M + m];
+      if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
+    }
+    dzs[i] = d;
+  }
+  __syncthreads();
   const int k = blockIdx.x * 256 + threadIdx.x;
-  float acc = 0.f, accb = 0.f;
-#pragma unroll 8
-  for (int n = 0; n < N; n++) {
-    float d = dy[(long long)n * M + m];
-    if (act == X3D_ACT_RELU && !(y[(long long)n * M + m] > 0.f)) d = 0.f;
-    accb += d;
-    if (k < K) {
-      float xv = x[(long long)n * K + k];
-      if (mask) xv *= mask[(long long)n * K + k] * mask_scale;
-      acc += d * xv;
+  const int kc = k < K ? k : K - 1;   // clamped: every lane loads (unconditional, 8 samples in flight), only k < K is stored
+  float acc[DENSE_BM], accb[DENSE_BM];
+#pragma unroll
+  for (int j = 0; j < DENSE_BM; j++) { acc[j] = 0.f; accb[j] = 0.f; }
+  // samples in batches of 8 with the loads written out first (left to the unroller, the masked variant waited for
+  // every load separately); rows past N are clamped and weighted by dz = 0
+  constexpr int DWB = 8;
+  for (int nb = 0; nb < N; nb += DWB) {
+    float xv[DWB], mv[DWB];
+#pragma unroll
+    for (int u = 0; u < DWB; u++) xv[u] = x[(long long)min(nb + u, N - 1) * K + kc];
+    if (mask) {
+#pragma unroll
+      for (int u = 0; u < DWB; u++) mv[u] = mask[(long long)min(nb + u, N - 1) * K + kc];
+#pragma unroll
+      for (int u = 0; u < DWB; u++) xv[u] *= mv[u] * mask_scale;
+    }
+#pragma unroll
+    for (int u = 0; u < DWB; u++) {
+      const f32x4 d0 = *(const f32x4*)&dzs[(nb + u) * DENSE_BM], d1 = *(const f32x4*)&dzs[(nb + u) * DENSE_BM + 4];   // LDS broadcast
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        accb[j] += d0[j]; acc[j] += d0[j] * xv[u];
+        accb[4 + j] += d1[j]; acc[4 + j] += d1[j] * xv[u];
+      }
     }
   }
-  if (k < K) dw[(long long)m * K + k] += acc;
-  if (db && blockIdx.x == 0 && threadIdx.x == 0) db[m] += accb;
+#pragma unroll
+  for (int j = 0; j < DENSE_BM; j++) {
+    const int m = m0 + j;
+    if (m < M) {
+      if (k < K) dw[(long long)m * K + k] += acc[j];
+      if (db && blockIdx.x == 0 && threadIdx.x == 0) db[m] += accb[j];
+    }
+  }
 }
 
 extern "C" int x3d_dense_fwd(const float* x, const float* mask, float mask_scale, const float* w, const float* b,
                              float* y, int act, int N, int K, int M, void* stream) {
   X3D_REQUIRE(x && w && y && N > 0 && K > 0 && M > 0, "dense_fwd: bad args");
   X3D_REQUIRE(act == X3D_ACT_NONE || act == X3D_ACT_RELU, "dense_fwd: act must be none/relu");
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3(M, ceil_div(N, DENSE_NT)), dim3(64), 0, (hipStream_t)stream, x, mask,
-                     mask_scale, w, b, y, act, N, K, M);
+  hipLaunchKernelGGL(dense_fwd_kernel, dim3(ceil_div(M, DENSE_MT), ceil_div(N, DENSE_NT)), dim3(64), 0, (hipStream_t)stream,
+                     x, mask, mask_scale, w, b, y, act, N, K, M);
   X3D_LAUNCH_CHECK("dense_fwd");
   return X3D_OK;
 }
@@ -97,15 +206,17 @@ extern "C" int x3d_dense_bwd(const float* dy, const float* y, int act, const flo
                              void* stream) {
   X3D_REQUIRE(dy && x && w && dw && N > 0 && K > 0 && M > 0, "dense_bwd: bad args");
   X3D_REQUIRE(act == X3D_ACT_NONE || (act == X3D_ACT_RELU && y), "dense_bwd: relu needs y");
-  X3D_REQUIRE((size_t)M * sizeof(float) <= 48 * 1024, "dense_bwd: M too large");
+  const size_t dz_bytes = (size_t)DENSE_BN * (M > 256 ? M : 256) * sizeof(float);   // >= the [4][DENSE_BN][64] partial sums
+  X3D_REQUIRE(dz_bytes <= 64 * 1024, "dense_bwd: M too large");
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL(dense_bwd_dx_kernel, dim3(ceil_div(K, 256), N), dim3(256), M * sizeof(float), st, dy, y, act,
+    hipLaunchKernelGGL(dense_bwd_dx_kernel, dim3(ceil_div(K, 64), ceil_div(N, DENSE_BN)), dim3(256), dz_bytes, st, dy, y, act,
                        mask, mask_scale, w, dx, N, K, M);
     X3D_LAUNCH_CHECK("dense_bwd_dx");
   }
-  hipLaunchKernelGGL(dense_bwd_dw_kernel, dim3(ceil_div(K, 256), M), dim3(256), 0, st, dy, y, act, x, mask,
-                     mask_scale, dw, db, N, K, M);
+  const size_t dzs_bytes = (size_t)((N + 7) & ~7) * DENSE_BM * sizeof(float);
+  X3D_REQUIRE(dzs_bytes <= 64 * 1024, "dense_bwd: N too large");
+  hipLaunchKernelGGL(dense_bwd_dw_kernel, dim3(ceil_div(K, 256), ceil_div(M, DENSE_BM)), dim3(256), dzs_bytes, st, dy, y, act, x, mask, mask_scale, dw, db, N, K, M);
   X3D_LAUNCH_CHECK("dense_bwd_dw");
   return X3D_OK;
 }
