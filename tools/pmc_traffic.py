@@ -14,7 +14,7 @@ import re
 import sys
 
 
-_DW = re.compile(r"_Z\d+(dw3d_(?:fwd|bwd)(?:_pd)?_kernel)I(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE")
+_DW = re.compile(r"_Z\d+(dw3d_(?:fwd|bwd)(?:_pd)?(?:_s1)?_kernel)I(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE")
 
 
 def canonical(name):

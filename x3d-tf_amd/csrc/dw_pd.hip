@@ -416,6 +416,245 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
   }
 }
 
+// ---- stride-1 variant with register ROLES (see the comment at the accumulators) ----
+template <typename T, int SW, int CV, int PD, int UN>
+__global__ __launch_bounds__(256, (BwdPdWaves<1, SW, CV>::v)) void dw3d_bwd_pd_s1_kernel(const DwBwdArgs a) {
+  constexpr int S = 1;
+  static_assert(UN % 6 == 0 && UN % PD == 0, "roles have periods 2 (windows) and 3 (planes); slots period PD");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwGeom& g = a.g;
+  constexpr int WIN = (SW - 1) * S + 3;          // act window columns
+  constexpr int BW = (S == 1) ? SW + 2 : SW + 1; // dB window columns
+  constexpr int BR = (S == 1) ? 3 : 2;           // dB window rows
+  constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
+  constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
+  constexpr bool DEFER = (S == 1);               // emit a finished dA plane one iteration late (register budget, see dw_bwd.hip)
+  constexpr int VA = CV, VB = (S == 1) ? CV : (CV > 1 ? CV / 2 : 1);
+  constexpr int EB = (int)sizeof(T);
+  const int aplane = g.RIN * g.LP;
+  const int bplane = a.RB * a.LPB;
+  float* Al = lds;
+  float* Bl = lds + aplane;
+  float* scratch = Bl + bplane;
+
+  int b = blockIdx.x;
+  const int tile = b % g.ntile_h; b /= g.ntile_h;
+  const int c = b % g.C;
+  const int n = b / g.C;
+  const int h0 = tile * g.TH;
+  const int th_here = min(g.TH, g.Ho - h0);
+  const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
+  const bool active = r < th_here;
+  const int ho = h0 + r, wo0 = sidx * SW;
+
+  for (int i = threadIdx.x; i < aplane + bplane; i += blockDim.x) lds[i] = 0.f;
+
+  float wgt[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
+  const float* cf = a.coef_nc + ((long long)n * g.C + c) * 4;
+  const float cA = cf[0], cB = cf[1], cC = cf[2];
+  auto af = [=](float v) { return fmaxf(sc * v + sh, 0.f); };
+  auto bf = [=](float dvv, float bv) { return cA * dvv + cB * bv + cC; };
+
+  const int iplB = g.H * g.W * EB, oplB = g.Ho * g.Wo * EB;
+  const long long chan = (long long)n * g.C + c;
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((T*)a.araw + chan * g.T * g.H * g.W, 0, g.T * iplB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG =
+      __builtin_amdgcn_make_buffer_rsrc((T*)a.ga + chan * g.T * g.H * g.W, 0, g.T * iplB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD =
+      __builtin_amdgcn_make_buffer_rsrc((T*)a.dv + chan * g.T * g.Ho * g.Wo, 0, g.T * oplB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR =
+      __builtin_amdgcn_make_buffer_rsrc((T*)a.braw + chan * g.T * g.Ho * g.Wo, 0, g.T * oplB, 0x00020000);
+  const int rowA0 = h0 * S - g.ph;
+
+  // staging maps: ONE vector per thread and tensor (host guarantees it)
+  int gA = DW_OOB, lA = 0, gB = DW_OOB, lB = 0;
+  bool okA = false, okB = false;
+  {
+    const int nvr = g.W / VA, v = threadIdx.x;
+    if (v < g.RIN * nvr) {
+      const int lr = v / nvr, jv = v - lr * nvr, hi = rowA0 + lr;
+      if (hi >= 0 && hi < g.H) { okA = true; gA = (hi * g.W + jv * VA) * EB; lA = lr * g.LP + g.pw + jv * VA; }
+    }
+  }
+  {  // dB plane: lds row 0 <-> output row h0-1, col 0 <-> col -1
+    const int nvr = g.Wo / VB, v = threadIdx.x;
+    if (v < a.RB * nvr) {
+      const int lr = v / nvr, jv = v - lr * nvr, hi = h0 - 1 + lr;
+      if (hi >= 0 && hi < g.Ho) { okB = true; gB = (hi * g.Wo + jv * VB) * EB; lB = lr * a.LPB + 1 + jv * VB; }
+    }
+  }
+  // image rows / cols owned for dA (NA contiguous, NA-aligned columns per row: host checks W % NA == 0, pw == 0 for S == 2)
+  const int hA = (S == 1) ? ho : ho * 2 - g.ph;
+  const int wA0 = (S == 1) ? wo0 : wo0 * 2 - g.pw;
+  int oOwn[NR];
+  bool okOwn[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int h = hA + q;
+    okOwn[q] = active && h >= 0 && h < g.H;
+    oOwn[q] = okOwn[q] ? (h * g.W + wA0) * EB : DW_OOB;
+  }
+
+  struct Slot { Raw A, D, R, O[NR]; };
+  Slot slot[PD];
+  auto issue = [&](int t, Slot& s) {
+    raw_bload<VA * EB>(s.A, rsA, gA + t * iplB, 0);
+    raw_bload<VB * EB>(s.D, rsD, gB + t * oplB, 0);
+    raw_bload<VB * EB>(s.R, rsR, gB + t * oplB, 0);
+#pragma unroll
+    for (int q = 0; q < NR; q++) raw_bload<NA * EB>(s.O[q], rsA, oOwn[q] + t * iplB, 0);
+  };
+
+  // Registers with ROLES instead of copies: the T loop is unrolled by UN (a multiple of 6), so which register set is
+  // "the previous plane's window" (period 2) and which accumulator is "plane t-1 / t / t+1" (period 3) are compile-time
+  // facts of each unrolled iteration -- the ~20 v_mov per plane of the copying form (window -> previous window,
+  // dA1 -> dA0, dA2 -> dA1, dA0 -> fin) disappear.  Slots: plane t sits in slot t % PD.
+  float dAr[3][SW];            // dAr[p % 3] = gradient plane p while it is being accumulated / waiting for its emit
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int i = 0; i < SW; i++) dAr[k][i] = 0.f;
+  float dW[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) dW[k] = 0.f;
+  float winA2[2][3][WIN], dBs[2][SW];   // [t % 2]: this plane's act window / own dB strip; [1 - t % 2]: the previous plane's
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+      for (int j = 0; j < WIN; j++) winA2[k][kh][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SW; i++) dBs[k][i] = 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  Raw own1, own2;   // araw strips of planes t-1 / t-2 (the slot itself is refilled right after staging)
+  own1.w[0] = own1.w[1] = own1.w[2] = own1.w[3] = 0u;
+  own2 = own1;
+
+  auto emit = [&](int t, bool live, const float (&v)[SW], const Raw& own) {   // !live: nothing stored / summed
+    float gv[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) {
+      const float av = raw_get<T>(own, i);
+      gv[i] = (live && okOwn[0] && sc * av + sh > 0.f) ? v[i] : 0.f;
+      s1 += gv[i];
+      s2 += gv[i] * av;
+    }
+    Raw o;
+    raw_pack<T, SW>(o, gv);
+    raw_bstore<SW * EB>(o, rsG, live ? oOwn[0] + t * iplB : DW_OOB, 0);
+  };
+
+  // prologue: the same load / store sequence as a steady-state iteration (stores dropped)
+#pragma unroll
+  for (int d = 0; d < PD; d++) {
+    issue(d, slot[d]);
+    Raw z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+    raw_bstore<SW * EB>(z, rsG, DW_OOB, 0);
+  }
+
+  for (int t0 = 0; t0 < g.T; t0 += UN) {
+#pragma unroll
+    for (int d = 0; d < UN; d++) {
+      const int t = t0 + d;
+      if (t >= g.T) break;
+      const int sl = d % PD, cur = d & 1, prv = cur ^ 1;           // compile-time after unrolling (t0 % UN == 0)
+      const int pm1 = (d + 2) % 3, p0 = d % 3, pp1 = (d + 1) % 3;  // accumulators of planes t-1, t, t+1
+      __syncthreads();
+      if (okA) {
+        float* dst = Al + lA;
+#pragma unroll
+        for (int e = 0; e < VA; e++) dst[e] = af(raw_get<T>(slot[sl].A, e));
+      }
+      if (okB) {
+        float* dst = Bl + lB;
+#pragma unroll
+        for (int e = 0; e < VB; e++) dst[e] = bf(raw_get<T>(slot[sl].D, e), raw_get<T>(slot[sl].R, e));
+      }
+      const Raw own0 = slot[sl].O[0];
+      __syncthreads();
+      issue(t + PD, slot[sl]);
+      // plane t-2 was completed at the end of iteration t-1; it lives in the accumulator that plane t+1 takes over now
+      emit(t - 2, t >= 2, dAr[pp1], own2);
+#pragma unroll
+      for (int i = 0; i < SW; i++) dAr[pp1][i] = 0.f;
+      if (active) {
+        float winB[BR][BW];
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+          const float* row = Al + (r + kh) * g.LP + wo0;
+          lds_window<WIN, (SW >= 4 ? 4 : SW)>(row, winA2[cur][kh]);
+        }
+#pragma unroll
+        for (int q = 0; q < BR; q++) {
+          const float* row = Bl + (r + q) * a.LPB + wo0;
+          lds_window<BW, (SW >= 4 ? 4 : SW)>(row, winB[q]);
+        }
+#pragma unroll
+        for (int i = 0; i < SW; i++) dBs[cur][i] = winB[1][i + 1];
+
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+              dW[9 + kh * 3 + kw] += dBs[cur][i] * winA2[cur][kh][i + kw];
+              dW[18 + kh * 3 + kw] += dBs[prv][i] * winA2[cur][kh][i + kw];
+              dW[kh * 3 + kw] += dBs[cur][i] * winA2[prv][kh][i + kw];
+            }
+          }
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+              const float v = winB[2 - kh][i + 2 - kw];
+              dAr[pm1][i] += wgt[kh * 3 + kw] * v;
+              dAr[p0][i] += wgt[9 + kh * 3 + kw] * v;
+              dAr[pp1][i] += wgt[18 + kh * 3 + kw] * v;
+            }
+      }
+      own2 = own1;
+      own1 = own0;
+    }
+  }
+  // after the loop (T planes staged): plane T-2 waits in dAr[(T-2) % 3] with its strip in own2, plane T-1 in dAr[(T-1) % 3] / own1
+  {
+    const int m2 = (g.T + 1) % 3, m1 = (g.T + 2) % 3;   // (T-2) % 3, (T-1) % 3 for T >= 1
+    float v2[SW], v1[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) {
+      v2[i] = m2 == 0 ? dAr[0][i] : (m2 == 1 ? dAr[1][i] : dAr[2][i]);
+      v1[i] = m1 == 0 ? dAr[0][i] : (m1 == 1 ? dAr[1][i] : dAr[2][i]);
+    }
+    emit(g.T - 2, g.T >= 2, v2, own2);
+    emit(g.T - 1, true, v1, own1);
+  }
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float red[29];
+#pragma unroll
+  for (int k = 0; k < 29; k++) red[k] = wave_sum_lane63(k < 27 ? dW[k] : (k == 27 ? s1 : s2));
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 29; k++) scratch[k * 4 + wid] = red[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 29) {
+    float v = 0.f;
+    for (int w = 0; w < nw; w++) v += scratch[threadIdx.x * 4 + w];
+    if (threadIdx.x < 27) atomicAdd(&a.dw[c * 27 + threadIdx.x], v);
+    else atomic_add_d(&a.a_sums[c * 2 + (threadIdx.x - 27)], (double)v);
+  }
+}
+
 // ================================================================================================
 // dispatch.  Depth 4 for strips of 1 / 2 outputs (rows of < 20 outputs), depth 2 for strips of 4 (stride 1).
 // ================================================================================================
@@ -440,6 +679,21 @@ static bool fwd_go(const DwFwdArgs& a, unsigned grid, int bd, size_t lds, hipStr
 }
 template <typename T, int S, int SW, int CV, int PD>
 static bool bwd_go(const DwBwdArgs& a, unsigned grid, int bd, size_t lds, hipStream_t st) {
+  // stride 1, strips of 2 (14x14 / 10x10 planes): the register-role form at depth 3 (164 -> 155 us at 14x14).  Strips of 1
+  // (7x7) keep the copying form at depth 4: there the role form needs the 128-VGPR cap's spills and was 0.7x.
+  // X3D_DW_ROLES=0: copying form everywhere (A/B hook).
+  static const char* roles = getenv("X3D_DW_ROLES");
+  if constexpr (S == 1 && SW == 2) {
+    if (!(roles && atoi(roles) == 0)) {
+      if (x3d_describe.out) {
+        snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_s1_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+                 SW, CV, 3, 6);
+        return true;
+      }
+      hipLaunchKernelGGL((dw3d_bwd_pd_s1_kernel<T, SW, CV, 3, 6>), dim3(grid), dim3(bd), lds, st, a);
+      return true;
+    }
+  }
   DW_PD_DESCRIBE("bwd")
   hipLaunchKernelGGL((dw3d_bwd_pd_kernel<T, S, SW, CV, PD>), dim3(grid), dim3(bd), lds, st, a);
   return true;
