@@ -189,12 +189,16 @@ static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
 // and launch publishes scale_shift / mean_invstd and updates the moving statistics.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, bool writer, float& sc, float& sh) {
-  const double mean = f.stats[c * 2] / f.count;
-  double var = f.stats[c * 2 + 1] / f.count - mean * mean;  // biased batch variance (Keras, training)
+  // the four loads first: left in use order they compiled to four dependent L2 round trips at the head of every
+  // consumer workgroup (load, s_waitcnt vmcnt(0), fp64 division, next load, ...)
+  const double sum1 = f.stats[c * 2], sum2 = f.stats[c * 2 + 1];
+  const float ga = f.gamma[c], be = f.beta[c];
+  const double mean = sum1 / f.count;
+  double var = sum2 / f.count - mean * mean;  // biased batch variance (Keras, training)
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-  sc = f.gamma[c] * invstd;
-  sh = f.beta[c] - (float)mean * sc;
+  sc = ga * invstd;
+  sh = be - (float)mean * sc;
   if (writer) {
     f.scale_shift[c * 2] = sc;
     f.scale_shift[c * 2 + 1] = sh;
