@@ -84,7 +84,11 @@ def test_inference_batch_must_be_multiple_of_views(gpu):
         m(torch.randn(3, 4, 32, 32, 3, device=gpu), training=False)
 
 
-@pytest.mark.parametrize("name,n,t,s", [("XS", 4, 4, 64), ("S", 2, 13, 64), ("M", 2, 4, 64), ("S", 3, 5, 96)])
+@pytest.mark.parametrize("name,n,t,s", [
+    ("XS", 4, 4, 64), ("S", 2, 13, 64), ("M", 2, 4, 64), ("S", 3, 5, 96),
+    ("XS", 2, 4, 78),     # odd extents end to end: 78 -> 39 -> 20 -> 10 -> 5 -> 3 (X3D-L's 39 -> 20 TF-SAME pads, odd stride-2 planes)
+    ("M", 2, 16, 112),    # T = 16 and 56 / 28 / 14 / 7 planes: the deep-prefetch depthwise variants (dw_pd.hip) inside the model
+])
 def test_train_step_fp32(gpu, name, n, t, s):
     """fwd + bwd in training mode (batch statistics, fixed dropout mask) against oracle autograd."""
     from oracle import x3d_oracle as O
