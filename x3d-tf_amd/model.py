@@ -115,6 +115,14 @@ class _Plan:
         self._zero_views: List = []
         self.bwd_stage_marks: Dict[int, int] = {}
         self.structs: Dict = {}
+        # experiment switch X3D_SIDE_WGRAD=1: the weight-gradient GEMMs that have no consumer before the optimizer run on
+        # a SIDE stream, concurrently with the data-gradient chain (see X3D._record_backward).  Measured on X3D-M B=64
+        # (r01i): 27.03 ms/step on one stream, 27.4 ms with the side stream -- the kernels already compete for the same
+        # CUs and HBM, so the default is one stream.
+        self.side_on = training and os.environ.get("X3D_SIDE_WGRAD") == "1"
+        self.side_entries = set()      # (id(list), index) of launches that go to the side stream
+        self.side = None               # torch.cuda.Stream, created with the first forked launch
+        self._side_pending = False
 
     # -- allocation ------------------------------------------------------------------------------
     def act(self, *shape):
@@ -157,6 +165,48 @@ class _Plan:
             else:
                 conv.append(a)
         lst.append((name, fn, tuple(conv)))
+
+    # -- side stream ------------------------------------------------------------------------------
+    def rec_side(self, lst, name, *args):
+        """Record a launch for the side stream: it starts after everything recorded before it and is waited for by
+        the next rec_join().  Only for launches whose outputs nothing reads before that join."""
+        self.rec(lst, name, *args)
+        if self.side_on:
+            self.side_entries.add((id(lst), len(lst) - 1))
+
+    def rec_join(self, lst):
+        """The main stream waits here for every launch forked so far (no-op when none is pending)."""
+        if self.side_on:
+            lst.append(("side_join", self._join, ()))
+
+    def _join(self, stream):
+        if self._side_pending:
+            torch.cuda.current_stream().wait_event(self._ev_join)
+            self._side_pending = False
+        return 0
+
+    def wrap_side(self, lst):
+        """After the placeholders are resolved: replace the marked launches by fork wrappers."""
+        if not self.side_on:
+            return
+        for i, (name, fn, args) in enumerate(lst):
+            if (id(lst), i) in self.side_entries:
+                lst[i] = (name, self._forked(fn), args)
+
+    def _forked(self, fn):
+        def launch(*a):
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.model.device)
+                self._ev_fork = torch.cuda.Event()
+                self._ev_join = torch.cuda.Event()
+            main = torch.cuda.current_stream()
+            self._ev_fork.record(main)
+            self.side.wait_event(self._ev_fork)
+            rc = fn(*a[:-1], self.side.cuda_stream)
+            self._ev_join.record(self.side)
+            self._side_pending = True
+            return rc
+        return launch
 
     def run(self, lst, start=0, stop=None):
         s = torch.cuda.current_stream().cuda_stream
@@ -586,6 +636,7 @@ class X3D:
             f.stats = pl._zero_views[handle].data_ptr()
         self._resolve(pl, pl.fwd)
         self._resolve(pl, pl.bwd)
+        pl.wrap_side(pl.bwd)
         return pl
 
     @staticmethod
@@ -657,13 +708,14 @@ class X3D:
         c_last = a.stages[-1].cout
         w5 = hip.PwWgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(pl.y_last), None, None, ACT_NONE,
                              _p(g["conv5/layer_with_weights-0/kernel"]), n, c_last, c5, t, pl.h5, pl.w5, 1, dt)
-        pl.rec(Bk, "x3d_pw_wgrad", w5)
+        pl.rec_side(Bk, "x3d_pw_wgrad", w5)
         cur = 0
         dy = pl.gbuf[cur][:pl.y_last.numel()]
         d5 = hip.PwDgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(p["conv5/layer_with_weights-0/kernel"]),
                              _p(dy), EPI_STORE, None, None, None, None, None, n, c_last, c5, t, pl.h5, pl.w5, dt)
         d5.w_panel = self._wp("conv5/layer_with_weights-0/kernel", True)
         pl.rec(Bk, "x3d_pw_dgrad", d5)
+        pl.rec_join(Bk)
         pl.bwd_stage_marks[len(a.stages)] = len(Bk)   # head finished
 
         # ---- residual blocks, last to first ----------------------------------------------------
@@ -695,7 +747,10 @@ class X3D:
             if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fc)):
                 pl.rec(Bk, "x3d_pw_bwd", ("field", fc, {"nc_sums": B.nc_sums}))
             else:
-                pl.rec(Bk, "x3d_pw_wgrad", wc)
+                # Weight gradients feed nothing but the optimizer: they run on the side stream next to the data-gradient
+                # chain.  What they read (g, the raw conv outputs, the shared `ga` scratch) is next overwritten by the
+                # following depthwise backward / the block after it, and every depthwise backward is preceded by a join.
+                pl.rec_side(Bk, "x3d_pw_wgrad", wc)
                 pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
             # SE + BN_b backward from the per-(n,c) sums
             se = hip.SeBnbBwdArgs(
@@ -711,6 +766,7 @@ class X3D:
             db = hip.Dw3dBwdArgs(_p(dvv), _p(B.b_raw), _p(pl.coef_nc), _p(B.a_raw), _p(B.bn_a.ss),
                                  _p(p[f"{q}/b/kernel"]), _p(gaa), None, _p(g[f"{q}/b/kernel"]), n, b.inner, t, B.hh,
                                  B.ww, b.stride, dt)
+            pl.rec_join(Bk)
             pl.rec(Bk, "x3d_dw3d_bwd", ("field", db, {"a_sums": B.bn_a.bsums}))
             pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_a.bsums), float(n * P_in), B.bn_a.mi, p[f"{q}/bn_a/gamma"],
                    B.bn_a.coef, g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
@@ -723,7 +779,7 @@ class X3D:
                        p[f"{pre}/bn_r/gamma"], B.bn_r.coef, g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
                 wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
                                      _p(g[f"{pre}/residual/kernel"]), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
-                pl.rec(Bk, "x3d_pw_wgrad", wr)
+                pl.rec_side(Bk, "x3d_pw_wgrad", wr)
                 rt = pl.rtmp[:n * b.cin * P_out]
                 dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(p[f"{pre}/residual/kernel"]), _p(rt),
                                      EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
@@ -741,12 +797,13 @@ class X3D:
             if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
                 pl.rec(Bk, "x3d_pw_bwd", fa)
             else:
-                pl.rec(Bk, "x3d_pw_wgrad", wa)
+                pl.rec_side(Bk, "x3d_pw_wgrad", wa)
                 pl.rec(Bk, "x3d_pw_dgrad", da)
             cur = 1 - cur
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt
             if b.index == 0:
+                pl.rec_join(Bk)
                 pl.bwd_stage_marks[b.stage] = len(Bk)   # every gradient of stages >= b.stage is final
 
         # ---- stem ------------------------------------------------------------------------------
@@ -759,6 +816,7 @@ class X3D:
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
         pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
                a.c1, dt)
+        pl.rec_join(Bk)
         pl.bwd_stage_marks[-1] = len(Bk)
 
     # ---------------------------------------------------------------------------------------------
