@@ -386,11 +386,33 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
     }
   }
 
+  // split-K waves (nks > 1: one or two tiles shared by the four waves) first add their partial tiles in LDS: the narrow
+  // layers (24 x 24, 48 x 24 shortcuts) have thousands of workgroups adding into a few hundred dW addresses, all in one
+  // or two L2 channels, and the atomics -- not the streaming -- were their bound
+  if constexpr (TPW == 1) {
+    if (nks > 1) {
+      float* red = (float*)smem_raw;          // [4 waves][16][64] floats = 16 KB <= the staging tiles (2 * 32 * LP * 2 B = 17 KB)
+      __syncthreads();                        // every wave is done with As / Bs
+#pragma unroll
+      for (int j = 0; j < 16; j++) red[(wid * 16 + j) * 64 + lane] = acc[0][j];
+      __syncthreads();
+      const int id = wid % ntiles, kpart = wid / ntiles;
+      if (kpart == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          float v = acc[0][j];
+          for (int kp = 1; kp < nks; kp++) v += red[((id + kp * ntiles) * 16 + j) * 64 + lane];
+          acc[0][j] = v;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < TPW; s++) {
     int id = wid + 4 * s;
-    if (nks > 1) id = wid % ntiles;
-    if (id < ntiles && s_begin < s_end) {
+    bool writer = true;
+    if (nks > 1) { id = wid % ntiles; writer = wid < ntiles; }
+    if (id < ntiles && s_begin < s_end && writer) {
       const int mt = id / nt_here, nt = id - mt * nt_here;
       const int ci = ci0 + nt * 32 + r;
 #pragma unroll
@@ -431,6 +453,11 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   if (gx_target < 1) gx_target = 1;
   long long spb = ceil_div_ll(total_steps, gx_target);
   if (spb < 8) spb = 8;      // keeps the atomic partial (<= 32 KB) below ~10 % of the streamed bytes
+  // every workgroup of a (y, z) tile group adds into the SAME dW tile: past ~500 workgroups per group the fp32 atomics on
+  // a few hundred addresses are the bound (48 x 24 @ 28x28: 96 us with 1255 workgroups, 85 us with 392)
+  if (ceil_div_ll(total_steps, spb) > 512) spb = ceil_div_ll(total_steps, 512);
+  static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
+  if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
   a.steps_per_block = (int)spb;
   const long long gx = ceil_div_ll(total_steps, spb);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
