@@ -264,6 +264,7 @@ def test_dw3d_fwd(gpu, dtype, shape):
     # N, Cin, Cout, T, H, W
     (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
     (1, 216, 96, 2, 7, 7), (1, 200, 40, 1, 4, 8),
+    (1, 54, 24, 4, 14, 14), (1, 48, 108, 2, 28, 28),   # strided add with rows of 2k / 4k points (pair / quad groups)
 ])
 @pytest.mark.parametrize("epi", ["store", "add", "add_strided", "swish_bwd"])
 def test_pw_dgrad(gpu, dtype, shape, epi):

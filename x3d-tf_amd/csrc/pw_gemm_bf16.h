@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     constexpr bool EPL4 = (OVEC == 8) && (EPI == X3D_EPI_ADD_STRIDED);
     bf16x8 epl8[EPL8 ? ROWS_PT : 1];
     bf16x4 epl4[EPL4 ? ROWS_PT : 1];
-    const bool epl4_vec = EPL4 && (a.eW & 7) == 0;
+    // the 8 points of a vector (p % 8 == 0) split into groups of egv points that stay inside one image row; each group's
+    // even pixels receive egv / 2 contiguous half-resolution values.  egv = 8 / 4 / 2 by the row length; 0 (odd rows): scalar
+    const int egv = !EPL4 ? 0 : ((a.eW & 7) == 0 ? 8 : ((a.eW & 3) == 0 ? 4 : ((a.eW & 1) == 0 ? 2 : 0)));
+    const bool epl4_vec = egv != 0;
     constexpr bool SWB_ = (EPI == X3D_EPI_SWISH_BWD);
     float esb[SWB_ ? ROWS_PT : 1], etb[SWB_ ? ROWS_PT : 1], egt[SWB_ ? ROWS_PT : 1];   // per-row BN_b scale/shift, SE gate
     if constexpr (SWB_) {
@@ -382,15 +385,38 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
           if (epl4_vec && m < a.M && p < a.P) {
-            // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
             const long long hw = (long long)a.eH * a.eW;
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
             const long long T_ = a.P / hw;
-            const long long t = p / hw;
-            const int rem = (int)(p - t * hw);
-            const int h = rem / a.eW, w = rem - h * a.eW;
-            if ((h & 1) == 0)
-              epl4[i] = *(const bf16x4*)((const T*)a.add + ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
+            const T* abase = (const T*)a.add + ((long long)n * a.M + m) * T_ * Hh * Wh;
+            if (egv == 8) {
+              // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
+              const long long t = p / hw;
+              const int rem = (int)(p - t * hw);
+              const int h = rem / a.eW, w = rem - h * a.eW;
+              if ((h & 1) == 0) epl4[i] = *(const bf16x4*)(abase + (t * Hh + (h >> 1)) * Wh + (w >> 1));
+            } else if (egv == 4) {
+#pragma unroll
+              for (int gq = 0; gq < 2; gq++) {
+                const long long pe = p + 4 * gq;
+                const long long t = pe / hw;
+                const int rem = (int)(pe - t * hw);
+                const int h = rem / a.eW, w = rem - h * a.eW;
+                if ((h & 1) == 0) {
+                  const bf16x2 v2 = *(const bf16x2*)(abase + (t * Hh + (h >> 1)) * Wh + (w >> 1));
+                  epl4[i][2 * gq] = v2[0]; epl4[i][2 * gq + 1] = v2[1];
+                }
+              }
+            } else {
+#pragma unroll
+              for (int gq = 0; gq < 4; gq++) {
+                const long long pe = p + 2 * gq;
+                const long long t = pe / hw;
+                const int rem = (int)(pe - t * hw);
+                const int h = rem / a.eW, w = rem - h * a.eW;
+                if ((h & 1) == 0) epl4[i][gq] = abase[(t * Hh + (h >> 1)) * Wh + (w >> 1)];
+              }
+            }
           }
         }
       }
