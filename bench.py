@@ -138,7 +138,7 @@ def cpu_baseline(variant, seconds_budget=25.0, batch=1):
         O.train_step(p, xin, labels, arch, lr=0.01, apply_update=True)
         done += 1
         el = time.perf_counter() - t0
-        if el + warm > seconds_budget or done >= 10:
+        if el + warm > seconds_budget or done >= 30:   # about 10-25 s of CPU work on the GPU box's host
             break
     steps_txt = f"1 warm-up + {done} timed steps" if done else "the single (warm-up) step"
     value = done * batch / el if done else batch / warm
