@@ -67,7 +67,7 @@ def main():
             tag = f"{'bf16' if dtype == torch.bfloat16 else 'fp32'} C{c} {t}x{h}x{w} s{s}"
             # forward
             y = torch.empty((nn, c, t, ho, wo), dtype=dtype, device=dev)
-            stats = torch.zeros((c, 2), dtype=torch.float64, device=dev)
+            stats = ops.stats_buffer(c, dev)   # replicated accumulator (include/x3d_hip.h)
             pool = torch.zeros((nn, c), dtype=torch.float64, device=dev)
             fa = hip.Dw3dFwdArgs(hip.ptr(x), hip.ptr(wt), hip.ptr(y), hip.ptr(ss), 1, hip.ptr(stats), hip.ptr(pool),
                                  nn, c, t, h, w, s, hip.dtype_code(dtype))

@@ -64,9 +64,10 @@ int main(int argc, char** argv) {
     float* ss = dev_random_f32((size_t)C * 2, 6, 0.2f, 0.6f);
     float* coef = dev_random_f32((size_t)N * C * 4, 7, 0.3f, 0.5f);
     double *stats, *pool, *asums; float* dw;
-    HIP_OK(hipMalloc((void**)&stats, C * 16)); HIP_OK(hipMalloc((void**)&pool, (size_t)N * C * 8));
+    const size_t stats_bytes = (size_t)x3d_stats_replicas() * x3d_stats_stride(C) * 8;   // replicated accumulator
+    HIP_OK(hipMalloc((void**)&stats, stats_bytes)); HIP_OK(hipMalloc((void**)&pool, (size_t)N * C * 8));
     HIP_OK(hipMalloc((void**)&asums, C * 16)); HIP_OK(hipMalloc((void**)&dw, C * 27 * 4));
-    HIP_OK(hipMemset(stats, 0, C * 16)); HIP_OK(hipMemset(pool, 0, (size_t)N * C * 8));
+    HIP_OK(hipMemset(stats, 0, stats_bytes)); HIP_OK(hipMemset(pool, 0, (size_t)N * C * 8));
     HIP_OK(hipMemset(asums, 0, C * 16)); HIP_OK(hipMemset(dw, 0, C * 27 * 4));
 
     x3d_dw3d_fwd_args f; memset(&f, 0, sizeof(f));

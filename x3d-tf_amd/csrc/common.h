@@ -188,11 +188,20 @@ static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
 // coefficients are the same bits whichever path computed them.  `writer`: exactly one thread per channel
 // and launch publishes scale_shift / mean_invstd and updates the moving statistics.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, bool writer, float& sc, float& sh) {
-  // the four loads first: left in use order they compiled to four dependent L2 round trips at the head of every
-  // consumer workgroup (load, s_waitcnt vmcnt(0), fp64 division, next load, ...)
-  const double sum1 = f.stats[c * 2], sum2 = f.stats[c * 2 + 1];
-  const float ga = f.gamma[c], be = f.beta[c];
+// Replicated statistics accumulators (include/x3d_hip.h): STATS_R copies of [C][2] doubles, stats_stride(C) apart.
+#define STATS_R 32
+__host__ __device__ __forceinline__ long long stats_stride(int C) {
+  const long long need = ((long long)C * 2 + 63) & ~63ll;
+  return need > 512 ? need : 512;        // >= 4 KB apart: the copies land in different L2 channels
+}
+// the copy a producer workgroup adds into; `key`: any index that differs between the workgroups that share a channel
+__device__ __forceinline__ double* stats_replica(double* stats, int C, unsigned key) {
+  return stats + (long long)(key % STATS_R) * stats_stride(C);
+}
+
+// coefficients of one channel from its totals (sum, sum of squares); `writer` publishes them / updates the moving stats
+__device__ __forceinline__ void bn_coefs(const x3d_bn_fold& f, int c, double sum1, double sum2, float ga, float be,
+                                         bool writer, float& sc, float& sh) {
   const double mean = sum1 / f.count;
   double var = sum2 / f.count - mean * mean;  // biased batch variance (Keras, training)
   if (var < 0.0) var = 0.0;
@@ -212,6 +221,25 @@ __device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, boo
       f.moving_var[c] = f.moving_var[c] * f.momentum + (float)unb * (1.f - f.momentum);
     }
   }
+}
+// one thread sums the STATS_R copies itself (the folded consumers, x3d_bn_fold): batches of 8 copies = 16 loads in
+// flight and 32 VGPRs; all 32 at once would set the register count of the whole consumer kernel.  The copies are
+// summed pairwise in the same tree as bn_finalize_kernel's lane reduction, so both paths give the same bits.
+__device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, bool writer, float& sc, float& sh, int C) {
+  const float ga = f.gamma[c], be = f.beta[c];
+  const long long rs = stats_stride(C);
+  double q1[STATS_R / 8], q2[STATS_R / 8];
+#pragma unroll
+  for (int r0 = 0; r0 < STATS_R; r0 += 8) {
+    double p1[8], p2[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { p1[r] = f.stats[(r0 + r) * rs + c * 2]; p2[r] = f.stats[(r0 + r) * rs + c * 2 + 1]; }
+    // xor-butterfly order over 8: (0+1, 2+3, 4+5, 6+7) -> pairs -> total
+    q1[r0 / 8] = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
+    q2[r0 / 8] = ((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4] + p2[5]) + (p2[6] + p2[7]));
+  }
+  const double sum1 = (q1[0] + q1[1]) + (q1[2] + q1[3]), sum2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+  bn_coefs(f, c, sum1, sum2, ga, be, writer, sc, sh);
 }
 static inline bool bn_fold_valid(const x3d_bn_fold* f) {
   return f && f->stats && f->gamma && f->beta && f->scale_shift && f->mean_invstd && f->count > 0 &&

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
     w0[k / 3][k % 3] = a.w[c * 27 + k];
   }
   float sc = 1.f, sh = 0.f;
-  if (a.bn.stats) bn_fold_channel(a.bn, c, n == 0 && tile == 0 && threadIdx.x == 0, sc, sh);   // BN finalize folded in
+  if (a.bn.stats) bn_fold_channel(a.bn, c, n == 0 && tile == 0 && threadIdx.x == 0, sc, sh, g.C);   // BN finalize folded in
   else if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
   const int act = a.act;
   auto xf = [=](float v) {
@@ -143,8 +143,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
     block_sum<2>(red, scratch);
     if (threadIdx.x == 0) {
       if (a.stats) {
-        atomic_add_d(&a.stats[c * 2], (double)red[0]);
-        atomic_add_d(&a.stats[c * 2 + 1], (double)red[1]);
+        double* sp = stats_replica(a.stats, g.C, (unsigned)(n * g.ntile_h + tile));
+        atomic_add_d(&sp[c * 2], (double)red[0]);
+        atomic_add_d(&sp[c * 2 + 1], (double)red[1]);
       }
       if (a.pool) atomic_add_d(&a.pool[(long long)n * g.C + c], (double)red[0]);
     }

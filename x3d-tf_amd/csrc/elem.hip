@@ -6,11 +6,23 @@
 // ------------------------------------------------------------------------------------------------
 // BN finalize kernels: one thread per channel (C <= a few hundred)
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const x3d_bn_fold f, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// One lane per (channel, copy): 32 lanes load the 32 copies of a channel in ONE round trip and add them with an xor
+// butterfly (1, 2, 4, 8, 16); a 64-thread block finalizes two channels.  (One thread per channel summing the copies
+// itself is four dependent round trips: 84 such launches sit between producers and consumers in every train step.)
+static_assert(STATS_R == 32, "bn_finalize_kernel maps one half-wave to the copies of a channel");
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const x3d_bn_fold f, int C) {
+  const int c = blockIdx.x * 2 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+  const int cc = c < C ? c : C - 1;
+  const long long rs = stats_stride(C);
+  double s1 = f.stats[r * rs + cc * 2], s2 = f.stats[r * rs + cc * 2 + 1];
+  const float ga = f.gamma[cc], be = f.beta[cc];
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
   float sc, sh;
-  bn_fold_channel(f, c, true, sc, sh);
+  bn_coefs(f, cc, s1, s2, ga, be, r == 0 && c < C, sc, sh);
 }
 
 __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -46,6 +58,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
   dbeta[c] += (float)dbe;
 }
 
+extern "C" int x3d_stats_replicas(void) { return STATS_R; }
+extern "C" long long x3d_stats_stride(int C) { return stats_stride(C); }
+
 extern "C" int x3d_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                                float* moving_mean, float* moving_var, float eps, float momentum,
                                int update_moving, float* scale_shift, float* mean_invstd, int C,
@@ -55,7 +70,7 @@ extern "C" int x3d_bn_finalize(const double* stats, double count, const float* g
   x3d_bn_fold f;
   f.stats = stats; f.count = count; f.gamma = gamma; f.beta = beta; f.moving_mean = moving_mean; f.moving_var = moving_var;
   f.eps = eps; f.momentum = momentum; f.update_moving = update_moving; f.scale_shift = scale_shift; f.mean_invstd = mean_invstd;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, f, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 2)), dim3(64), 0, (hipStream_t)stream, f, C);
   X3D_LAUNCH_CHECK("bn_finalize");
   return X3D_OK;
 }
@@ -123,8 +138,8 @@ __global__ __launch_bounds__(ELEM_BLOCK) void tail_fwd_kernel(const T* __restric
   float sc, tc, sr = 1.f, tr = 0.f;
   if constexpr (FOLD) {
     const bool writer = (nc < C) && blockIdx.x == 0 && threadIdx.x == 0;
-    bn_fold_channel(fold.c, c, writer, sc, tc);
-    if (fold.has_r) bn_fold_channel(fold.r, c, writer, sr, tr);
+    bn_fold_channel(fold.c, c, writer, sc, tc, C);
+    if (fold.has_r) bn_fold_channel(fold.r, c, writer, sr, tr, C);
   } else {
     sc = ssc[c * 2]; tc = ssc[c * 2 + 1];
     if (ssr) { sr = ssr[c * 2]; tr = ssr[c * 2 + 1]; }

@@ -285,8 +285,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         if ((tid & 15) == 0 && m < a.M) {
           if constexpr (EPI == EPI_STATS) {
             if (a.stats) {
-              atomic_add_d(&a.stats[m * 2], (double)s1);
-              atomic_add_d(&a.stats[m * 2 + 1], (double)s2);
+              double* sp = stats_replica(a.stats, a.M, blockIdx.x);
+              atomic_add_d(&sp[m * 2], (double)s1);
+              atomic_add_d(&sp[m * 2 + 1], (double)s2);
             }
           } else {
             double* d = a.nc_sums + ((long long)n * a.M + m) * 2;

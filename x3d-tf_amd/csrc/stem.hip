@@ -531,8 +531,9 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, c
   if (stats) {
     block_sum<2>(red, scratch);
     if (threadIdx.x == 0) {
-      atomic_add_d(&stats[c * 2], (double)red[0]);
-      atomic_add_d(&stats[c * 2 + 1], (double)red[1]);
+      double* sp = stats_replica(stats, C, blockIdx.x + (unsigned)(nc / C));
+      atomic_add_d(&sp[c * 2], (double)red[0]);
+      atomic_add_d(&sp[c * 2 + 1], (double)red[1]);
     }
   }
 }

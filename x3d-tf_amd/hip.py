@@ -100,6 +100,8 @@ _SIGS = {
     "x3d_stem_s_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_dwt_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_stats_replicas": ([], _i),
+    "x3d_stats_stride": ([_i], _ll),
     "x3d_bn_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "x3d_bn_eval_coef": ([_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], _i),
     "x3d_bn_eval_coef_batched": ([_vp, _i, _f, _vp], _i),
@@ -207,3 +209,9 @@ def call(name, *args):
 def call_struct(name, struct):
     lib = load()
     check(getattr(lib, name)(C.byref(struct), stream_ptr()), name)
+
+
+def stats_layout(c: int):
+    """(replicas, stride in doubles) of a statistics accumulator for c channels (include/x3d_hip.h)."""
+    lib = load()
+    return int(lib.x3d_stats_replicas()), int(lib.x3d_stats_stride(int(c)))

@@ -254,6 +254,7 @@ class X3D:
         # fused dgrad + wgrad of the pointwise convs (x3d_pw_bwd) where it applies; X3D_NO_FUSED_PW_BWD=1 records
         # the separate kernels instead (A/B measurements)
         self._fuse_pw_bwd = os.environ.get("X3D_NO_FUSED_PW_BWD", "0") != "1"
+        self._stats_r = int(hip.load().x3d_stats_replicas())
 
     # ---------------------------------------------------------------------------------------------
     # parameters: one flat fp32 buffer (trainable first, then BN moving statistics), one flat
@@ -462,7 +463,8 @@ class X3D:
             b.prefix, b.c = prefix, c
             b.ss = pl.f32(c, 2)
             b.mi = pl.f32(c, 2)
-            b.stats = pl.acc64(c, 2) if training else None
+            # forward statistics: the library's replicated layout (x3d_stats_replicas copies, x3d_stats_stride apart)
+            b.stats = pl.acc64(self._stats_r * int(pl.lib.x3d_stats_stride(c))) if training else None
             b.bsums = pl.acc64(c, 2) if training else None
             b.coef = pl.f32(c, 4) if training else None
             return b
@@ -477,10 +479,11 @@ class X3D:
             else:   # inference: every layer's coefficients in ONE launch at the head of the forward list (below)
                 pl.bn_eval_items.append(hip.BnEvalItem(_p(g), _p(be), _p(mm), _p(mv), _p(b.ss), _p(b.mi), b.c))
 
-        # training: the finalize of a BatchNorm whose consumer has one channel per workgroup (depthwise conv, residual
-        # tail) is folded into that consumer (x3d_bn_fold) -- 57 launches of ~6 us fewer per X3D-M step.
-        # X3D_NO_BN_FOLD=1 records the separate x3d_bn_finalize launches instead (A/B switch).
-        fold_on = training and os.environ.get("X3D_NO_BN_FOLD") != "1"
+        # experiment switch X3D_BN_FOLD=1 (training): the finalize of a BatchNorm whose consumer has one channel per
+        # workgroup (depthwise conv, residual tail) runs inside that consumer (x3d_bn_fold) -- 57 launches fewer per
+        # X3D-M step, worth 0.08 ms with single-copy statistics.  With the replicated accumulators every consumer
+        # workgroup would have to sum 32 copies first, so the separate x3d_bn_finalize launches are the default.
+        fold_on = training and os.environ.get("X3D_BN_FOLD") == "1"
         pl.folds = []
 
         def bn_fold(b, count):

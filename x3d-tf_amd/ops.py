@@ -44,13 +44,57 @@ def stem_s_wgrad(x, dy, dw):
              hip.dtype_code(x.dtype))
 
 
+# ---- replicated statistics accumulators (include/x3d_hip.h) ----------------------------------------
+def stats_buffer(c, device):
+    """Zeroed accumulator in the library's replicated layout for c channels."""
+    r, stride = hip.stats_layout(c)
+    return torch.zeros(r * stride, dtype=torch.float64, device=device)
+
+
+def stats_sum(buf, c):
+    """[c, 2] totals of a replicated accumulator."""
+    r, stride = hip.stats_layout(c)
+    return buf.view(r, stride)[:, :2 * c].sum(0).view(c, 2)
+
+
+_KEEP = []
+
+
+class _Stats:
+    """Producers called with a plain [C, 2] tensor (tests, tools) run on a temporary replicated accumulator whose
+    totals are added to the tensor afterwards; a tensor already in the replicated layout is passed through."""
+
+    def __init__(self, user, c):
+        self.user, self.c, self.tmp = user, c, None
+        if user is not None and user.numel() == 2 * c:
+            self.tmp = stats_buffer(c, user.device)
+
+    def arg(self):
+        return self.user if self.tmp is None else self.tmp
+
+    def done(self):
+        if self.tmp is not None:
+            self.user += stats_sum(self.tmp, self.c).view_as(self.user)
+
+
+def _expand_stats(stats, c):
+    """Consumers called with plain [C, 2] totals: replica 0 holds them, the others are zero."""
+    if stats.numel() != 2 * c:
+        return stats
+    buf = stats_buffer(c, stats.device)
+    buf[:2 * c] = stats.reshape(-1)
+    return buf
+
+
 def dwt_fwd(x, w, y=None, stats=None):
     _chk(x, w, y, stats)
     n, c, t, h, ww = x.shape
     if y is None:
         y = torch.empty_like(x)
-    hip.call("x3d_dwt_fwd", ptr(x), ptr(w), ptr(y), ptr(stats), n, c, t, h * ww, w.shape[1],
+    st = _Stats(stats, c)
+    hip.call("x3d_dwt_fwd", ptr(x), ptr(w), ptr(y), ptr(st.arg()), n, c, t, h * ww, w.shape[1],
              hip.dtype_code(x.dtype))
+    st.done()
     return y
 
 
@@ -64,6 +108,7 @@ def dwt_bwd(g, yraw, coef, x, w, dx, dw):
 # ---- batch norm ---------------------------------------------------------------------------------
 def bn_finalize(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, ss, mi):
     _chk(stats, gamma, beta, mmean, mvar, ss, mi)
+    stats = _expand_stats(stats, gamma.numel())
     hip.call("x3d_bn_finalize", ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar),
              float(eps), float(momentum), int(update), ptr(ss), ptr(mi), gamma.numel())
 
@@ -71,6 +116,9 @@ def bn_finalize(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, s
 def bn_fold(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, ss, mi):
     """x3d_bn_fold for a consumer that runs the finalize itself (x3d_dw3d_fwd in_bn / x3d_tail_fwd_bn)."""
     _chk(stats, gamma, beta, mmean, mvar, ss, mi)
+    stats = _expand_stats(stats, gamma.numel())
+    _KEEP.append(stats)   # the struct holds a raw pointer
+    del _KEEP[:-64]
     return hip.BnFold(ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(mmean), ptr(mvar), float(eps), float(momentum),
                       int(update), ptr(ss), ptr(mi))
 
@@ -115,9 +163,11 @@ def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, 
     ho, wo = _out_hw(h, ww, stride)
     if y is None:
         y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
-    a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(stats), ptr(in_ss), ptr(in_gate), in_act, n, cin,
+    st = _Stats(stats, cout)
+    a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(st.arg()), ptr(in_ss), ptr(in_gate), in_act, n, cin,
                       cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel))
     hip.call_struct("x3d_pw_fwd", a)
+    st.done()
     return y
 
 
@@ -167,9 +217,11 @@ def dw3d_fwd(x, w, stride, y=None, in_ss=None, in_act=ACT_NONE, stats=None, pool
     ho, wo = _out_hw(h, ww, stride)
     if y is None:
         y = torch.empty((n, c, t, ho, wo), dtype=x.dtype, device=x.device)
-    a = hip.Dw3dFwdArgs(ptr(x), ptr(w), ptr(y), ptr(in_ss), in_act, ptr(stats), ptr(pool), n, c, t, h,
+    st = _Stats(stats, c)
+    a = hip.Dw3dFwdArgs(ptr(x), ptr(w), ptr(y), ptr(in_ss), in_act, ptr(st.arg()), ptr(pool), n, c, t, h,
                         ww, stride, hip.dtype_code(x.dtype), None if in_bn is None else ctypes.pointer(in_bn))
     hip.call_struct("x3d_dw3d_fwd", a)
+    st.done()
     return y
 
 
