@@ -64,12 +64,8 @@ __device__ __forceinline__ void pw_load_vec(const PwGemmArgs& a, int n, int gk, 
     float s = a.coef[gk * 2], t = a.coef[gk * 2 + 1];
     float g = a.gate ? a.gate[(long long)n * a.K + gk] : 1.0f;
 #pragma unroll
-    for (int e = 0; e < VEC; e++) {
-      float u = (s * v[e] + t) * g;
-      if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-      else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
-      v[e] = u;
-    }
+    for (int e = 0; e < VEC; e++) v[e] = (s * v[e] + t) * g;
+    act_vec<VEC>(v, a.act);
   } else if constexpr (PRO == PRO_BNBWD) {
     float y2[VEC];
     VecIO<T, VEC>::load((const T*)a.x2 + ((long long)n * a.K + gk) * a.Pin + p, y2);

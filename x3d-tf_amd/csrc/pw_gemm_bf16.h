@@ -232,12 +232,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         }
         if constexpr (PRO == PRO_AFFINE) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) {
-            float u = cf[0] * val[e] + cf[1];
-            if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-            else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
-            val[e] = u;
-          }
+          for (int e = 0; e < VEC; e++) val[e] = cf[0] * val[e] + cf[1];
+          act_vec<VEC>(val, a.act);
         } else {  // PRO_BNBWD
 #pragma unroll
           for (int e = 0; e < VEC; e++) {

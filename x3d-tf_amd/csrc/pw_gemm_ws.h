@@ -99,12 +99,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) 
         if constexpr (PRO == PRO_AFFINE) {
           const float2 cf = *(const float2*)&Cs[k * 2];
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            float u = cf.x * val[e] + cf.y;
-            if (a.act == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-            else if (a.act == X3D_ACT_SWISH) u = swishf_(u);
-            val[e] = u;
-          }
+          for (int e = 0; e < 8; e++) val[e] = cf.x * val[e] + cf.y;
+          act_vec<8>(val, a.act);
         } else {
           const f32x4 cf = *(const f32x4*)&Cs[k * 4];
 #pragma unroll

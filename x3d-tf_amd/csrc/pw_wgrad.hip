@@ -88,12 +88,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
           const float s = a.xcoef[row * 2], t = a.xcoef[row * 2 + 1];
           const float g = a.xgate ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
 #pragma unroll
-          for (int e = 0; e < VEC; e++) {
-            float u = (s * val[e] + t) * g;
-            if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-            else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
-            val[e] = u;
-          }
+          for (int e = 0; e < VEC; e++) val[e] = (s * val[e] + t) * g;
+          act_vec<VEC>(val, a.xact);
         }
       } else {
 #pragma unroll

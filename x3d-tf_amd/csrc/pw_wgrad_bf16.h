@@ -86,12 +86,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a)
             const float s = a.xcoef[row * 2], t = a.xcoef[row * 2 + 1];
             const float g = a.xgate ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
 #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-              float u = (s * val[e] + t) * g;
-              if (a.xact == X3D_ACT_RELU) u = fmaxf(u, 0.f);
-              else if (a.xact == X3D_ACT_SWISH) u = swishf_(u);
-              val[e] = u;
-            }
+            for (int e = 0; e < VEC; e++) val[e] = (s * val[e] + t) * g;
+            act_vec<VEC>(val, a.xact);
           }
           VecIO<bf16, VEC>::store(dst, val);
         }
@@ -322,12 +318,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs
         const long long p = (long long)stp * BP + sp;
         const bool pin = live && p < a.P;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float uu = (s * (float)rx[u][i][e] + t) * g;
-          if (a.xact == X3D_ACT_RELU) uu = fmaxf(uu, 0.f);
-          else if (a.xact == X3D_ACT_SWISH) uu = swishf_(uu);
-          v[e] = pin ? uu : 0.f;
-        }
+        for (int e = 0; e < 8; e++) v[e] = (s * (float)rx[u][i][e] + t) * g;
+        act_vec<8>(v, a.xact);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = pin ? v[e] : 0.f;
         VecIO<bf16, 8>::store(dst, v);
       } else {
         *(bf16x8*)dst = rx[u][i];
