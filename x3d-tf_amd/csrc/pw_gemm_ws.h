@@ -12,6 +12,8 @@
 //   wave w computes row blocks w, w+4, ...; each 32x32 result goes through a wave-private LDS slab so the epilogue
 //   (statistics / residual add / swish' with per-(n,c) sums) works on 16-point row pieces with 16-byte accesses.
 #pragma once
+#include <type_traits>
+
 #include "pw_gemm_bf16.h"
 
 #define WS_BN 32
@@ -174,19 +176,25 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) 
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[j] = 0.f;
       bf16x8 A0[G], A1[G];
-      auto loadA = [&](bf16x8 (&A)[G], int ks0) {
+      // a group of G k-steps is either whole (no per-step test, unconditional loads: every group but possibly the last)
+      // or ragged; one uniform branch per GROUP picks the variant -- the per-step tests were 2 scalar branches per MFMA
+      auto loadA = [&](bf16x8 (&A)[G], int ks0, auto FULL) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
-          bf16x8 z;
+          if constexpr (decltype(FULL)::value) {
+            A[j] = *(const bf16x8*)(wrow + (ks0 + j) * 16);
+          } else {
+            bf16x8 z;
 #pragma unroll
-          for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-          A[j] = (ks0 + j < ksteps) ? *(const bf16x8*)(wrow + (ks0 + j) * 16) : z;
+            for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+            A[j] = (ks0 + j < ksteps) ? *(const bf16x8*)(wrow + (ks0 + j) * 16) : z;
+          }
         }
       };
-      auto mmaA = [&](const bf16x8 (&A)[G], int ks0) {
+      auto mmaA = [&](const bf16x8 (&A)[G], int ks0, auto FULL) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
-          if (ks0 + j < ksteps) {
+          if (decltype(FULL)::value || ks0 + j < ksteps) {
             const int kk = (ks0 + j) * 16;
             const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row) * BN + tr_col]));
             const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row + 4) * BN + tr_col]));
@@ -195,12 +203,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) 
           }
         }
       };
-      loadA(A0, 0);
+      auto load_g = [&](bf16x8 (&A)[G], int ks0) {
+        if (ks0 + G <= ksteps) loadA(A, ks0, std::true_type{});
+        else if (ks0 < ksteps) loadA(A, ks0, std::false_type{});
+      };
+      auto mma_g = [&](const bf16x8 (&A)[G], int ks0) {
+        if (ks0 + G <= ksteps) mmaA(A, ks0, std::true_type{});
+        else if (ks0 < ksteps) mmaA(A, ks0, std::false_type{});
+      };
+      load_g(A0, 0);
       for (int ks0 = 0; ks0 < ksteps; ks0 += 2 * G) {
-        loadA(A1, ks0 + G);
-        mmaA(A0, ks0);
-        loadA(A0, ks0 + 2 * G);
-        mmaA(A1, ks0 + G);
+        load_g(A1, ks0 + G);
+        mma_g(A0, ks0);
+        load_g(A0, ks0 + 2 * G);
+        mma_g(A1, ks0 + G);
       }
 
       // ---- epilogue through the wave-private slab: lane -> row lane >> 1, points 16*(lane & 1) .. +15
