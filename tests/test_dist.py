@@ -126,3 +126,73 @@ def test_shard_range_and_schedule():
     for e in (0, 10, 35, 36, 100, 255):
         assert lr_schedule(e, cfg) == pytest.approx(O.lr_schedule(e, cfg))
     assert xd.BucketReducer([torch.zeros(3)]).world == 1       # no process group: single replica, no-ops
+
+
+# ---- the real Trainer, two processes on the GPU (gloo: RCCL refuses two ranks on one device) -----------------------
+def _gpu_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), X3D_DIST_BACKEND="gloo")
+    import x3d_tf_amd as x
+    from x3d_tf_amd import dist as xd
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.train import Trainer
+    r, lr_, w = xd.init_process_group()
+    dev = torch.device(f"cuda:{xd.local_device(lr_)}")
+    torch.cuda.set_device(dev)
+    cfg = x.get_config("XS")
+    m = X3D(cfg, dtype=torch.float32, device=dev, seed=11 + rank)     # different inits: the Trainer must broadcast rank 0's
+    tr = Trainer(m, cfg)
+    torch.manual_seed(5)
+    clips = torch.randn(4, 4, 32, 32, 3)
+    labels = torch.randint(0, 400, (4,))
+    mask = (torch.rand(4, 2048) >= 0.5).float()
+    lo, hi = xd.shard_range(4, rank, world)
+    m.set_dropout_mask(mask[lo:hi])
+    hooks = []
+    orig = tr.reducer.launch
+    tr.reducer.launch = lambda i: (hooks.append(i), orig(i))[1]
+    tr.step(clips[lo:hi].to(dev), labels[lo:hi].to(dev), lr=0.05)
+    torch.cuda.synchronize()
+    torch.save(dict(grads=m.flat_grads.cpu(), params=m.flat_params.cpu(), hooks=hooks), os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_trainer_two_ranks_on_gpu_match_sequential_shards(gpu, tmp_path):
+    """Trainer.step with world_size 2 (real HIP model per rank, bucket hooks fired from the backward plan, gloo exchange)
+    == the two shards run one after the other in one process: summed gradients of the global-mean loss, rank 0's
+    initial variables everywhere, moving statistics averaged, identical updated parameters on both ranks."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.model import X3D
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["hooks"] == [0, 1, 2, 3, 4, 5] and r1["hooks"] == r0["hooks"]      # head, stages 3..0, stem: in backward order
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["params"], r1["params"])
+    # sequential reference: rank 0's initial variables, each shard with its own batch statistics, loss / global batch
+    cfg = x.get_config("XS")
+    torch.manual_seed(5)
+    clips = torch.randn(4, 4, 32, 32, 3)
+    labels = torch.randint(0, 400, (4,))
+    mask = (torch.rand(4, 2048) >= 0.5).float()
+    gsum, moving = None, []
+    for lo, hi in ((0, 2), (2, 4)):
+        m = X3D(cfg, dtype=torch.float32, device=gpu, seed=11)
+        m.set_dropout_mask(mask[lo:hi])
+        m.forward_backward(clips[lo:hi].to(gpu), labels[lo:hi].to(gpu), global_batch=4)
+        torch.cuda.synchronize()
+        gsum = m.flat_grads.cpu().clone() if gsum is None else gsum + m.flat_grads.cpu()
+        moving.append(m.moving_stats_flat().cpu().clone())
+    err = (r0["grads"] - gsum).abs().max().item() / gsum.abs().max().item()
+    assert err < 1e-4, err                                       # fp32 atomics: summation order only
+    nt = m.n_trainable_flat
+    mref = (moving[0] + moving[1]) / 2
+    assert torch.allclose(r0["params"][nt:], mref, rtol=1e-5, atol=1e-6)
+    # the update was applied to rank 0's initial variables with the reduced gradient
+    m0 = X3D(cfg, dtype=torch.float32, device=gpu, seed=11)
+    m0.flat_grads.copy_(gsum.to(gpu))
+    m0.apply_sgd(0.05, cfg.TRAIN.MOMENTUM)
+    torch.cuda.synchronize()
+    assert torch.allclose(r0["params"][:nt], m0.flat_params[:nt].cpu(), rtol=1e-5, atol=1e-6)
