@@ -151,10 +151,13 @@ def test_pw_bwd_fused(gpu, shape):
         report("nc_sums", nc1, nc0.cpu(), 1e-4, 1e-4 * max(1.0, nc0.abs().max().item()))
 
 
-@pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6)])
+@pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6),
+                                   (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7)])
 def test_pw_weights_streamed_path(gpu, shape):
     """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
-    (pw_gemm_ws.h); without a panel the same call runs the resident-panel kernel.  Same bf16 operands and the same
+    (pw_gemm_ws.h) or, for K = 432 -> M <= 192 and K = 192 -> M <= 448, the weights-stationary one (pw_gemm_wst.h:
+    the last shape gives every persistent workgroup several tiles across a sample boundary, the 7x7 ones a ragged
+    last tile); without a panel the same call runs the resident-panel kernel.  Same bf16 operands and the same
     accumulation order over K: outputs bit-identical; statistics / per-(n,c) sums to summation-order tolerance."""
     ops = _ops()
     n, cin, cout, t, h, w = shape
@@ -205,9 +208,14 @@ def test_pw_packed_panels(gpu, shape):
     lib = __import__("x3d_tf_amd").hip.load()
     assert fp.numel() == lib.x3d_pw_panel_elems(cout, cin) and dp.numel() == lib.x3d_pw_panel_elems(cin, cout)
     pitch = (cin + 15) // 16 * 16 + 8
-    img = fp.view(-1, pitch).float().cpu()
+    rows, kp = (cout + 31) // 32 * 32, pitch - 8
+    img = fp[:rows * pitch].view(rows, pitch).float().cpu()
     assert torch.equal(img[:cout, :cin], wt.bfloat16().float().cpu())
     assert img[cout:].abs().sum().item() == 0 and img[:, cin:].abs().sum().item() == 0
+    # second image: [row block][k-step][lane = 32 * half + r][8] = the 32x32x16 MFMA A operand, one 1 KB load per k-step
+    tiled = fp[rows * pitch:].view(rows // 32, kp // 16, 2, 32, 8).float().cpu()
+    want = img[:, :kp].view(rows // 32, 32, kp // 16, 2, 8).permute(0, 2, 3, 1, 4)
+    assert torch.equal(tiled, want)
     x = torch.randn((n, cin, t, h, w), generator=g_).bfloat16().to(gpu)
     ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
     y0 = ops.pw_fwd(x, wt, in_ss=ss, in_act=2)

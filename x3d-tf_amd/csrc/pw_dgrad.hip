@@ -1,5 +1,5 @@
 // x3d_pw_dgrad: pointwise convolution data gradient (see pw_gemm.h)
-#include "pw_gemm_ws.h"
+#include "pw_gemm_wst.h"
 
 template <typename T>
 static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
@@ -39,6 +39,13 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == X3D_F32) return pw_dgrad_dispatch<float>(a, d->epi, vec, st);
   const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
+  if (const int shp = d->epi != X3D_EPI_ADD_STRIDED ? pw_wst_shape(a, vec, ovec) : 0) {   // stage 5: weights stationary
+    switch (d->epi) {
+      case X3D_EPI_STORE: return pw_wst_launch<PRO_BNBWD, X3D_EPI_STORE>(a, shp, st);
+      case X3D_EPI_ADD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_ADD>(a, shp, st);
+      case X3D_EPI_SWISH_BWD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, shp, st);
+    }
+  }
   if (d->epi != X3D_EPI_ADD_STRIDED && pw_ws_applies(a, vec, ovec)) {   // deep, narrow layers (stage 5)
     switch (d->epi) {
       case X3D_EPI_STORE: return pw_ws_launch<PRO_BNBWD, X3D_EPI_STORE>(a, st);

@@ -20,9 +20,12 @@
 #define WS_G 8                 // k-steps per A-operand group (double buffered: 2 * 8 * 4 VGPRs)
 #define WS_OP 36               // slab pitch (floats)
 #define WS_MAXMT 4             // row blocks per wave (M <= 512)
+#ifndef WS_OCC
+#define WS_OCC 2
+#endif
 
 template <int PRO, int EPI>
-__global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) {
+__global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
   constexpr int BN = WS_BN, G = WS_G, OP = WS_OP;
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) 
       const int mi = wid + 4 * i;
       if (mi >= mt) break;
       // ---- 32x32 block mi: A from the packed panel in global memory, groups of G k-steps, double buffered
-      const bf16* wrow = (const bf16*)a.wp + (long long)(mi * 32 + r) * WP + 8 * half;
+      // tiled image behind the row-major one (pw_pack.hip): k-step ks of row block mi = 64 lanes x 16 B, contiguous
+      const bf16* wrow = (const bf16*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * ksteps * 64 + lane) * 8;
       f32x16 acc;
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[j] = 0.f;
@@ -182,12 +186,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_ws_kernel(const PwGemmArgs a) 
 #pragma unroll
         for (int j = 0; j < G; j++) {
           if constexpr (decltype(FULL)::value) {
-            A[j] = *(const bf16x8*)(wrow + (ks0 + j) * 16);
+            A[j] = *(const bf16x8*)(wrow + (ks0 + j) * 512);
           } else {
             bf16x8 z;
 #pragma unroll
             for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-            A[j] = (ks0 + j < ksteps) ? *(const bf16x8*)(wrow + (ks0 + j) * 16) : z;
+            A[j] = (ks0 + j < ksteps) ? *(const bf16x8*)(wrow + (ks0 + j) * 512) : z;
           }
         }
       };

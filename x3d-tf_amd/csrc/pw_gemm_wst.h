@@ -1,0 +1,326 @@
+// Weights-STATIONARY variant of the bf16 pointwise GEMM for the deep, narrow layers (X3D stage 5: 192 <-> 432 channels
+// on 784 points per sample, 50k points per launch at batch 64).
+//
+// The weights-streamed kernel (pw_gemm_ws.h) re-reads its A operand (the weights) from L2 for every 32-point tile; at
+// two workgroups per CU every k-step group, every epilogue load and every staging round exposes its full latency (SQ
+// counters, r01n: instructions active 18-27 % of the wave cycles) and a 62 MB layer takes 52 us.  Here ONE persistent
+// workgroup per CU keeps the weights in REGISTERS for its whole life: wave w owns row blocks w, w + NW, ... (RB of them,
+// KS k-steps x 4 VGPRs each: 108 VGPRs for 432 -> 192, 96 for 192 -> 432), loaded once from the MFMA-operand-tiled
+// panel image (pw_pack.hip: one contiguous 1 KB wave load per k-step).  Per 32-point tile only the streamed operand
+// moves: global -> registers one tile ahead -> (prologue) -> one of TWO LDS tiles, so that the commit of tile t+1
+// follows the MFMAs of tile t with a single barrier per tile; the MFMA loop is KS fully unrolled steps of
+// ds_read_b64_tr_b16 + RB MFMAs with no global access in it.  Epilogue operands (residual / swish' input) are
+// fetched before the MFMA loop.
+#pragma once
+#include "pw_gemm_ws.h"
+
+template <int PRO, int EPI, int NW, int RB, int KS>
+__global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef bf16 T;
+  constexpr int BN = WS_BN, OP = WS_OP, NT = NW * 64, Kp = KS * 16, WP = Kp + 8;
+  constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
+  constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
+  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
+  constexpr int NSV = (Kp * 4 + NT - 1) / NT;             // staging vectors (8 points) per thread
+  bf16* Xs = (bf16*)smem_raw;                                               // [2][Kp][32]
+  float* Cs = (float*)(smem_raw + (size_t)2 * Kp * 64);                     // [Kp][CSW]
+  float* Os = (float*)(smem_raw + (size_t)2 * Kp * 64 + (size_t)Kp * 16);   // [NW waves][32][OP]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int mt = (a.M + 31) >> 5;
+  const int tiles_per_n = (int)((a.P + BN - 1) / BN);
+  const int total_tiles = tiles_per_n * a.N;
+  const int tile_begin = blockIdx.x * a.tiles_per_block;
+  const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
+  if (tile_begin >= tile_end) return;
+  float* myOs = Os + wid * 32 * OP;
+
+  // ---- the stationary operand
+  bf16x8 A[RB][KS];
+#pragma unroll
+  for (int j = 0; j < RB; j++) {
+    const int mi = wid + NW * j;
+    if (mi < mt) {
+      const bf16* wt = (const bf16*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * KS * 64 + lane) * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) A[j][ks] = *(const bf16x8*)(wt + ks * 512);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) A[j][ks][e] = (bf16)0.f;
+    }
+  }
+
+  auto fill_coef = [&](int n) {
+    if constexpr (PRO != PRO_NONE) {
+      for (int k = tid; k < Kp; k += NT) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K) {
+          if constexpr (PRO == PRO_AFFINE) {
+            const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
+            c[0] = a.coef[k * 2] * g;
+            c[1] = a.coef[k * 2 + 1] * g;
+          } else {
+            c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2];
+          }
+        }
+        if constexpr (CSW == 2) *(float2*)&Cs[k * 2] = make_float2(c[0], c[1]);
+        else *(f32x4*)&Cs[k * 4] = c;
+      }
+    }
+  };
+
+  // ---- staging: vector v = tid + NT*i -> row v >> 2, 8 points at unit v & 3.  Loads are unconditional (clamped
+  // address, zero selected afterwards) so that the whole batch is in flight at once.
+  bf16x8 xr[NSV], yr[PRO == PRO_BNBWD ? NSV : 1];
+  auto issue_loads = [&](int tile) {
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = tid + i * NT;
+      const int k = v >> 2;
+      const long long p = p0 + (v & 3) * 8;
+      const bool ok = k < a.K && p < a.P;
+      const long long o = ok ? ((long long)n * a.K + k) * a.P + p : 0;
+      xr[i] = *(const bf16x8*)((const T*)a.x + o);
+      if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+    }
+  };
+  auto commit = [&](int tile, bf16* dstbuf) {
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = tid + i * NT;
+      const int k = v >> 2;
+      if (k >= Kp) continue;
+      const bool ok = k < a.K && p0 + (v & 3) * 8 < a.P;
+      bf16* dst = &dstbuf[k * BN + (v & 3) * 8];
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+      if constexpr (PRO == PRO_NONE) {
+        *(bf16x8*)dst = ok ? xr[i] : z;
+      } else {
+        float val[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) val[e] = (float)xr[i][e];
+        if constexpr (PRO == PRO_AFFINE) {
+          const float2 cf = *(const float2*)&Cs[k * 2];
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] = cf.x * val[e] + cf.y;
+          act_vec<8>(val, a.act);
+        } else {
+          const f32x4 cf = *(const f32x4*)&Cs[k * 4];
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] = cf[0] * val[e] + cf[1] * (float)yr[i][e] + cf[2];
+        }
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) val[e] = 0.f;
+        }
+        VecIO<bf16, 8>::store(dst, val);
+      }
+    }
+  };
+
+  // per-lane partial sums: lane owns row (lane >> 1) of each of this wave's row blocks, 16 points
+  float st1[HAS_SUMS ? RB : 1], st2[HAS_SUMS ? RB : 1];
+  if constexpr (HAS_SUMS) {
+#pragma unroll
+    for (int i = 0; i < RB; i++) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
+  auto flush_sums = [&](int n) {
+    if constexpr (HAS_SUMS) {
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        const int mi = wid + NW * i;
+        const float s1 = st1[i] + dpp_get<0xB1, 0xF>(st1[i]), s2 = st2[i] + dpp_get<0xB1, 0xF>(st2[i]);
+        const int m = mi * 32 + (lane >> 1);
+        if (mi < mt && (lane & 1) == 0 && m < a.M) {
+          if constexpr (EPI == EPI_STATS) {
+            if (a.stats) {
+              double* sp = stats_replica(a.stats, a.M, blockIdx.x);
+              atomic_add_d(&sp[m * 2], (double)s1);
+              atomic_add_d(&sp[m * 2 + 1], (double)s2);
+            }
+          } else {
+            double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
+            atomic_add_d(d, (double)s1);
+            atomic_add_d(d + 1, (double)s2);
+          }
+        }
+        st1[i] = 0.f;
+        st2[i] = 0.f;
+      }
+    }
+  };
+
+  const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_off = (8 * (g16 >> 1) + q) * BN + 16 * (g16 & 1) + 4 * pp;
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const int row = lane >> 1, c0 = 16 * (lane & 1);
+
+  int n_prev = tile_begin / tiles_per_n;
+  fill_coef(n_prev);
+  issue_loads(tile_begin);
+  __syncthreads();
+  commit(tile_begin, Xs);
+  __syncthreads();
+  if (tile_begin + 1 < tile_end) issue_loads(tile_begin + 1);
+
+  int cur = 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile, cur ^= 1) {
+    const int n = tile / tiles_per_n;
+    const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+    if (n != n_prev) {
+      if constexpr (EPI == X3D_EPI_SWISH_BWD) flush_sums(n_prev);
+    }
+    n_prev = n;
+
+    // ---- epilogue operands of this tile, in flight during the MFMAs
+    bf16x8 eo[EPI_LOADS ? RB : 1][2];
+    if constexpr (EPI_LOADS) {
+      const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const int m = (wid + NW * j) * 32 + row;
+#pragma unroll
+        for (int hv = 0; hv < 2; hv++) {
+          const long long p = p0 + c0 + 8 * hv;
+          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.P + p : 0;
+          eo[j][hv] = *(const bf16x8*)(src + o);
+        }
+      }
+    }
+
+    // ---- MFMAs: B operand from the current LDS tile, A from registers
+    const bf16* xb = Xs + cur * (Kp * BN) + tr_off;
+    f32x16 acc[RB];
+#pragma unroll
+    for (int j = 0; j < RB; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb + ks * 16 * BN));
+      const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb + (ks * 16 + 4) * BN));
+      const s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const bf16x8 bv = __builtin_bit_cast(bf16x8, bs);
+#pragma unroll
+      for (int j = 0; j < RB; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][ks], bv, acc[j], 0, 0, 0);
+    }
+
+    // ---- epilogue through the wave-private slab: lane -> row lane >> 1, points 16*(lane & 1) .. +15
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+      const int mi = wid + NW * j;
+      if (mi >= mt) continue;
+#pragma unroll
+      for (int e = 0; e < 16; e++) myOs[((e & 3) + 8 * (e >> 2) + 4 * half) * OP + r] = acc[j][e];
+      const int m = mi * 32 + row;
+      if (m < a.M) {
+        float sb = 0.f, tb = 0.f, gt = 1.f;
+        if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+          sb = a.b_ss[m * 2]; tb = a.b_ss[m * 2 + 1];
+          gt = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+        }
+#pragma unroll
+        for (int hv = 0; hv < 2; hv++) {
+          const long long p = p0 + c0 + 8 * hv;
+          if (p >= a.P) continue;                       // P % 8 == 0: a vector of 8 points is inside or outside
+          const long long o = ((long long)n * a.M + m) * a.P + p;
+          float val[8];
+          {
+            const f32x4 v0 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv], v1 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv + 4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
+          }
+          if constexpr (EPI == X3D_EPI_ADD) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) val[e] += (float)eo[j][hv][e];
+          } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float b = (float)eo[j][hv][e];
+              const float dv = val[e] * swish_grad_((sb * b + tb) * gt);
+              val[e] = dv;
+              st1[j] += dv;
+              st2[j] += dv * b;
+            }
+          }
+          if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { st1[j] += val[e]; st2[j] += val[e] * val[e]; }
+          }
+          VecIO<T, 8>::store((T*)a.y + o, val);
+        }
+      }
+    }
+
+    // ---- the next tile goes into the other LDS tile; one barrier per tile
+    if (tile + 1 < tile_end) {
+      if constexpr (PRO == PRO_AFFINE) {
+        const int n1 = (tile + 1) / tiles_per_n;
+        if (a.gate && n1 != n) {        // every earlier read of the table is behind the previous barrier
+          fill_coef(n1);
+          __syncthreads();
+        }
+      }
+      commit(tile + 1, Xs + (cur ^ 1) * (Kp * BN));
+    }
+    __syncthreads();
+    if (tile + 2 < tile_end) issue_loads(tile + 2);
+  }
+  flush_sums(n_prev);
+}
+
+template <int NW, int KS>
+static inline size_t pw_wst_lds_bytes() {
+  return (size_t)2 * KS * 16 * 64 + (size_t)KS * 16 * 16 + (size_t)NW * 32 * WS_OP * 4;
+}
+
+// shapes with an instantiation: 0 = none, 1 = K 417..432 -> M <= 192 (6 waves x 1 row block x 27 k-steps),
+// 2 = K 177..192 -> M <= 448 (7 waves x 2 row blocks x 12 k-steps)
+static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
+  static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never
+  if (e && atoi(e) == 0) return 0;
+  if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || (a.P % 8) != 0) return 0;
+  const int ks = (a.K + 15) >> 4;
+  if (ks == 27 && a.M <= 192) return 1;
+  if (ks == 12 && a.M <= 448) return 2;
+  return 0;
+}
+
+template <int PRO, int EPI, int NW, int RB, int KS>
+static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
+  a.KC = KS * 16;
+  const size_t lds = pw_wst_lds_bytes<NW, KS>();
+  auto kern = pw_gemm_wst_kernel<PRO, EPI, NW, RB, KS>;
+  static bool attr_set = false;
+  static int cus = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const long long total_tiles = ceil_div_ll(a.P, WS_BN) * a.N;
+  X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_wst: too many tiles");
+  const long long tpb = ceil_div_ll(total_tiles, cus);
+  a.tiles_per_block = (int)tpb;
+  const long long gx = ceil_div_ll(total_tiles, tpb);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NW * 64), lds, st, a);
+  X3D_LAUNCH_CHECK("pw_gemm_wst");
+  return X3D_OK;
+}
+
+template <int PRO, int EPI>
+static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
+  if (shape == 1) return pw_wst_launch_t<PRO, EPI, 6, 1, 27>(a, st);
+  return pw_wst_launch_t<PRO, EPI, 7, 2, 12>(a, st);
+}

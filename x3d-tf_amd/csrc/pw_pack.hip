@@ -7,7 +7,22 @@ static inline int panel_rows(int rows) { return (rows + 31) & ~31; }
 
 extern "C" long long x3d_pw_panel_elems(int rows, int cols) {
   if (rows <= 0 || cols <= 0) return 0;
-  return (long long)panel_rows(rows) * panel_pitch(cols);
+  // row-major LDS image + the MFMA-operand-tiled image the weights-streamed kernel reads (pw_gemm_ws.h)
+  return (long long)panel_rows(rows) * panel_pitch(cols) + (long long)panel_rows(rows) * ((cols + 15) & ~15);
+}
+
+// tiled image: [row block of 32][k-step of 16][lane 0..63][8] -- lane (r, half) holds W[32*mi + r][16*ks + 8*half ..+7],
+// i.e. exactly the A operand of one 32x32x16 MFMA as ONE contiguous 1 KB wave load (the row-major image makes that
+// load touch 32 cache lines and use a quarter of each)
+__device__ inline void pack_tiled(bf16* dst, const float* w, int rows, int Kp, int R, int C, long long sr, long long sc,
+                                  int start, int step) {
+  const int ksteps = Kp >> 4;
+  for (int i = start; i < rows * Kp; i += step) {
+    const int e = i & 7, lane = (i >> 3) & 63, blk = i >> 9;
+    const int mi = blk / ksteps, ks = blk - mi * ksteps;
+    const int r = mi * 32 + (lane & 31), c = ks * 16 + 8 * (lane >> 5) + e;
+    dst[i] = (bf16)((r < R && c < C) ? w[r * sr + c * sc] : 0.f);
+  }
 }
 
 __global__ __launch_bounds__(256) void pw_pack_kernel(const x3d_pw_pack_item* __restrict__ items) {
@@ -20,6 +35,8 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const x3d_pw_pack_item* __
       const int r = i / pitch, c = i - r * pitch;
       dst[i] = (bf16)((r < Cout && c < Cin) ? it.w[(long long)r * Cin + c] : 0.f);
     }
+    pack_tiled(dst + (long long)rows * pitch, it.w, rows, pitch - 8, Cout, Cin, Cin, 1, blockIdx.y * 256 + threadIdx.x,
+               gridDim.y * 256);
   }
   if (it.dgrad_panel) {
     const int pitch = ((Cout + 15) & ~15) + 8, rows = (Cin + 31) & ~31;
@@ -28,6 +45,8 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const x3d_pw_pack_item* __
       const int r = i / pitch, c = i - r * pitch;   // r = ci, c = co
       dst[i] = (bf16)((r < Cin && c < Cout) ? it.w[(long long)c * Cin + r] : 0.f);
     }
+    pack_tiled(dst + (long long)rows * pitch, it.w, rows, pitch - 8, Cin, Cout, 1, Cin, blockIdx.y * 256 + threadIdx.x,
+               gridDim.y * 256);
   }
 }
 
