@@ -14,11 +14,16 @@
 #pragma once
 #include "pw_gemm_ws.h"
 
+// waves per workgroup: all of them stage (two per SIMD: the swish prologue is transcendental-bound VALU work and wants
+// the four SIMDs evenly loaded), the first NW of them own row blocks
+#define WST_NWT 8
+
 template <int PRO, int EPI, int NW, int RB, int KS>
-__global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArgs a) {
+__global__ __launch_bounds__(WST_NWT * 64, 1) void pw_gemm_wst_kernel(const PwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
-  constexpr int BN = WS_BN, OP = WS_OP, NT = NW * 64, Kp = KS * 16, WP = Kp + 8;
+  constexpr int BN = WS_BN, OP = WS_OP, NT = WST_NWT * 64, Kp = KS * 16, WP = Kp + 8;
+  static_assert(NW <= WST_NWT, "MFMA waves are a subset of the workgroup");
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
 #pragma unroll
   for (int j = 0; j < RB; j++) {
     const int mi = wid + NW * j;
-    if (mi < mt) {
+    if (wid < NW && mi < mt) {
       const bf16* wt = (const bf16*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * KS * 64 + lane) * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) A[j][ks] = *(const bf16x8*)(wt + ks * 512);
@@ -74,8 +79,13 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
 
   // ---- staging: vector v = tid + NT*i -> row v >> 2, 8 points at unit v & 3.  Loads are unconditional (clamped
   // address, zero selected afterwards) so that the whole batch is in flight at once.
-  bf16x8 xr[NSV], yr[PRO == PRO_BNBWD ? NSV : 1];
-  auto issue_loads = [&](int tile) {
+  // TWO register sets: the loads of tile t+2 are issued before the commit of tile t+1, so a whole iteration (commit,
+  // epilogue, barrier, MFMAs) covers their latency.  Tiles past the end re-load the last tile (unconditional: the
+  // number of loads in flight stays static and the compiler can wait with an exact vmcnt).
+  constexpr int NSY = PRO == PRO_BNBWD ? NSV : 1;
+  bf16x8 xr0[NSV], yr0[NSY], xr1[NSV], yr1[NSY];
+  auto issue_loads = [&](int tile_, bf16x8 (&xr)[NSV], bf16x8 (&yr)[NSY]) {
+    const int tile = min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
       if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
     }
   };
-  auto commit = [&](int tile, bf16* dstbuf) {
+  auto commit = [&](int tile, bf16* dstbuf, const bf16x8 (&xr)[NSV], const bf16x8 (&yr)[NSY]) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
         const int mi = wid + NW * i;
         const float s1 = st1[i] + dpp_get<0xB1, 0xF>(st1[i]), s2 = st2[i] + dpp_get<0xB1, 0xF>(st2[i]);
         const int m = mi * 32 + (lane >> 1);
-        if (mi < mt && (lane & 1) == 0 && m < a.M) {
+        if (wid < NW && mi < mt && (lane & 1) == 0 && m < a.M) {
           if constexpr (EPI == EPI_STATS) {
             if (a.stats) {
               double* sp = stats_replica(a.stats, a.M, blockIdx.x);
@@ -166,14 +176,15 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
 
   int n_prev = tile_begin / tiles_per_n;
   fill_coef(n_prev);
-  issue_loads(tile_begin);
+  issue_loads(tile_begin, xr0, yr0);
   __syncthreads();
-  commit(tile_begin, Xs);
+  commit(tile_begin, Xs, xr0, yr0);
   __syncthreads();
-  if (tile_begin + 1 < tile_end) issue_loads(tile_begin + 1);
+  issue_loads(tile_begin + 1, xr1, yr1);
+  issue_loads(tile_begin + 2, xr0, yr0);
 
-  int cur = 0;
-  for (int tile = tile_begin; tile < tile_end; ++tile, cur ^= 1) {
+  // one tile: MFMAs of `tile`, commit of tile + 1 out of the register set (xr, yr), re-load that set with tile + 3
+  auto step = [&](int tile, int cur, bf16x8 (&xr)[NSV], bf16x8 (&yr)[NSY]) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     if (n != n_prev) {
@@ -183,6 +194,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
 
     // ---- epilogue operands of this tile, in flight during the MFMAs
     bf16x8 eo[EPI_LOADS ? RB : 1][2];
+    f32x16 acc[RB];
+    if (wid < NW) {
     if constexpr (EPI_LOADS) {
       const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
 #pragma unroll
@@ -199,7 +212,6 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
 
     // ---- MFMAs: B operand from the current LDS tile, A from registers
     const bf16* xb = Xs + cur * (Kp * BN) + tr_off;
-    f32x16 acc[RB];
 #pragma unroll
     for (int j = 0; j < RB; j++)
 #pragma unroll
@@ -214,6 +226,23 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
       for (int j = 0; j < RB; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][ks], bv, acc[j], 0, 0, 0);
     }
 
+    }   // wid < NW
+
+    // ---- the next tile goes into the other LDS tile.  This sits BEFORE the epilogue: the commit waits for the staged
+    // loads with vmcnt, which retires in order and counts stores -- after the epilogue it would also wait for this
+    // tile's output stores, every tile
+    if (tile + 1 < tile_end) {
+      if constexpr (PRO == PRO_AFFINE) {
+        const int n1 = (tile + 1) / tiles_per_n;
+        if (a.gate && n1 != n) {        // every earlier read of the table is behind the previous barrier
+          fill_coef(n1);
+          __syncthreads();
+        }
+      }
+      commit(tile + 1, Xs + (cur ^ 1) * (Kp * BN), xr, yr);
+    }
+
+    if (wid < NW) {
     // ---- epilogue through the wave-private slab: lane -> row lane >> 1, points 16*(lane & 1) .. +15
 #pragma unroll
     for (int j = 0; j < RB; j++) {
@@ -261,19 +290,13 @@ __global__ __launch_bounds__(NW * 64, 1) void pw_gemm_wst_kernel(const PwGemmArg
       }
     }
 
-    // ---- the next tile goes into the other LDS tile; one barrier per tile
-    if (tile + 1 < tile_end) {
-      if constexpr (PRO == PRO_AFFINE) {
-        const int n1 = (tile + 1) / tiles_per_n;
-        if (a.gate && n1 != n) {        // every earlier read of the table is behind the previous barrier
-          fill_coef(n1);
-          __syncthreads();
-        }
-      }
-      commit(tile + 1, Xs + (cur ^ 1) * (Kp * BN));
-    }
-    __syncthreads();
-    if (tile + 2 < tile_end) issue_loads(tile + 2);
+    }   // wid < NW
+    __syncthreads();                    // one barrier per tile
+    issue_loads(tile + 3, xr, yr);
+  };
+  for (int tile = tile_begin; tile < tile_end; tile += 2) {
+    step(tile, 0, xr1, yr1);
+    if (tile + 1 < tile_end) step(tile + 1, 1, xr0, yr0);
   }
   flush_sums(n_prev);
 }
@@ -314,7 +337,7 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   const long long tpb = ceil_div_ll(total_tiles, cus);
   a.tiles_per_block = (int)tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(WST_NWT * 64), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm_wst");
   return X3D_OK;
 }
