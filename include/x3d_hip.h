@@ -198,6 +198,10 @@ int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
  * pointwise weight of the model once per step, in ONE launch, into the exact LDS image:
  *   fwd_panel   bf16 [roundup(Cout,32)][roundup(Cin,16)+8]   row co, column ci   (zero padded)
  *   dgrad_panel bf16 [roundup(Cin,32)][roundup(Cout,16)+8]   row ci, column co   (may be NULL)
+ * each followed by a second image of the same matrix tiled as the 32x32x16 MFMA A operand,
+ *   bf16 [rows/32][roundup(cols,16)/16][64 lanes][8]: lane (r = lane%32, half = lane/32) holds W[32*mi + r][16*ks + 8*half ..+7]
+ * (one contiguous 1 KB wave load per k-step: the weights-stationary stage-5 kernel keeps it in registers).
+ * x3d_pw_panel_elems(rows, cols) is the element count of BOTH images; always size panels with it.
  * `items` is an array in DEVICE memory; x3d_pw_panel_elems gives the element count of a panel. */
 typedef struct {
   const float* w;              /* [Cout][Cin] fp32 */

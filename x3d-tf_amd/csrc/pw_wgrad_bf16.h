@@ -198,7 +198,7 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
 //    elements of 16 contiguous input elements -> two 16-byte loads, no scalar gather.
 // ================================================================================================
 template <int MG, int NG, bool XPRO, int STRIDED>
-__global__ __launch_bounds__(256) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
+__global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
   // U sub-steps of 64 points are staged and multiplied per barrier pair: half the barriers and twice the loads in
@@ -470,6 +470,20 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
     // measured slower (80 -> 100 us), so 128 x 64 stays the default
     static const char* e = getenv("X3D_PW_WG_NG4");
     if (MG == 4 && nt >= 4 && e && atoi(e) == 1) return pw_wgrad_v2_launch<4, 4, XPRO, STRIDED>(a, st);
+  }
+  if constexpr (STRIDED == 0) {
+    // wide layers: every dY (+ yraw) row is staged once per N-group and every X row once per M-group, so the tile shape
+    // sets the traffic: gz * (1 or 2) * Cout + gy * Cin rows of P points.  12-tile shapes (3 tiles per wave) still
+    // fit two workgroups per CU; pick the cheapest of 4x2 / 4x3 / 3x4 (216 x 96: 1056 -> 624 rows, 192 x 432:
+    // 3552 -> 2400, 432 x 192: 3360 -> 2496).
+    static const char* e12 = getenv("X3D_PW_WG_T12");   // A/B switch: 0 = 4x2 only
+    if (MG == 4 && nt >= 3 && !(e12 && atoi(e12) == 0)) {
+      const int dyr = a.coef ? 2 : 1;
+      auto rows = [&](int mg, int ng) { return (long long)ceil_div(nt, ng) * dyr * a.Cout + (long long)ceil_div(mt, mg) * a.Cin; };
+      const long long r42 = rows(4, 2), r43 = rows(4, 3), r34 = rows(3, 4);
+      if (r43 < r42 && r43 <= r34) return pw_wgrad_v2_launch<4, 3, XPRO, STRIDED>(a, st);
+      if (r34 < r42) return pw_wgrad_v2_launch<3, 4, XPRO, STRIDED>(a, st);
+    }
   }
   if (MG == 1) return NG == 1 ? pw_wgrad_v2_launch<1, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<1, 2, XPRO, STRIDED>(a, st);
   if (MG == 2) return NG == 1 ? pw_wgrad_v2_launch<2, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<2, 2, XPRO, STRIDED>(a, st);
