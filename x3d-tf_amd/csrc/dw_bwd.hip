@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   float* scratch = Bl + bplane;
 
   int b = blockIdx.x;
-  const int tile = b % g.ntile_h; b /= g.ntile_h;
-  const int c = b % g.C;
-  const int n = b / g.C;
+  const int tile = __builtin_amdgcn_readfirstlane(b % g.ntile_h); b /= g.ntile_h;
+  const int c = __builtin_amdgcn_readfirstlane(b % g.C);
+  const int n = __builtin_amdgcn_readfirstlane(b / g.C);
   const int h0 = tile * g.TH;
   const int th_here = min(g.TH, g.Ho - h0);
   const int r = threadIdx.x / g.nstrips, sidx = threadIdx.x - r * g.nstrips;
