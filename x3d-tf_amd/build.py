@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libx3d_hip.so")
 SOURCES = ["api.cpp", "pw_fwd.hip", "pw_dgrad.hip", "pw_wgrad.hip", "pw_pack.hip", "pw_bwd_fused.hip", "dw_fwd.hip", "dw_bwd.hip", "dw_pd.hip", "elem.hip", "stem.hip",
            "se.hip", "head.hip", "views.hip"]
-HEADERS = ["common.h", "pw_gemm.h", "pw_gemm_bf16.h", "pw_gemm_ws.h", "pw_wgrad_bf16.h", "dw_common.h", os.path.join("..", "..", "include", "x3d_hip.h")]
+HEADERS = ["common.h", "pw_gemm.h", "pw_gemm_bf16.h", "pw_gemm_ws.h", "pw_gemm_wst.h", "pw_wgrad_bf16.h", "dw_common.h", os.path.join("..", "..", "include", "x3d_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value",
          # hipcc SLP-packs adjacent fp32 mul/add into v_pk_mul + v_pk_add (no FMA, weights no longer SGPR operands):
          # 2.4x the VALU instructions and 2x the VGPRs in the depthwise stencils (measured in the .s)

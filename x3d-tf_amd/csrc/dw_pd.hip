@@ -157,8 +157,11 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
 // ================================================================================================
 // waves per SIMD the register allocator must keep (amdgpu-waves-per-eu): the narrow instantiations fit 128 VGPRs
 // without spilling and are only worth running at 4 waves; the wide ones would spill
+#ifndef DW_S1_OCC
+#define DW_S1_OCC 4
+#endif
 template <int S, int SW, int CV> struct BwdPdWaves {
-  static constexpr int v = (SW == 1 && CV <= 4) || (S == 1 && SW == 2 && CV <= 2) ? 4 : 1;
+  static constexpr int v = (S == 1 && SW == 2 && CV <= 2) ? DW_S1_OCC : ((SW == 1 && CV <= 4) ? 4 : 1);
 };
 template <typename T, int S, int SW, int CV, int PD>
 __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_kernel(const DwBwdArgs a) {
