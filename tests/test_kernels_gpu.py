@@ -325,7 +325,8 @@ def test_pw_dgrad(gpu, dtype, shape, epi):
     (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
     (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),
     (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
-    (2, 96, 216, 2, 8, 8, 1, None), (2, 192, 432, 3, 8, 8, 1, None), (2, 432, 192, 2, 8, 8, 1, "swish"),  # 12-tile groups (4x3 / 3x4)
+    (2, 96, 216, 2, 8, 8, 1, None), (2, 192, 432, 3, 8, 8, 1, None), (2, 432, 192, 2, 8, 8, 1, "swish"),  # wide layers: 12-tile groups (4x3 / 3x4)
+    (2, 192, 432, 8, 7, 7, 1, None), (3, 432, 192, 8, 7, 7, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None),  # ragged last 64-point step
 ])
 def test_pw_wgrad(gpu, dtype, shape):
     ops = _ops()
