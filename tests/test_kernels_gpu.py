@@ -67,7 +67,8 @@ def _affine(x, ss, gate=None, act=0):
     (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
     (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
     (1, 24, 24, 2, 32, 32, 2, None),       # Wo % 8 == 0
-    (2, 432, 192, 2, 8, 8, 1, "swish"), (2, 192, 432, 2, 8, 8, 1, None), (1, 440, 200, 1, 8, 5, 1, "relu"),  # weights-streamed path
+    (2, 432, 192, 2, 8, 8, 1, "swish"), (2, 192, 432, 2, 8, 8, 1, None), (1, 440, 200, 1, 8, 5, 1, "relu"),  # weights-streamed / -stationary paths
+    (2, 216, 96, 2, 14, 14, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None), (2, 200, 90, 1, 8, 8, 1, "relu"),  # stage-4 weights-stationary shapes (two workgroups per CU)
 ])
 def test_pw_fwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
@@ -152,12 +153,13 @@ def test_pw_bwd_fused(gpu, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6),
-                                   (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7)])
+                                   (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7),
+                                   (2, 216, 96, 2, 14, 14), (2, 96, 216, 2, 14, 14), (24, 216, 96, 8, 14, 14), (2, 210, 90, 1, 8, 8)])
 def test_pw_weights_streamed_path(gpu, shape):
     """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
     (pw_gemm_ws.h) or, for K = 432 -> M <= 192 and K = 192 -> M <= 448, the weights-stationary one (pw_gemm_wst.h:
-    the last shape gives every persistent workgroup several tiles across a sample boundary, the 7x7 ones a ragged
-    last tile); without a panel the same call runs the resident-panel kernel.  Same bf16 operands and the same
+    (40, ...) and (24, ...) give every persistent workgroup several tiles across a sample boundary, the 7x7 ones a
+    ragged last tile; K = 216 -> M <= 96 and K = 96 -> M <= 224 are the stage-4 forward instantiations); without a panel the same call runs the resident-panel kernel.  Same bf16 operands and the same
     accumulation order over K: outputs bit-identical; statistics / per-(n,c) sums to summation-order tolerance."""
     ops = _ops()
     n, cin, cout, t, h, w = shape

@@ -18,8 +18,8 @@
 // the four SIMDs evenly loaded), the first NW of them own row blocks
 #define WST_NWT 8
 
-template <int PRO, int EPI, int NW, int RB, int KS>
-__global__ __launch_bounds__(WST_NWT * 64, 1) void pw_gemm_wst_kernel(const PwGemmArgs a) {
+template <int PRO, int EPI, int NW, int RB, int KS, int OCC>
+__global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef bf16 T;
   constexpr int BN = WS_BN, OP = WS_OP, NT = WST_NWT * 64, Kp = KS * 16, WP = Kp + 8;
@@ -307,22 +307,27 @@ static inline size_t pw_wst_lds_bytes() {
 }
 
 // shapes with an instantiation: 0 = none, 1 = K 417..432 -> M <= 192 (6 waves x 1 row block x 27 k-steps),
-// 2 = K 177..192 -> M <= 448 (7 waves x 2 row blocks x 12 k-steps)
+// 2 = K 177..192 -> M <= 448 (7 waves x 2 row blocks x 12 k-steps); stage 4, two workgroups per CU (<= 128 VGPRs: one
+// workgroup's prologue overlaps the other's MFMAs): 3 = K 209..224 -> M <= 96 (3 x 1 x 14), 4 = K 81..96 -> M <= 224
+// (7 x 1 x 6)
 static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
-  static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never
+  static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never, 1 = stage 5 only
   if (e && atoi(e) == 0) return 0;
   if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || (a.P % 8) != 0) return 0;
   const int ks = (a.K + 15) >> 4;
   if (ks == 27 && a.M <= 192) return 1;
   if (ks == 12 && a.M <= 448) return 2;
+  if (e && atoi(e) == 1) return 0;
+  if (ks == 14 && a.M <= 96) return 3;
+  if (ks == 6 && a.M <= 224) return 4;
   return 0;
 }
 
-template <int PRO, int EPI, int NW, int RB, int KS>
+template <int PRO, int EPI, int NW, int RB, int KS, int OCC>
 static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   a.KC = KS * 16;
   const size_t lds = pw_wst_lds_bytes<NW, KS>();
-  auto kern = pw_gemm_wst_kernel<PRO, EPI, NW, RB, KS>;
+  auto kern = pw_gemm_wst_kernel<PRO, EPI, NW, RB, KS, OCC>;
   static bool attr_set = false;
   static int cus = 256;
   if (!attr_set) {
@@ -334,7 +339,7 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   }
   const long long total_tiles = ceil_div_ll(a.P, WS_BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_wst: too many tiles");
-  const long long tpb = ceil_div_ll(total_tiles, cus);
+  const long long tpb = ceil_div_ll(total_tiles, (long long)cus * OCC);
   a.tiles_per_block = (int)tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(WST_NWT * 64), lds, st, a);
@@ -344,6 +349,10 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
 
 template <int PRO, int EPI>
 static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
-  if (shape == 1) return pw_wst_launch_t<PRO, EPI, 6, 1, 27>(a, st);
-  return pw_wst_launch_t<PRO, EPI, 7, 2, 12>(a, st);
+  switch (shape) {
+    case 1: return pw_wst_launch_t<PRO, EPI, 6, 1, 27, 1>(a, st);
+    case 2: return pw_wst_launch_t<PRO, EPI, 7, 2, 12, 1>(a, st);
+    case 3: return pw_wst_launch_t<PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
+    default: return pw_wst_launch_t<PRO, EPI, 7, 1, 6, 2>(a, st);
+  }
 }
