@@ -182,7 +182,7 @@ def main():
     lr = cfg.TRAIN.WARMUP_LR
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
 
     for _ in range(max(args.warmup, 1)):
@@ -243,7 +243,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.variant, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

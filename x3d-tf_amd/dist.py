@@ -33,15 +33,26 @@ def local_device(local_rank: int) -> int:
     return local_rank % n
 
 
+def _rehearse() -> bool:
+    """X3D_DIST_REHEARSE=1: run every collective even with ONE rank (a one-GPU box then exercises the real RCCL
+    communicator, the bucketed asynchronous all-reduces and their stream ordering; the sums are identities)."""
+    return os.environ.get("X3D_DIST_REHEARSE") == "1"
+
+
+def _active(group=None) -> bool:
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _rehearse())
+
+
 def init_process_group(backend: Optional[str] = None):
     """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE if WORLD_SIZE > 1."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _rehearse()) and not dist.is_initialized():
         if backend is None:
             # X3D_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
             # (RCCL refuses two ranks on one device; gloo stages device tensors through the host)
             backend = os.environ.get("X3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.cuda.set_device(local_device(local_rank))
@@ -69,10 +80,11 @@ class BucketReducer:
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = _active(group)
         self._work: List = []
 
     def launch(self, i: int):
-        if self.world == 1:
+        if not self.active:
             return
         self._work.append(dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -84,21 +96,21 @@ class BucketReducer:
 
 def broadcast_(tensors: Sequence[torch.Tensor], src: int = 0, group=None):
     """Make every replica start from rank `src`'s values (mirrored-variable initialisation)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         for t in tensors:
             dist.broadcast(t, src=src, group=group)
 
 
 def mean_(t: torch.Tensor, group=None):
     """In-place mean over replicas (mirrored-variable MEAN aggregation of BN moving statistics) [TF-3p]."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(dist.get_world_size(group))
     return t
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -878,8 +878,9 @@ class X3D:
 
         global_batch: divisor of the loss mean (defaults to the local batch; data-parallel callers pass
             world_size * local batch so that summing gradients over ranks gives the global mean).
-        on_stage_done(stage): called as soon as every gradient of ``stage`` (4 = head, 3..0 = stages,
-            -1 = stem) is final on the stream -- the hook gradient all-reduce buckets attach to.
+        on_stage_done(stage): called with "fwd" once the forward pass is on the stream, then as soon as every
+            gradient of ``stage`` (4 = head, 3..0 = stages, -1 = stem) is final on the stream -- the hook gradient
+            all-reduce buckets attach to.
         """
         n, t, h, w, _ = input.shape
         pl = self._plan(n, t, h, w, True)
@@ -896,6 +897,7 @@ class X3D:
         if on_stage_done is None:
             pl.run(pl.bwd)
         else:
+            on_stage_done("fwd")      # forward (and the BN moving-statistics updates in it) is on the stream
             marks = sorted(pl.bwd_stage_marks.items(), key=lambda kv: kv[1])
             start = 0
             for stage, stop in marks:
