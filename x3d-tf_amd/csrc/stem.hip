@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x
 template <int SEGS>
 __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                               bf16* __restrict__ y, int Cin, int Cout, int Tn, int H,
-                                                              int W, int Ho, int Wo, int nws, long long total_segs,
+                                                              int W, int Ho, int Wo, int nws, int total_segs,
                                                               int segs_per_block) {
   static_assert(SEGS == 4, "one wave per segment");
   constexpr int LP = SEGS * 64 + 32;        // 576 B pitch = 64 mod 256: the transposed read is conflict-free
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int ntap = Cin * 9;
-  const long long seg_begin = (long long)blockIdx.x * segs_per_block;
-  const long long seg_end = min(seg_begin + segs_per_block, total_segs);
+  // segment indices fit 32 bits (host check): the (n, t, ho, ws) decomposition is four 32-bit divisions per segment
+  // instead of 64-bit ones (each a ~100-instruction sequence, eight of them per iteration)
+  const int seg_begin = blockIdx.x * segs_per_block;
+  const int seg_end = min(seg_begin + segs_per_block, total_segs);
   for (int i = tid; i < 32 * LP / 8; i += 256) {
     bf16x8 z;
 #pragma unroll
@@ -94,20 +96,20 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
   const bool xrow_ok = xrow < Cin * 3;
   bf16x8 rx[SEGS];
   bf16 rl[SEGS];
-  auto issue = [&](long long s0) {
+  auto issue = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
-      const long long seg = s0 + q;
+      const int seg = s0 + q;
       bf16x8 z;
 #pragma unroll
       for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
       rx[q] = z; rl[q] = (bf16)0.f;
       if (seg >= seg_end) continue;
-      const int ws = (int)(seg % nws);
-      long long tmp = seg / nws;
-      const int ho = (int)(tmp % Ho); tmp /= Ho;
-      const int t = (int)(tmp % Tn);
-      const int n = (int)(tmp / Tn);
+      const int ws = seg % nws;
+      int tmp = seg / nws;
+      const int ho = tmp % Ho; tmp /= Ho;
+      const int t = tmp % Tn;
+      const int n = tmp / Tn;
       const int wo0 = ws * 64;
       const int hi = 2 * ho + xkh - 1;
       if (xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
@@ -143,12 +145,12 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
   float* myOs = Os + wid * 32 * OP;
 
   if (seg_begin < seg_end) issue(seg_begin);
-  for (long long s0 = seg_begin; s0 < seg_end; s0 += SEGS) {
+  for (int s0 = seg_begin; s0 < seg_end; s0 += SEGS) {
     __syncthreads();
     commit();
     __syncthreads();
     if (s0 + SEGS < seg_end) issue(s0 + SEGS);
-    const long long seg = s0 + wid;
+    const int seg = s0 + wid;
     f32x16 acc[2];
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
     }
     // the slab is private to the wave: its own LDS writes are visible to it after the wait the compiler inserts
     if (seg < seg_end) {
-      const int ws = (int)(seg % nws);
-      long long tmp = seg / nws;
-      const int ho = (int)(tmp % Ho); tmp /= Ho;
-      const int t = (int)(tmp % Tn);
-      const int n = (int)(tmp / Tn);
+      const int ws = seg % nws;
+      int tmp = seg / nws;
+      const int ho = tmp % Ho; tmp /= Ho;
+      const int t = tmp % Tn;
+      const int n = tmp / Tn;
       const int wo0 = ws * 64;
       // 32 rows x 8 vectors of 8 points = 256 vectors per wave, 4 per lane: row = i*8 + lane/8, vector = lane & 7
 #pragma unroll
@@ -212,9 +214,9 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
     if (spb2 < 4 * SEGS) spb2 = 4 * SEGS;
     spb2 = ceil_div_ll(spb2, SEGS) * SEGS;
     const long long gx2 = ceil_div_ll(total_segs, spb2);
-    X3D_REQUIRE(gx2 < (1ll << 31), "stem_s_fwd: grid too large");
+    X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_fwd: too many row segments");
     hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x, w, (bf16*)y,
-                       Cin, Cout, T, H, W, Ho, Wo, nws, total_segs, (int)spb2);
+                       Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
     X3D_LAUNCH_CHECK("stem_s_fwd");
     return X3D_OK;
   }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_kernel(const T* __restrict__
 template <int SEGS>
 __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                                 float* dw, int Cin, int Cout, int Tn, int H, int W,
-                                                                int Ho, int Wo, int nws, long long total_segs,
+                                                                int Ho, int Wo, int nws, int total_segs,
                                                                 int segs_per_block) {
   static_assert(SEGS == 4, "one wave per segment");
   constexpr int LP = SEGS * 64 + 8;
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int ntap = Cin * 9;
-  const long long seg_begin = (long long)blockIdx.x * segs_per_block;
-  const long long seg_end = min(seg_begin + segs_per_block, total_segs);
+  const int seg_begin = blockIdx.x * segs_per_block;      // 32-bit segment arithmetic (host check), as in the forward
+  const int seg_end = min(seg_begin + segs_per_block, total_segs);
   for (int i = tid; i < 32 * LP / 8; i += 256) {
     bf16x8 z;
 #pragma unroll
@@ -343,21 +345,21 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
   bf16x8 rd[SEGS], rx[SEGS];
   bf16 rl[SEGS];
   bool okd[SEGS], okx[SEGS];
-  auto issue = [&](long long s0) {
+  auto issue = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
-      const long long seg = s0 + q;
+      const int seg = s0 + q;
       bf16x8 z;
 #pragma unroll
       for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
       rd[q] = z; rx[q] = z; rl[q] = (bf16)0.f;
       okd[q] = false; okx[q] = false;
       if (seg >= seg_end) continue;
-      const int ws = (int)(seg % nws);
-      long long tmp = seg / nws;
-      const int ho = (int)(tmp % Ho); tmp /= Ho;
-      const int t = (int)(tmp % Tn);
-      const int n = (int)(tmp / Tn);
+      const int ws = seg % nws;
+      int tmp = seg / nws;
+      const int ho = tmp % Ho; tmp /= Ho;
+      const int t = tmp % Tn;
+      const int n = tmp / Tn;
       const int wo0 = ws * 64;
       {  // dY: this thread's vector (row, v) of segment q is item tid of the segment's 256
         const int row = tid >> 3, v = tid & 7;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
   };
 
   if (seg_begin < seg_end) issue(seg_begin);
-  for (long long s0 = seg_begin; s0 < seg_end; s0 += SEGS) {
+  for (int s0 = seg_begin; s0 < seg_end; s0 += SEGS) {
     __syncthreads();
     commit();
     __syncthreads();
@@ -458,8 +460,9 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
     spb2 = ceil_div_ll(spb2, SEGS) * SEGS;
     const long long gx2 = ceil_div_ll(total_segs, spb2);
     X3D_REQUIRE(gx2 < (1ll << 31), "stem_s_wgrad: grid too large");
+    X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_wgrad: too many row segments");
     hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x,
-                       (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, total_segs, (int)spb2);
+                       (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
     X3D_LAUNCH_CHECK("stem_s_wgrad");
     return X3D_OK;
   }
