@@ -150,9 +150,9 @@ __device__ __forceinline__ void strided_gather16(const bf16* base, long long p, 
                                                  bf16x8& lo, bf16x8& hi) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-  const long long hw = (long long)Ho * Wo;
-  long long t = p / hw;
-  const int rem = (int)(p - t * hw);
+  const int hw = Ho * Wo;                  // p < 2^31 (per-sample point index): 32-bit divisions
+  long long t = (int)p / hw;
+  const int rem = (int)p - (int)t * hw;
   int ho = rem / Wo, wo = rem - ho * Wo;
   unsigned int w[8];
 #pragma unroll

@@ -270,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 #pragma unroll
         for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
         if (ok && epl4_vec) {
-          const long long hw = (long long)a.eH * a.eW;
+          const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
           const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-          const long long T_ = a.P / hw;
-          const long long t = p / hw;
-          const int rem = (int)(p - t * hw);
+          const int T_ = (int)a.P / hw;
+          const int t = (int)p / hw;
+          const int rem = (int)p - t * hw;
           const int h = rem / a.eW, w = rem - h * a.eW;
           if ((h & 1) == 0)
             epl4[i] = *(const bf16x4*)((const T*)a.add + ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
@@ -319,17 +319,17 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] += (float)epl8[i][e];
         } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
-          const long long hw = (long long)a.eH * a.eW;
+          const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
           const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-          const long long T_ = a.P / hw;
+          const int T_ = (int)a.P / hw;
           if (epl4_vec) {   // loaded above (zeros on odd rows)
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           } else {
             for (int e = 0; e < 8; e++) {
-              const long long pe = p + e;
-              const long long t = pe / hw;
-              const int rem = (int)(pe - t * hw);
+              const int pe = (int)p + e;
+              const int t = pe / hw;
+              const int rem = pe - t * hw;
               const int h = rem / a.eW, w = rem - h * a.eW;
               if (((h | w) & 1) == 0) {
                 const long long oa = ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
@@ -456,7 +456,7 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
   // slicing Ci re-stages the dY tile once per slice: worth it up to ~4 slices (x3d_pw_dgrad does the same per row block)
   if (ceil_div(ceil_div(b->Cin, 32), MT) > 4) return false;
   const long long P = (long long)b->T * b->H * b->W;
-  if (P % 8) return false;
+  if (P % 8 || P >= (1ll << 31)) return false;      // 32-bit point indices in the kernel
   const void* ps[] = {b->g, b->yraw, b->dx, b->w_panel, b->epi == X3D_EPI_SWISH_BWD ? b->braw : b->x,
                       b->epi == X3D_EPI_ADD ? b->add : nullptr};
   for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;

@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         if (ok) {
           long long src = p;
           if constexpr (STRIDED) {
-            const long long hw = (long long)a.Ho * a.Wo;
-            const long long t = p / hw;
-            const int rem = (int)(p - t * hw);
+            const int hw = a.Ho * a.Wo;
+            const int t = (int)p / hw;
+            const int rem = (int)p - t * hw;
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+            src = ((long long)t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
           }
           const long long o = ((long long)n * a.K + gk) * a.Pin + src;
           xs1[i] = to_f<T>(((const T*)a.x)[o]);
@@ -382,36 +382,36 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
           if (epl4_vec && m < a.M && p < a.P) {
-            const long long hw = (long long)a.eH * a.eW;
+            const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-            const long long T_ = a.P / hw;
+            const int T_ = (int)a.P / hw;
             const T* abase = (const T*)a.add + ((long long)n * a.M + m) * T_ * Hh * Wh;
             if (egv == 8) {
               // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
-              const long long t = p / hw;
-              const int rem = (int)(p - t * hw);
+              const int t = (int)p / hw;
+              const int rem = (int)p - t * hw;
               const int h = rem / a.eW, w = rem - h * a.eW;
-              if ((h & 1) == 0) epl4[i] = *(const bf16x4*)(abase + (t * Hh + (h >> 1)) * Wh + (w >> 1));
+              if ((h & 1) == 0) epl4[i] = *(const bf16x4*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
             } else if (egv == 4) {
 #pragma unroll
               for (int gq = 0; gq < 2; gq++) {
-                const long long pe = p + 4 * gq;
-                const long long t = pe / hw;
-                const int rem = (int)(pe - t * hw);
+                const int pe = (int)p + 4 * gq;
+                const int t = pe / hw;
+                const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
                 if ((h & 1) == 0) {
-                  const bf16x2 v2 = *(const bf16x2*)(abase + (t * Hh + (h >> 1)) * Wh + (w >> 1));
+                  const bf16x2 v2 = *(const bf16x2*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
                   epl4[i][2 * gq] = v2[0]; epl4[i][2 * gq + 1] = v2[1];
                 }
               }
             } else {
 #pragma unroll
               for (int gq = 0; gq < 4; gq++) {
-                const long long pe = p + 2 * gq;
-                const long long t = pe / hw;
-                const int rem = (int)(pe - t * hw);
+                const int pe = (int)p + 2 * gq;
+                const int t = pe / hw;
+                const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
-                if ((h & 1) == 0) epl4[i][gq] = abase[(t * Hh + (h >> 1)) * Wh + (w >> 1)];
+                if ((h & 1) == 0) epl4[i][gq] = abase[((long long)t * Hh + (h >> 1)) * Wh + (w >> 1)];
               }
             }
           }
@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           for (int e = 0; e < nvalid; e++) val[e] += to_f<T>(((const T*)a.add)[o + e]);
         }
       } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
-        const long long hw = (long long)a.eH * a.eW;
+        const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-        const long long T_ = a.P / hw;
+        const int T_ = (int)a.P / hw;
         if (epl4_vec) {
           if constexpr (EPL4) {   // loaded above (zeros on odd rows)
 #pragma unroll
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           }
         } else
         for (int e = 0; e < nvalid; e++) {
-          const long long pe = p + e;
-          const long long t = pe / hw;
-          const int rem = (int)(pe - t * hw);
+          const int pe = (int)p + e;
+          const int t = pe / hw;
+          const int rem = pe - t * hw;
           const int h = rem / a.eW, w = rem - h * a.eW;
           if (((h | w) & 1) == 0) {
             const long long oa = ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);

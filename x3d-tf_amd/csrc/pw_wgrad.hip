@@ -198,6 +198,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   a.Ho = ceil_div(w->H, w->stride); a.Wo = ceil_div(w->W, w->stride);
   a.Pin = (long long)w->T * w->H * w->W;
   a.P = (long long)w->T * a.Ho * a.Wo;
+  X3D_REQUIRE(a.Pin < (1ll << 31) && a.P < (1ll << 31), "pw_wgrad: more than 2^31 points per sample");   // 32-bit point indices in the kernels
   const bool xpro = w->in_scale_shift != nullptr;
   X3D_REQUIRE(xpro || (!w->in_gate && w->in_act == X3D_ACT_NONE), "pw_wgrad: prologue needs in_scale_shift");
   const int eb = w->dtype == X3D_F32 ? 4 : 2;
