@@ -42,9 +42,11 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
   // stage 5: weights stationary.  The stage-4 shapes stay with the resident-panel kernel here: with two staged tensors
   // the stationary kernel needs 132-146 VGPRs = one workgroup per CU (216 -> 96 dgrad: 58 -> 61 us)
-  const int shp_ = d->epi != X3D_EPI_ADD_STRIDED ? pw_wst_shape(a, vec, ovec) : 0;
+  // (strided shortcut gradient: even image width only -- pairs of points never straddle a row)
+  const int shp_ = (d->epi != X3D_EPI_ADD_STRIDED || (d->W % 2 == 0 && ((uintptr_t)d->add % 2) == 0)) ? pw_wst_shape(a, vec, ovec) : 0;
   if (const int shp = shp_ <= 2 ? shp_ : 0) {
     switch (d->epi) {
+      case X3D_EPI_ADD_STRIDED: return pw_wst_launch<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, shp, st);
       case X3D_EPI_STORE: return pw_wst_launch<PRO_BNBWD, X3D_EPI_STORE>(a, shp, st);
       case X3D_EPI_ADD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_ADD>(a, shp, st);
       case X3D_EPI_SWISH_BWD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, shp, st);

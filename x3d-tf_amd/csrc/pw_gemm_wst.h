@@ -195,7 +195,29 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     // ---- epilogue operands of this tile, in flight during the MFMAs
     bf16x8 eo[EPI_LOADS ? RB : 1][2];
     f32x16 acc[RB];
+    bf16 es[EPI == X3D_EPI_ADD_STRIDED ? RB : 1][2][4];      // strided shortcut gradient: one value per even pixel
     if (wid < NW) {
+    if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
+      // dx [eH x eW] receives `add` [ceil(eH/2) x ceil(eW/2)] on its even pixels.  eW is even (dispatch): the 8 points of
+      // a vector are four pairs inside one image row each, the first of a pair on an even column.  32-bit index maths.
+      const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.P / hw;
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const int m = (wid + NW * j) * 32 + row;
+        const T* abase = (const T*)a.add + ((long long)n * a.M + min(m, a.M - 1)) * T_ * Hh * Wh;
+#pragma unroll
+        for (int hv = 0; hv < 2; hv++)
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++) {
+            const int pe = (int)p0 + c0 + 8 * hv + 2 * gq;
+            const int t = pe / hw, rem = pe - t * hw;
+            const int h = rem / a.eW, w = rem - h * a.eW;
+            const bool ok = m < a.M && pe < (int)a.P && (h & 1) == 0;
+            const bf16 v = abase[ok ? (t * Hh + (h >> 1)) * Wh + (w >> 1) : 0];
+            es[j][hv][gq] = ok ? v : (bf16)0.f;
+          }
+      }
+    }
     if constexpr (EPI_LOADS) {
       const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
 #pragma unroll
@@ -271,6 +293,9 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
           if constexpr (EPI == X3D_EPI_ADD) {
 #pragma unroll
             for (int e = 0; e < 8; e++) val[e] += (float)eo[j][hv][e];
+          } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) val[2 * gq] += (float)es[j][hv][gq];
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
