@@ -155,7 +155,7 @@ def test_pw_bwd_fused(gpu, shape):
 @pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6),
                                    (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7),
                                    (2, 216, 96, 2, 14, 14), (2, 96, 216, 2, 14, 14), (24, 216, 96, 8, 14, 14), (2, 210, 90, 1, 8, 8),
-                                   (3, 96, 432, 4, 14, 14), (20, 96, 432, 16, 14, 14)])   # stage-5 block 0: dgrad K = 432 -> M = 96 with the strided add
+                                   (3, 96, 432, 4, 14, 14), (20, 96, 432, 16, 14, 14)])   # (forward: K = 96 -> M = 432)   # stage-5 block 0: dgrad K = 432 -> M = 96 with the strided add
 def test_pw_weights_streamed_path(gpu, shape):
     """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
     (pw_gemm_ws.h) or, for K = 432 -> M <= 192 and K = 192 -> M <= 448, the weights-stationary one (pw_gemm_wst.h:

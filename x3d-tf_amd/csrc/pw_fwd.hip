@@ -31,7 +31,8 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
   // bf16 storage: bf16 matrix cores (fp32 accumulate)
   const int ovec = pick_vec(eb, a.P, f->y);
-  if (const int shp = pw_wst_shape(a, vec, ovec))   // stage 5: weights stationary in registers, one workgroup per CU
+  const int shp_ = pw_wst_shape(a, vec, ovec);       // stage 4 / 5: weights stationary in registers
+  if (const int shp = (shp_ == 5 && pro) ? 0 : shp_)  // (shape 5 with a prologue: 129 VGPRs, one workgroup per CU)
     return pro ? pw_wst_launch<PRO_AFFINE, EPI_STATS>(a, shp, st) : pw_wst_launch<PRO_NONE, EPI_STATS>(a, shp, st);
   if (pw_ws_applies(a, vec, ovec))   // deep, narrow layers (stage 5): weights streamed, 32-point tiles
     return pro ? pw_ws_launch<PRO_AFFINE, EPI_STATS>(a, st) : pw_ws_launch<PRO_NONE, EPI_STATS>(a, st);

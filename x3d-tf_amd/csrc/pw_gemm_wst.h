@@ -334,7 +334,7 @@ static inline size_t pw_wst_lds_bytes() {
 // shapes with an instantiation: 0 = none, 1 = K 417..432 -> M <= 192 (6 waves x 1 row block x 27 k-steps),
 // 2 = K 177..192 -> M <= 448 (7 waves x 2 row blocks x 12 k-steps); stage 4, two workgroups per CU (<= 128 VGPRs: one
 // workgroup's prologue overlaps the other's MFMAs): 3 = K 209..224 -> M <= 96 (3 x 1 x 14), 4 = K 81..96 -> M <= 224
-// (7 x 1 x 6)
+// (7 x 1 x 6), 5 = K 81..96 -> M <= 448 (7 x 2 x 6)
 static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never, 1 = stage 5 only
   if (e && atoi(e) == 0) return 0;
@@ -345,6 +345,7 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   if (e && atoi(e) == 1) return 0;
   if (ks == 14 && a.M <= 96) return 3;
   if (ks == 6 && a.M <= 224) return 4;
+  if (ks == 6 && a.M <= 448) return 5;     // stage-5 block 0 `a` conv: 96 -> 432 (7 x 2 x 6)
   return 0;
 }
 
@@ -378,6 +379,7 @@ static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
     case 1: return pw_wst_launch_t<PRO, EPI, 6, 1, 27, 1>(a, st);
     case 2: return pw_wst_launch_t<PRO, EPI, 7, 2, 12, 1>(a, st);
     case 3: return pw_wst_launch_t<PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
-    default: return pw_wst_launch_t<PRO, EPI, 7, 1, 6, 2>(a, st);
+    case 4: return pw_wst_launch_t<PRO, EPI, 7, 1, 6, 2>(a, st);
+    default: return pw_wst_launch_t<PRO, EPI, 7, 2, 6, 2>(a, st);
   }
 }
