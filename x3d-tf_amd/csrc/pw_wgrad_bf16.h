@@ -450,6 +450,9 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   // every workgroup of a (y, z) tile group adds into the SAME dW tile: past ~500 workgroups per group the fp32 atomics on
   // a few hundred addresses are the bound (48 x 24 @ 28x28: 96 us with 1255 workgroups, 85 us with 392)
   if (ceil_div_ll(total_steps, spb) > 512) spb = ceil_div_ll(total_steps, 512);
+  // 12-tile groups flush 12 K fp32 atomics per workgroup: 216 x 96 @ 14x14 with 242 workgroups per group 64 us, with
+  // 157 (20 steps each) 58 us; the stage-5 layers (61 per group) are unaffected
+  if (MG * NG > 8 && ceil_div_ll(total_steps, spb) > 160) spb = ceil_div_ll(total_steps, 160);
   static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
   if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
   a.steps_per_block = (int)spb;
