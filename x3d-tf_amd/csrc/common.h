@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/x3d_hip.h"
@@ -189,6 +190,12 @@ static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
 // and launch publishes scale_shift / mean_invstd and updates the moving statistics.
 // ---------------------------------------------------------------------------------------------
 // Replicated statistics accumulators (include/x3d_hip.h): STATS_R copies of [C][2] doubles, stats_stride(C) apart.
+// A/B switch X3D_XCD_PAD=0: do not pad grid.x to a multiple of the XCD count (see pw_bwd_fused.hip, pw_wgrad_bf16.h)
+static inline bool xcd_pad_enabled() {
+  static const char* e = getenv("X3D_XCD_PAD");
+  return !(e && atoi(e) == 0);
+}
+
 #define STATS_R 32
 __host__ __device__ __forceinline__ long long stats_stride(int C) {
   const long long need = ((long long)C * 2 + 63) & ~63ll;

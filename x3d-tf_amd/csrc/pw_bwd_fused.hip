@@ -416,7 +416,11 @@ static int fb_launch(PwBwdArgs& a, hipStream_t st) {
   long long tpb = ceil_div_ll(total_tiles * gy, slots);   // one balanced round
   if (tpb < 4) tpb = 4;                               // keeps the dW atomics (<= 32 KB) small against the streamed tiles
   a.tiles_per_block = (int)tpb;
-  const long long gx = ceil_div_ll(total_tiles, tpb);
+  long long gx = ceil_div_ll(total_tiles, tpb);
+  // workgroups go to the 8 XCDs round-robin by linear index x + gx * y: with gx a multiple of 8 the slices (blockIdx.y)
+  // of one point-tile range share an XCD -- and its L2 -- so the dY / yraw tiles they all stage are fetched once
+  // (surplus workgroups find no tiles and leave)
+  if (gy > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_fused");
   return X3D_OK;

@@ -456,7 +456,8 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
   if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
   a.steps_per_block = (int)spb;
-  const long long gx = ceil_div_ll(total_steps, spb);
+  long long gx = ceil_div_ll(total_steps, spb);
+  if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
   return X3D_OK;
