@@ -21,8 +21,11 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: must be set before HIP initialises
 
 import torch
 
@@ -159,9 +162,26 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Invoked directly with --gpus N: start the N ranks as CHILD processes (torchrun, one rank per GPU) and exit with
+        # their status.  Nothing in this process has touched the GPU yet (torch.cuda.device_count() does not initialise
+        # HIP), and the parent never does: a process that initialised the GPU must not be replaced or forked.
+        have = torch.cuda.device_count()
+        if have < args.gpus and os.environ.get("X3D_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node (one process per GPU); "
+                             "refusing to time fewer GPUs than asked for")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     rank, local_rank, world = xdist.init_process_group()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` directly, which starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     device = torch.device(f"cuda:{xdist.local_device(local_rank)}")
@@ -229,6 +249,7 @@ def main():
                                    f"{args.dtype} activation storage / fp32 arithmetic, random-init weights",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": loss,
+            "collectives": trainer.collective_stats(),
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,

@@ -7,8 +7,9 @@
  *
  * Conventions
  *  - Plain pointers and sizes only.  Every pointer is DEVICE memory unless marked host.
- *  - Activations are NCTHW, contiguous, element type `dtype` (X3D_F32 or X3D_BF16).  Arithmetic,
- *    weights, per-channel coefficients and reductions are fp32 (statistics accumulate in fp64).
+ *  - Activations are NCTHW, contiguous, element type `dtype` (X3D_F32, X3D_BF16 or X3D_F16).  Arithmetic,
+ *    weights, per-channel coefficients and reductions are fp32 (statistics accumulate in fp64); with a 16-bit
+ *    `dtype` the pointwise GEMM operands are rounded to that type for the matrix cores (fp32 accumulation).
  *  - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing allocates,
  *    nothing synchronises; functions are re-entrant.
  *  - Return value: X3D_OK, or an error code with a message in x3d_last_error() (thread local).
@@ -31,6 +32,7 @@ extern "C" {
 
 #define X3D_F32 0
 #define X3D_BF16 1
+#define X3D_F16 2   /* IEEE half: the reference's only reduced-precision mode (Keras mixed_float16, utils.py:176-192) */
 
 #define X3D_ACT_NONE 0
 #define X3D_ACT_RELU 1
@@ -210,7 +212,7 @@ typedef struct {
   int Cout, Cin;
 } x3d_pw_pack_item;
 long long x3d_pw_panel_elems(int rows, int cols);
-int x3d_pw_pack_weights(const x3d_pw_pack_item* items, int n_items, void* stream);
+int x3d_pw_pack_weights(const x3d_pw_pack_item* items, int n_items, int dtype /* X3D_BF16 or X3D_F16: element type of the panels */, void* stream);
 
 /* weight gradient: dw [Cout][Cin] += sum_{n,p} dYraw[n][co][p] * act_in(x)[n][ci][q(p)] */
 typedef struct {
@@ -225,6 +227,13 @@ typedef struct {
   int N, Cin, Cout, T, H, W, stride, dtype; /* T,H,W: INPUT extents (as in fwd) */
 } x3d_pw_wgrad_args;
 int x3d_pw_wgrad(const x3d_pw_wgrad_args* a, void* stream);
+
+/* Which kernel instantiation a pointwise launch with these arguments runs ("pw_gemm_wst_kernel<1, 100, 6, 1, 27, 1>", ...),
+ * without launching anything: the dispatch of x3d_pw_fwd / x3d_pw_dgrad / x3d_pw_wgrad / x3d_pw_bwd in dry-run mode (works
+ * without a GPU; pointers are only inspected for alignment).  Exactly one struct is non-NULL.  Used by the dispatch-coverage
+ * test (every instantiation the BASELINE configurations launch has an oracle-parity case) and by the profiling tools. */
+int x3d_pw_kernel_name(const x3d_pw_fwd_args* fwd, const x3d_pw_dgrad_args* dgrad, const x3d_pw_wgrad_args* wgrad,
+                       const x3d_pw_bwd_args* bwd, char* out, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * K6  channelwise Conv3D(k=(3,3,3), s=(1,s,s), padding='same', groups=C, no bias)
@@ -338,7 +347,8 @@ int x3d_dense_bwd(const float* dy, const float* y, int act, const float* x, cons
                   int M, void* stream);
 /* probs = softmax(logits); loss_rows[n] = -log q_y + log sum_j q_j with q = clip(p,1e-7,1-1e-7)
  * (tf.keras SparseCategoricalCrossentropy on probabilities, train.py:104); dlogits = d(mean loss)/dlogits
- * scaled by grad_scale (= 1/global_batch).  labels int32; loss_rows / dlogits may be NULL. */
+ * scaled by grad_scale (= 1/global_batch).  labels int32; loss_rows / dlogits may be NULL.  A label outside
+ * [0, M) is never used as an index: its loss row is NaN and its dlogits row zero. */
 int x3d_softmax_xent(const float* logits, const int* labels, float* probs, float* loss_rows,
                      float* dlogits, float grad_scale, int N, int M, void* stream);
 /* out[v][m] = mean over `views` consecutive rows (model.py:123-126) */
@@ -351,6 +361,14 @@ int x3d_view_mean(const float* probs, float* out, int videos, int views, int M, 
  * ------------------------------------------------------------------------------------------ */
 int x3d_sgd_nesterov(float* w, float* v, const float* g, const unsigned char* l2_mask, float lr,
                      float momentum, float weight_decay, float grad_scale, long long n, void* stream);
+/* Adam, the reference's other optimizer branch (tf.optimizers.Adam(learning_rate), train.py:93-95; Keras defaults
+ * beta1 0.9, beta2 0.999, eps 1e-7):  g' as above; m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2;
+ * w -= lr * sqrt(1 - b2^step) / (1 - b1^step) * m / (sqrt(v) + eps).  `step` counts from 1. */
+int x3d_adam(float* w, float* m, float* v, const float* g, const unsigned char* l2_mask, float lr, float beta1,
+             float beta2, float eps, float weight_decay, float grad_scale, long long step, long long n, void* stream);
+/* LossScaleOptimizer support (Keras mixed_float16, train.py:99-100): *flag (device int the caller set to 1) is cleared
+ * when any of the n values is inf / nan -- the step is then skipped and the loss scale halved. */
+int x3d_all_finite(const float* g, long long n, int* flag, void* stream);
 /* sum of squares of the masked entries (L2 regularisation loss term), out [1] double += */
 int x3d_l2_sumsq(const float* w, const unsigned char* l2_mask, double* out, long long n, void* stream);
 

@@ -1,0 +1,183 @@
+"""Shapes of the `-m gpu` oracle-parity cases, as data.
+
+tests/test_kernels_gpu.py and tests/test_model_gpu.py parametrise over these lists; tests/test_dispatch_coverage.py
+(CPU) asks the library's dry-run dispatch which kernel instantiation every case runs and asserts that every
+instantiation the BASELINE configurations launch at full size appears among them.  A case belongs here only if its GPU
+test compares the kernel with the CPU oracle / an fp64 restatement (not with another device kernel).
+"""
+import torch
+
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
+DTYPES = [F32, BF16, F16]
+HALF_DTYPES = [BF16, F16]
+
+# ---- x3d_pw_fwd: N, Cin, Cout, T, H, W, stride, prologue ------------------------------------------------------------
+PW_FWD = [
+    (2, 24, 54, 4, 12, 12, 1, None),       # bottleneck a (stage 2 widths)
+    (2, 54, 24, 3, 10, 10, 1, "swish"),    # bottleneck c with BN_b + SE gate + swish folded
+    (2, 24, 48, 4, 12, 12, 2, None),       # strided shortcut (valid, samples pixels 0,2,..)
+    (1, 48, 108, 13, 5, 5, 1, "relu"),     # P = 325 (odd): scalar path
+    (2, 96, 216, 2, 7, 7, 1, None),        # Cout > 128: two row blocks
+    (1, 216, 96, 2, 7, 7, 1, "swish"),     # K chunking (does not fit LDS resident)
+    (1, 24, 24, 2, 9, 11, 2, None),        # odd extents with stride 2
+    (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
+    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
+    (1, 24, 24, 2, 32, 32, 2, None),       # Wo % 8 == 0
+    (2, 432, 192, 2, 8, 8, 1, "swish"), (2, 192, 432, 2, 8, 8, 1, None), (1, 440, 200, 1, 8, 5, 1, "relu"),  # weights-streamed / -stationary paths
+    (2, 216, 96, 2, 14, 14, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None), (2, 200, 90, 1, 8, 8, 1, "relu"),  # stage-4 weights-stationary shapes (two workgroups per CU)
+    (2, 96, 432, 2, 14, 14, 1, None),      # stage-5 block 0 `a` conv (7 waves x 2 row blocks x 6 k-steps)
+    (1, 24, 24, 1, 156, 156, 2, None), (1, 24, 48, 1, 78, 78, 2, None), (1, 48, 96, 2, 39, 39, 2, None),   # X3D-L / XL shortcuts
+    (1, 96, 192, 2, 20, 20, 2, None),
+    (1, 96, 192, 8, 14, 14, 2, None), (1, 24, 48, 8, 78, 78, 2, None),   # odd Wo with P % 8 == 0: gather group 1 on the vector path
+    (1, 24, 24, 8, 156, 156, 2, None),                                   # Wo = 78: gather group 2
+    (1, 24, 54, 1, 32, 32, 1, None), (1, 108, 48, 1, 16, 16, 1, "swish"), (1, 48, 108, 1, 16, 16, 1, None),  # aligned stage-2/3 layers
+    (1, 24, 108, 1, 16, 16, 1, None), (1, 48, 216, 1, 16, 16, 1, None),
+]
+# X3D-XL widths (configs/kinetics/X3D_XL.yaml: width factor 2.9, bottleneck 2.25): 32/72, 72/162, 136/306, 280/630, conv5 630
+PW_FWD_XL = [
+    (1, 32, 72, 1, 16, 16, 1, None), (1, 72, 32, 1, 16, 16, 1, "swish"), (1, 32, 32, 1, 16, 16, 2, None),
+    (1, 32, 162, 1, 16, 16, 1, None), (1, 162, 72, 1, 8, 8, 1, "swish"), (1, 72, 162, 1, 8, 8, 1, None), (1, 32, 72, 1, 16, 16, 2, None),
+    (1, 72, 306, 1, 8, 8, 1, None), (1, 306, 136, 1, 8, 8, 1, "swish"), (1, 136, 306, 1, 8, 8, 1, None), (1, 72, 136, 1, 16, 16, 2, None),
+    (1, 136, 630, 1, 8, 8, 1, None), (1, 630, 280, 1, 8, 8, 1, "swish"), (1, 280, 630, 1, 8, 8, 1, None), (1, 136, 280, 1, 16, 16, 2, None),
+    (1, 32, 72, 8, 78, 78, 2, None), (1, 32, 32, 8, 156, 156, 2, None),
+]
+
+# ---- x3d_pw_dgrad: N, Cin, Cout, T, H, W  x  epilogue -----------------------------------------------------------------
+PW_DGRAD = [
+    (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
+    (1, 216, 96, 2, 7, 7), (1, 200, 40, 1, 4, 8),
+    (1, 54, 24, 4, 14, 14), (1, 48, 108, 2, 28, 28),   # strided add with rows of 2k / 4k points (pair / quad groups)
+    (1, 192, 432, 2, 8, 8), (1, 432, 192, 2, 8, 8), (1, 96, 192, 2, 8, 8), (1, 96, 432, 2, 14, 14),   # stage-5 weights-stationary dgrads
+    (1, 24, 48, 1, 16, 16), (1, 48, 96, 1, 16, 16), (1, 48, 216, 1, 16, 16),
+]
+PW_DGRAD_EPI = ["store", "add", "add_strided", "swish_bwd"]
+
+# ---- x3d_pw_wgrad: N, Cin, Cout, T, H, W, stride, prologue --------------------------------------------------------------
+PW_WGRAD = [
+    (2, 24, 54, 4, 12, 12, 1, None), (2, 54, 24, 3, 10, 10, 1, "swish"), (2, 24, 48, 4, 12, 12, 2, None),
+    (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
+    (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),
+    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
+    (2, 96, 216, 2, 8, 8, 1, None), (2, 192, 432, 3, 8, 8, 1, None), (2, 432, 192, 2, 8, 8, 1, "swish"),  # wide layers: 12-tile groups (4x3 / 3x4)
+    (2, 192, 432, 8, 7, 7, 1, None), (3, 432, 192, 8, 7, 7, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None),  # ragged last 64-point step
+    (1, 24, 24, 2, 32, 32, 2, None), (1, 48, 216, 1, 16, 16, 1, None), (1, 24, 24, 1, 156, 156, 2, None),
+    (1, 24, 48, 1, 78, 78, 2, None), (1, 48, 96, 2, 39, 39, 2, None), (1, 96, 192, 2, 20, 20, 2, None),
+    (1, 96, 192, 8, 14, 14, 2, None), (1, 24, 48, 8, 78, 78, 2, None), (1, 24, 24, 8, 156, 156, 2, None),
+    (1, 48, 108, 1, 16, 16, 1, None), (1, 108, 48, 1, 16, 16, 1, "swish"),
+]
+
+# ---- x3d_pw_bwd (fused dgrad + wgrad): N, Cin, Cout, T, H, W, epilogue ---------------------------------------------------
+PW_BWD = [
+    (2, 24, 54, 4, 16, 16, "add"), (2, 48, 108, 2, 28, 28, "add"), (1, 24, 108, 3, 16, 16, "add_strided"),
+    (2, 24, 54, 2, 28, 28, "add_strided"),
+    (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
+    (1, 96, 32, 2, 10, 12, "swish_bwd"),
+    (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv
+    (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
+    (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
+]
+
+# ---- x3d_dw3d_fwd / x3d_dw3d_bwd: N, C, T, H, W, stride --------------------------------------------------------------------
+DW = [
+    (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2),       # even, SW=2
+    (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),         # 7x7 planes, SW=1
+    (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1),       # X3D-L odd case 39 -> 20 (pads 1/1)
+    (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),     # X3D-M stage-2 planes, SW=4, H-tiled
+    (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1),        # T=1 / non-square / odd widths
+    (1, 2, 16, 28, 28, 1),                            # vec 4 path for bf16
+    (2, 3, 16, 14, 14, 1), (1, 2, 6, 7, 7, 1),        # deep-prefetch variants (dw_pd.hip): T = 4k, T % 4 != 0,
+    (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),         #   T < depth, stride 2
+    (1, 2, 4, 28, 28, 2),                             # X3D-M stage-4 first block (216 ch 28 -> 14): <2, 2, 2, 4> in bf16
+    (1, 2, 3, 56, 56, 2),                             # X3D-M stage-3 first block (56 -> 28)
+    (1, 2, 3, 156, 156, 2), (1, 2, 3, 78, 78, 1), (1, 2, 3, 78, 78, 2), (1, 2, 3, 39, 39, 1),   # X3D-L / XL planes (16 x 312 x 312 clips)
+    (1, 2, 3, 20, 20, 2), (1, 2, 3, 10, 10, 1), (1, 2, 3, 80, 80, 2), (1, 2, 3, 40, 40, 1), (1, 2, 3, 40, 40, 2),  # + X3D-S planes
+    (1, 2, 3, 10, 10, 2), (1, 2, 3, 5, 5, 1),
+]
+
+# ---- whole-model cases (tests/test_model_gpu.py): variant, N, T, S --------------------------------------------------------
+MODEL_TRAIN_FP32 = [
+    ("XS", 4, 4, 64), ("S", 2, 13, 64), ("M", 2, 4, 64), ("S", 3, 5, 96),
+    ("XS", 2, 4, 78),     # odd extents end to end: 78 -> 39 -> 20 -> 10 -> 5 -> 3 (X3D-L's 39 -> 20 TF-SAME pads, odd stride-2 planes)
+    ("M", 2, 16, 112),    # T = 16 and 56 / 28 / 14 / 7 planes: the deep-prefetch depthwise variants (dw_pd.hip) inside the model
+    ("S", 1, 2, 160),     # BASELINE config 2's real planes (80 / 40 / 20 / 10 / 5)
+]
+MODEL_TRAIN_HALF = [     # teacher-forced block by block, bf16 and fp16 storage
+    ("S", 3, 5, 96),      # odd point counts: scalar / generic kernel paths
+    ("M", 2, 4, 128),     # every P a multiple of 8, 16-byte aligned rows: the fast paths the benchmark runs
+    ("XL", 2, 4, 64),     # XL widths (72/162/306/630...: off the 32-grid, K > 432), 55 blocks, SE parity across stages
+    ("L", 1, 2, 312),     # BASELINE config 4's real planes: 156 / 78 / 39 / 20 / 10 (odd 39 -> 20)
+]
+MODEL_INFER = [           # variant, views, crops, T, S, dtype
+    ("XS", 10, 1, 4, 160, F32), ("S", 2, 1, 13, 96, F32),
+    ("XL", 10, 3, 2, 96, F32), ("XL", 10, 3, 2, 96, F16), ("XL", 10, 3, 2, 96, BF16),   # BASELINE config 5: 30 views per video
+]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# argument structs of the kernel-level cases over address-only operands (the dry-run dispatch only looks at alignment)
+# ----------------------------------------------------------------------------------------------------------------------
+class _Addr:
+    nxt = 0x5000_0000_0000
+
+    @classmethod
+    def new(cls):
+        cls.nxt += 1 << 32
+        return cls.nxt
+
+
+def _code(dtype):
+    from x3d_tf_amd import hip
+    return hip.dtype_code(dtype)
+
+
+def pw_fwd_struct(shape, dtype, panel):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w, stride, pro = shape
+    A = _Addr.new
+    return hip.PwFwdArgs(A(), A(), A(), A(), A() if pro else None, A() if pro == "swish" else None,
+                         {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, stride, _code(dtype),
+                         A() if panel else None)
+
+
+def pw_dgrad_struct(shape, epi, dtype, panel):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w = shape
+    A = _Addr.new
+    e = PW_DGRAD_EPI.index(epi)
+    sw = epi == "swish_bwd"
+    return hip.PwDgradArgs(A(), A(), A(), A(), A(), e, A() if epi in ("add", "add_strided") else None,
+                           A() if sw else None, A() if sw else None, A() if sw else None, A() if sw else None,
+                           n, cin, cout, t, h, w, _code(dtype), A() if panel else None)
+
+
+def pw_wgrad_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w, stride, pro = shape
+    A = _Addr.new
+    return hip.PwWgradArgs(A(), A(), A(), A(), A() if pro else None, A() if pro else None, 2 if pro else 0, A(),
+                           n, cin, cout, t, h, w, stride, _code(dtype))
+
+
+def pw_bwd_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w, epi = shape
+    A = _Addr.new
+    e = PW_DGRAD_EPI.index(epi)
+    sw = epi == "swish_bwd"
+    return hip.PwBwdArgs(A(), A(), A(), A(), A(), e, None if sw else A(), A() if sw else None, A() if sw else None,
+                         A() if sw else None, A() if sw else None, None if sw else A(), A(), n, cin, cout, t, h, w,
+                         _code(dtype))
+
+
+def dw_fwd_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, c, t, h, w, stride = shape
+    A = _Addr.new
+    return hip.Dw3dFwdArgs(A(), A(), A(), A(), 1, A(), A(), n, c, t, h, w, stride, _code(dtype))
+
+
+def dw_bwd_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, c, t, h, w, stride = shape
+    A = _Addr.new
+    return hip.Dw3dBwdArgs(A(), A(), A(), A(), A(), A(), A(), A(), A(), n, c, t, h, w, stride, _code(dtype))

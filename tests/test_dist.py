@@ -196,3 +196,20 @@ def test_trainer_two_ranks_on_gpu_match_sequential_shards(gpu, tmp_path):
     m0.apply_sgd(0.05, cfg.TRAIN.MOMENTUM)
     torch.cuda.synchronize()
     assert torch.allclose(r0["params"][:nt], m0.flat_params[:nt].cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_refuses_to_time_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` started directly (no torchrun environment) launches its own ranks as child processes --
+    and on a node with fewer than 2 GPUs it exits non-zero instead of silently timing one GPU."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a node with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "X3D_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "GPU" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout          # no benchmark line was printed

@@ -8,11 +8,13 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import report, rnd, tol_for
+from tests import shapes as S
+from tests.util import report, rnd, tol_for, tol_store
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = S.DTYPES            # fp32, bf16, fp16 activation storage
+HALF = S.HALF_DTYPES
 
 
 def _ops():
@@ -34,7 +36,7 @@ def _gen(seed=0):
 def _stol(dtype):
     """tolerance of the epilogue sums.  They are taken from the fp32 values BEFORE the store rounds them; for bf16
     storage they equal the sums of the stored tensor only to ~2^-9/sqrt(count) (unbiased rounding)."""
-    return 1e-5 if dtype == torch.float32 else 3e-3
+    return 1e-5 if dtype == torch.float32 else (3e-3 if dtype == torch.bfloat16 else 5e-4)
 
 
 def _stats_ref(y, dtype):
@@ -54,23 +56,19 @@ def _affine(x, ss, gate=None, act=0):
 
 
 # --------------------------------------------------------------------------------------------------
+def _panels(ops, wt, dtype, gpu):
+    (fp, dp), = ops.pw_pack_weights([wt.to(gpu)], dtype=dtype)
+    return fp, dp
+
+
+@pytest.mark.parametrize("panel", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [
-    # N, Cin, Cout, T, H, W, stride, prologue
-    (2, 24, 54, 4, 12, 12, 1, None),       # bottleneck a (stage 2 widths)
-    (2, 54, 24, 3, 10, 10, 1, "swish"),    # bottleneck c with BN_b + SE gate + swish folded
-    (2, 24, 48, 4, 12, 12, 2, None),       # strided shortcut (valid, samples pixels 0,2,..)
-    (1, 48, 108, 13, 5, 5, 1, "relu"),     # P = 325 (odd): scalar path
-    (2, 96, 216, 2, 7, 7, 1, None),        # Cout > 128: two row blocks
-    (1, 216, 96, 2, 7, 7, 1, "swish"),     # K chunking (does not fit LDS resident)
-    (1, 24, 24, 2, 9, 11, 2, None),        # odd extents with stride 2
-    (1, 200, 40, 1, 4, 8, 1, "swish"),     # widths off the 32-grid
-    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
-    (1, 24, 24, 2, 32, 32, 2, None),       # Wo % 8 == 0
-    (2, 432, 192, 2, 8, 8, 1, "swish"), (2, 192, 432, 2, 8, 8, 1, None), (1, 440, 200, 1, 8, 5, 1, "relu"),  # weights-streamed / -stationary paths
-    (2, 216, 96, 2, 14, 14, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None), (2, 200, 90, 1, 8, 8, 1, "relu"),  # stage-4 weights-stationary shapes (two workgroups per CU)
-])
-def test_pw_fwd(gpu, dtype, shape):
+@pytest.mark.parametrize("shape", S.PW_FWD + S.PW_FWD_XL)
+def test_pw_fwd(gpu, dtype, shape, panel):
+    """x3d_pw_fwd against the oracle's pointwise conv.  panel=True passes the packed weight panel, as model.py always does
+    for 16-bit storage: that is the production dispatch (weights-stationary / weights-streamed / resident-panel kernels)."""
+    if panel and dtype == torch.float32:
+        pytest.skip("weight panels exist for the 16-bit storage types only")
     ops, O = _ops(), _oracle()
     n, cin, cout, t, h, w, stride, pro = shape
     g = _gen(1)
@@ -87,8 +85,9 @@ def test_pw_fwd(gpu, dtype, shape):
         xin = _affine(xd, ss.double(), None if gate is None else gate.double(), act)
     ref = O.pointwise(xin, wt.double(), stride)
     stats = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+    fp = _panels(ops, wt, dtype, gpu)[0] if panel else None
     y = ops.pw_fwd(x.to(gpu), wt.to(gpu), stats=stats, in_ss=None if ss is None else ss.to(gpu),
-                   in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride)
+                   in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride, w_panel=fp)
     torch.cuda.synchronize()
     rt, at = tol_for(dtype)
     scale = ref.abs().max().item()
@@ -98,24 +97,77 @@ def test_pw_fwd(gpu, dtype, shape):
     report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
-@pytest.mark.parametrize("shape", [
-    # N, Cin, Cout, T, H, W, epi                 (a conv: Cin = block input, Cout = inner; c conv: Cin = inner, Cout = out)
-    (2, 24, 54, 4, 16, 16, "add"), (2, 48, 108, 2, 28, 28, "add"), (1, 24, 108, 3, 16, 16, "add_strided"),
-    (2, 24, 54, 2, 28, 28, "add_strided"),
-    (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
-    (1, 96, 32, 2, 10, 12, "swish_bwd"),
-    (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv: Cin sliced over blockIdx.y (4 slices of 64)
-    (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
-])
-def test_pw_bwd_fused(gpu, shape):
+def _dyraw(coef, gd, yd):
+    c = coef.double()
+    return c[:, 0].view(1, -1, 1, 1, 1) * gd + c[:, 1].view(1, -1, 1, 1, 1) * yd + c[:, 2].view(1, -1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", S.PW_BWD)
+def test_pw_bwd_oracle(gpu, dtype, shape):
+    """x3d_pw_bwd (fused data + weight gradient, one pass over dY) against an fp64 restatement of both gradients --
+    directly, not through the unfused kernels (test_pw_bwd_fused below keeps the bit-for-bit comparison with those)."""
+    ops = _ops()
+    n, cin, cout, t, h, w, epi = shape
+    g_ = _gen(31)
+    gy, gyd = rnd((n, cout, t, h, w), dtype, g_)
+    yraw, yrd = rnd((n, cout, t, h, w), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    dy = _dyraw(coef, gyd, yrd)
+    dx_ref = torch.einsum("oc,nothw->ncthw", wt.double(), dy)
+    dp = _panels(ops, wt, dtype, gpu)[1]
+    dx = torch.empty((n, cin, t, h, w), dtype=dtype, device=gpu)
+    dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)     # += semantics
+    dev = lambda v: v.to(gpu)
+    if epi == "swish_bwd":
+        braw, bd = rnd((n, cin, t, h, w), dtype, g_)
+        bss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1)
+        gate = torch.rand((n, cin), generator=g_)
+        v = _affine(bd, bss.double(), gate.double(), 0)
+        sg = torch.sigmoid(v)
+        dx_ref = dx_ref * (sg * (1 + v * (1 - sg)))
+        xin = v * sg                                                      # the conv input: swish(gate * bn_b(braw))
+        ncs = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+        ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, ops.EPI_SWISH_BWD, braw=dev(braw), b_ss=dev(bss),
+                        gate=dev(gate), nc_sums=ncs)
+    else:
+        x, xd = rnd((n, cin, t, h, w), dtype, g_)
+        xin = xd
+        if epi == "add":
+            add, addd = rnd((n, cin, t, h, w), dtype, g_)
+            dx_ref = dx_ref + addd
+            e = ops.EPI_ADD
+        else:
+            add, addd = rnd((n, cin, t, (h + 1) // 2, (w + 1) // 2), dtype, g_)
+            up = torch.zeros_like(dx_ref)
+            up[:, :, :, ::2, ::2] = addd
+            dx_ref = dx_ref + up
+            e = ops.EPI_ADD_STRIDED
+        ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, e, x=dev(x), add=dev(add))
+    torch.cuda.synchronize()
+    assert ok, "fused kernel should cover this shape"
+    rt, at = tol_for(dtype)
+    report("dx", dx, dx_ref, rt, at * dx_ref.abs().max().item())
+    dw_ref = torch.einsum("nothw,ncthw->oc", dy, xin)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1.5e-3        # both GEMM operands rounded to the storage type, fp32 accumulation
+    report("dw", dw, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
+    if epi == "swish_bwd":
+        dvs = dx.float().cpu().double()
+        sref = torch.stack([dvs.sum((2, 3, 4)), (dvs * bd).sum((2, 3, 4))], -1)
+        report("nc_sums", ncs, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
+
+
+@pytest.mark.parametrize("bf", HALF)
+@pytest.mark.parametrize("shape", S.PW_BWD)   # N, Cin, Cout, T, H, W, epi   (a conv: Cin = block input, Cout = inner; c conv: Cin = inner, Cout = out)
+def test_pw_bwd_fused(gpu, shape, bf):
     """x3d_pw_bwd (one pass over dY) against x3d_pw_dgrad + x3d_pw_wgrad: dx bit-identical (same bf16 operands,
     same accumulation order over Cout), dw and the per-(n,c) sums to fp32 summation-order tolerance."""
     ops = _ops()
     n, cin, cout, t, h, w, epi = shape
     g_ = _gen(21)
-    bf = torch.bfloat16
     wt = (torch.randn((cout, cin), generator=g_) * 0.2).to(gpu)
-    (fp, dp), = ops.pw_pack_weights([wt])
+    (fp, dp), = ops.pw_pack_weights([wt], dtype=bf)
     gy = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
     yraw = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
     coef = (torch.randn((cout, 4), generator=g_) * 0.5).to(gpu)
@@ -156,7 +208,8 @@ def test_pw_bwd_fused(gpu, shape):
                                    (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7),
                                    (2, 216, 96, 2, 14, 14), (2, 96, 216, 2, 14, 14), (24, 216, 96, 8, 14, 14), (2, 210, 90, 1, 8, 8),
                                    (3, 96, 432, 4, 14, 14), (20, 96, 432, 16, 14, 14)])   # (forward: K = 96 -> M = 432)   # stage-5 block 0: dgrad K = 432 -> M = 96 with the strided add
-def test_pw_weights_streamed_path(gpu, shape):
+@pytest.mark.parametrize("bf", HALF)
+def test_pw_weights_streamed_path(gpu, shape, bf):
     """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
     (pw_gemm_ws.h) or, for K = 432 -> M <= 192 and K = 192 -> M <= 448, the weights-stationary one (pw_gemm_wst.h:
     (40, ...) and (24, ...) give every persistent workgroup several tiles across a sample boundary, the 7x7 ones a
@@ -165,9 +218,8 @@ def test_pw_weights_streamed_path(gpu, shape):
     ops = _ops()
     n, cin, cout, t, h, w = shape
     g_ = _gen(41)
-    bf = torch.bfloat16
     wt = (torch.randn((cout, cin), generator=g_) * 0.1).to(gpu)
-    (fp, dp), = ops.pw_pack_weights([wt])
+    (fp, dp), = ops.pw_pack_weights([wt], dtype=bf)
     x = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
     ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
     gate = torch.rand((n, cin), generator=g_).to(gpu)
@@ -202,31 +254,32 @@ def test_pw_weights_streamed_path(gpu, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 54, 4, 16, 16), (1, 96, 216, 2, 14, 14), (2, 200, 72, 2, 7, 7), (1, 432, 192, 3, 7, 7)])
-def test_pw_packed_panels(gpu, shape):
+@pytest.mark.parametrize("bf", HALF)
+def test_pw_packed_panels(gpu, shape, bf):
     """bf16 GEMMs fed from x3d_pw_pack_weights panels give bit-identical results to the in-kernel fp32->bf16
     conversion (same rounded weights, same accumulation order), forward and dgrad, incl. row tiles past M."""
     ops = _ops()
     n, cin, cout, t, h, w = shape
     g_ = _gen(11)
     wt = (torch.randn((cout, cin), generator=g_) * 0.2).to(gpu)
-    (fp, dp), = ops.pw_pack_weights([wt])
+    (fp, dp), = ops.pw_pack_weights([wt], dtype=bf)
     lib = __import__("x3d_tf_amd").hip.load()
     assert fp.numel() == lib.x3d_pw_panel_elems(cout, cin) and dp.numel() == lib.x3d_pw_panel_elems(cin, cout)
     pitch = (cin + 15) // 16 * 16 + 8
     rows, kp = (cout + 31) // 32 * 32, pitch - 8
     img = fp[:rows * pitch].view(rows, pitch).float().cpu()
-    assert torch.equal(img[:cout, :cin], wt.bfloat16().float().cpu())
+    assert torch.equal(img[:cout, :cin], wt.to(bf).float().cpu())
     assert img[cout:].abs().sum().item() == 0 and img[:, cin:].abs().sum().item() == 0
     # second image: [row block][k-step][lane = 32 * half + r][8] = the 32x32x16 MFMA A operand, one 1 KB load per k-step
     tiled = fp[rows * pitch:].view(rows // 32, kp // 16, 2, 32, 8).float().cpu()
     want = img[:, :kp].view(rows // 32, 32, kp // 16, 2, 8).permute(0, 2, 3, 1, 4)
     assert torch.equal(tiled, want)
-    x = torch.randn((n, cin, t, h, w), generator=g_).bfloat16().to(gpu)
+    x = torch.randn((n, cin, t, h, w), generator=g_).to(bf).to(gpu)
     ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1).to(gpu)
     y0 = ops.pw_fwd(x, wt, in_ss=ss, in_act=2)
     y1 = ops.pw_fwd(x, wt, in_ss=ss, in_act=2, w_panel=fp)
-    gy = torch.randn((n, cout, t, h, w), generator=g_).bfloat16().to(gpu)
-    yraw = torch.randn((n, cout, t, h, w), generator=g_).bfloat16().to(gpu)
+    gy = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
+    yraw = torch.randn((n, cout, t, h, w), generator=g_).to(bf).to(gpu)
     coef = (torch.randn((cout, 4), generator=g_) * 0.5).to(gpu)
     dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
     ops.pw_dgrad(gy, yraw, coef, wt, dx0)
@@ -237,17 +290,7 @@ def test_pw_packed_panels(gpu, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [
-    # N, C, T, H, W, stride
-    (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2),       # even, SW=2
-    (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),         # 7x7 planes, SW=1
-    (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1),       # X3D-L odd case 39 -> 20 (pads 1/1)
-    (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),     # X3D-M stage-2 planes, SW=4, H-tiled
-    (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1),        # T=1 / non-square / odd widths
-    (1, 2, 16, 28, 28, 1),                            # vec 4 path for bf16
-    (2, 3, 16, 14, 14, 1), (1, 2, 6, 7, 7, 1),        # deep-prefetch variants (dw_pd.hip): T = 4k, T % 4 != 0,
-    (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),         #   T < depth, stride 2
-])
+@pytest.mark.parametrize("shape", S.DW)   # N, C, T, H, W, stride
 def test_dw3d_fwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
     n, c, t, h, w, stride = shape
@@ -261,7 +304,7 @@ def test_dw3d_fwd(gpu, dtype, shape):
     y = ops.dw3d_fwd(x.to(gpu), wt.to(gpu), stride, in_ss=ss.to(gpu), in_act=1, stats=stats, pool=pool)
     torch.cuda.synchronize()
     assert tuple(y.shape) == tuple(ref.shape)
-    rt, at = tol_for(dtype)
+    rt, at = tol_store(dtype)   # inputs pre-rounded, fp32 arithmetic: only the output rounding differs
     report("y", y, ref, rt, at * ref.abs().max().item())
     ys = y.float().cpu()
     sref = _stats_ref(ys, dtype)
@@ -272,15 +315,13 @@ def test_dw3d_fwd(gpu, dtype, shape):
     report("y_noprologue", y2, O.depthwise3x3x3(xd, wt.double(), stride), rt, at * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("panel", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [
-    # N, Cin, Cout, T, H, W
-    (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
-    (1, 216, 96, 2, 7, 7), (1, 200, 40, 1, 4, 8),
-    (1, 54, 24, 4, 14, 14), (1, 48, 108, 2, 28, 28),   # strided add with rows of 2k / 4k points (pair / quad groups)
-])
-@pytest.mark.parametrize("epi", ["store", "add", "add_strided", "swish_bwd"])
-def test_pw_dgrad(gpu, dtype, shape, epi):
+@pytest.mark.parametrize("shape", S.PW_DGRAD)   # N, Cin, Cout, T, H, W
+@pytest.mark.parametrize("epi", S.PW_DGRAD_EPI)
+def test_pw_dgrad(gpu, dtype, shape, epi, panel):
+    if panel and dtype == torch.float32:
+        pytest.skip("weight panels exist for the 16-bit storage types only")
     ops = _ops()
     n, cin, cout, t, h, w = shape
     g_ = _gen(3)
@@ -314,6 +355,8 @@ def test_pw_dgrad(gpu, dtype, shape, epi):
         ref = ref * (s * (1 + v * (1 - s)))
         ncs = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
         kw = dict(epi=ops.EPI_SWISH_BWD, braw=braw.to(gpu), b_ss=bss.to(gpu), gate=gate.to(gpu), nc_sums=ncs)
+    if panel:
+        kw["w_panel"] = _panels(ops, wt, dtype, gpu)[1]     # the production dispatch (model.py always passes the panel)
     ops.pw_dgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), wt.to(gpu), dx, **kw)
     torch.cuda.synchronize()
     report("dx", dx, ref, rt, at * ref.abs().max().item())
@@ -324,15 +367,7 @@ def test_pw_dgrad(gpu, dtype, shape, epi):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [
-    # N, Cin, Cout, T, H, W, stride, prologue
-    (2, 24, 54, 4, 12, 12, 1, None), (2, 54, 24, 3, 10, 10, 1, "swish"), (2, 24, 48, 4, 12, 12, 2, None),
-    (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
-    (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),
-    (1, 24, 48, 2, 56, 56, 2, None), (2, 48, 96, 2, 28, 28, 2, None), (2, 96, 192, 4, 14, 14, 2, None),  # gather groups 4 / 2 / 1
-    (2, 96, 216, 2, 8, 8, 1, None), (2, 192, 432, 3, 8, 8, 1, None), (2, 432, 192, 2, 8, 8, 1, "swish"),  # wide layers: 12-tile groups (4x3 / 3x4)
-    (2, 192, 432, 8, 7, 7, 1, None), (3, 432, 192, 8, 7, 7, 1, "swish"), (2, 96, 216, 2, 14, 14, 1, None),  # ragged last 64-point step
-])
+@pytest.mark.parametrize("shape", S.PW_WGRAD)   # N, Cin, Cout, T, H, W, stride, prologue
 def test_pw_wgrad(gpu, dtype, shape):
     ops = _ops()
     n, cin, cout, t, h, w, stride, pro = shape
@@ -361,17 +396,12 @@ def test_pw_wgrad(gpu, dtype, shape):
     torch.cuda.synchronize()
     # fp32: exact-fp32 MFMA.  bf16: both operands (after the fp32 prologue) are rounded to bf16 for the matrix
     # cores, 2^-9 relative per element, fp32 accumulation
-    tol = 2e-4 if dtype == torch.float32 else 1e-2
+    tol = 2e-4 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 1.5e-3)
     report("dw", dw, ref + 0.5, tol, tol * ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [
-    (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2), (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),
-    (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1), (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),
-    (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1), (1, 2, 16, 28, 28, 1),
-    (2, 3, 16, 14, 14, 1), (1, 2, 6, 7, 7, 1), (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),   # deep-prefetch variants
-])
+@pytest.mark.parametrize("shape", S.DW)
 def test_dw3d_bwd(gpu, dtype, shape):
     ops, O = _ops(), _oracle()
     n, c, t, h, w, stride = shape
@@ -397,7 +427,7 @@ def test_dw3d_bwd(gpu, dtype, shape):
     ops.dw3d_bwd(dv.to(gpu), braw.to(gpu), coef.to(gpu), araw.to(gpu), ss.to(gpu), wt.to(gpu).view(c, 27), ga,
                  a_sums, dw, stride)
     torch.cuda.synchronize()
-    rt, at = tol_for(dtype)
+    rt, at = tol_store(dtype)
     report("ga", ga, ga_ref, rt, at * ga_ref.abs().max().item())
     report("dw", dw, dWr.view(c, 27) + 0.25, 2e-4, 2e-4 * dWr.abs().max().item())
     gs = ga.float().cpu().double()
@@ -427,7 +457,8 @@ def test_stem(gpu, dtype, shape):
     stats = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
     yt = ops.dwt_fwd(ys, wt.to(gpu), stats=stats)
     torch.cuda.synchronize()
-    report("conv_t", yt, ref_t, rt, at * ref_t.abs().max().item())
+    rs, as_ = tol_store(dtype)
+    report("conv_t", yt, ref_t, rs, as_ * ref_t.abs().max().item())
     report("stats", stats, _stats_ref(yt.float().cpu(), dtype), 1e-5, 1e-4)
     # backward of conv_t (+BN coefficients) and wgrad of conv_s
     g, gd = rnd(tuple(yt.shape), dtype, g_)
@@ -443,7 +474,7 @@ def test_stem(gpu, dtype, shape):
     dwt = torch.zeros((c1, 5), dtype=torch.float32, device=gpu)
     ops.dwt_bwd(g.to(gpu), yt, coef.to(gpu), ys, wt.to(gpu), dx, dwt)
     torch.cuda.synchronize()
-    report("dwt_dx", dx, dxs, rt, at * dxs.abs().max().item())
+    report("dwt_dx", dx, dxs, rs, as_ * dxs.abs().max().item())
     report("dwt_dw", dwt, dwt_ref, 2e-4, 2e-4 * dwt_ref.abs().max().item())
     dxsd = dx.float().cpu().double()
     wsr = ws.double().requires_grad_(True)
@@ -489,7 +520,7 @@ def test_bn_tail_pool(gpu, dtype, P):
     # tail fwd (conv shortcut and identity)
     ssr = torch.stack([1 + 0.3 * torch.randn(c, generator=g_), 0.3 * torch.randn(c, generator=g_)], 1)
     ssc = ss.cpu().double()
-    rt, at = tol_for(dtype)
+    rt, at = tol_store(dtype)
     y = torch.empty(shape, dtype=dtype, device=gpu)
     ops.tail_fwd(craw.to(gpu), ss, rraw.to(gpu), ssr.to(gpu), y)
     ref = F.relu(_affine(cd, ssc) + _affine(rd, ssr.double()))
@@ -793,3 +824,45 @@ def test_bn_fold_tail_fwd(gpu, dtype, shape):
         assert torch.equal(ref_c[k], new_c[k]), k
         if conv_shortcut:
             assert torch.equal(ref_r[k], new_r[k]), k
+
+
+def test_adam_finite_and_label_range(gpu):
+    ops = _ops()
+    from x3d_tf_amd import hip
+    g_ = _gen(12)
+    nel = 1000
+    w = torch.randn(nel, generator=g_)
+    m1 = torch.randn(nel, generator=g_) * 0.1
+    v2 = torch.rand(nel, generator=g_) * 0.01
+    g = torch.randn(nel, generator=g_)
+    mask = (torch.rand(nel, generator=g_) > 0.5).to(torch.uint8)
+    wg, mg, vg = w.to(gpu), m1.to(gpu), v2.to(gpu)
+    step, lr, b1, b2, eps, wd, gs = 3, 0.01, 0.9, 0.999, 1e-7, 5e-5, 0.5
+    hip.call("x3d_adam", wg.data_ptr(), mg.data_ptr(), vg.data_ptr(), g.to(gpu).data_ptr(), mask.to(gpu).data_ptr(), lr, b1, b2,
+             eps, wd, gs, step, nel)
+    gg = g.double() * gs + 2 * wd * w.double() * mask.double()
+    mref = b1 * m1.double() + (1 - b1) * gg
+    vref = b2 * v2.double() + (1 - b2) * gg * gg
+    wref = w.double() - lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step) * mref / (vref.sqrt() + eps)
+    report("adam m", mg, mref, 1e-6, 1e-7)
+    report("adam v", vg, vref, 1e-6, 1e-9)
+    report("adam w", wg, wref, 1e-5, 1e-6)
+    # x3d_all_finite
+    flag = torch.ones(1, dtype=torch.int32, device=gpu)
+    big = torch.randn(100003, generator=g_).to(gpu)
+    hip.call("x3d_all_finite", big.data_ptr(), big.numel(), flag.data_ptr())
+    assert flag.item() == 1
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        big2 = big.clone()
+        big2[77777] = bad
+        flag.fill_(1)
+        hip.call("x3d_all_finite", big2.data_ptr(), big2.numel(), flag.data_ptr())
+        assert flag.item() == 0
+    # a label outside [0, M): NaN loss row, zero gradient row, no out-of-bounds read; the other rows are untouched
+    logits = torch.randn(3, 17, generator=g_).to(gpu)
+    lab = torch.tensor([2, 99, -1], dtype=torch.int32, device=gpu)
+    probs, rows, dl = torch.empty(3, 17, device=gpu), torch.empty(3, device=gpu), torch.full((3, 17), 7.0, device=gpu)
+    ops.softmax_xent(logits, lab, probs, rows, dl, 1.0)
+    assert torch.isfinite(rows[0]) and torch.isnan(rows[1]) and torch.isnan(rows[2])
+    assert dl[1].abs().sum().item() == 0 and dl[2].abs().sum().item() == 0 and dl[0].abs().sum().item() > 0
+    report("probs", probs, torch.softmax(logits.double().cpu(), -1), 1e-5, 1e-7)

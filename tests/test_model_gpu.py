@@ -16,7 +16,8 @@ import os
 import pytest
 import torch
 
-from tests.util import hip_relu_masks, rel_l2, report
+from tests import shapes as S
+from tests.util import hip_relu_masks, rel_l2, relu_mask_mismatch, report
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -44,21 +45,33 @@ def _scaled(name, got, ref, rel):
     return report(name, got, ref, 0, rel * scale)
 
 
-@pytest.mark.parametrize("name,views,t,s", [("XS", 10, 4, 160), ("S", 2, 13, 96)])
-def test_forward_inference_fp32(gpu, name, views, t, s):
-    """BASELINE config 1: X3D-XS, one video = 10 views of 4x160x160, inference mode with view averaging."""
+@pytest.mark.parametrize("name,views,crops,t,s,dtype", S.MODEL_INFER)
+def test_forward_inference(gpu, name, views, crops, t, s, dtype):
+    """Inference mode with view averaging.  BASELINE config 1: X3D-XS, one video = 10 views of 4x160x160 (fp32, 1e-4);
+    BASELINE config 5: X3D-XL, 10 temporal views x 3 spatial crops = 30 clips per video, fp32 and the 16-bit storage
+    types (fp16 is the reference's mixed_float16).  No batch statistics in this mode, so the 16-bit runs are compared
+    end to end: logits within 2 % (bf16) / 0.5 % (fp16) of the largest logit, probabilities within 5e-4 / 1.5e-4."""
     from oracle import x3d_oracle as O
-    cfg, arch, params = _setup(name, ["TEST.NUM_TEMPORAL_VIEWS", views])
+    cfg, arch, params = _setup(name, ["TEST.NUM_TEMPORAL_VIEWS", views, "TEST.NUM_SPATIAL_CROPS", crops])
+    nv = views * crops
+    assert arch.num_preds == nv
     torch.manual_seed(0)
-    x = torch.randn(views, t, s, s, 3)
+    x = torch.randn(nv, t, s, s, 3)
+    if dtype != torch.float32:
+        x = x.to(dtype).float()
     ref, ref_logits = O.forward(params, x, arch, training=False, return_logits=True)
-    m = _model(cfg, params, torch.float32, gpu)
+    m = _model(cfg, params, dtype, gpu)
     out = m(x.to(gpu), training=False)
     torch.cuda.synchronize()
     assert out.dtype == torch.float32 and tuple(out.shape) == (1, arch.num_classes)
-    pl = m._plans[(views, t, s, s, False)]
-    _scaled("logits", pl.logits, ref_logits, 1e-4)
-    report("probs", out, ref, 0, 1e-4)
+    pl = m._plans[(nv, t, s, s, False)]
+    if dtype == torch.float32:
+        _scaled("logits", pl.logits, ref_logits, 1e-4)
+        report("probs", out, ref, 0, 1e-4)
+    else:
+        rel, pabs = (2e-2, 5e-4) if dtype == torch.bfloat16 else (5e-3, 1.5e-4)
+        _scaled("logits", pl.logits, ref_logits, rel)
+        report("probs", out, ref, 0, pabs)
     assert abs(out.sum().item() - 1.0) < 1e-5
 
 
@@ -84,11 +97,7 @@ def test_inference_batch_must_be_multiple_of_views(gpu):
         m(torch.randn(3, 4, 32, 32, 3, device=gpu), training=False)
 
 
-@pytest.mark.parametrize("name,n,t,s", [
-    ("XS", 4, 4, 64), ("S", 2, 13, 64), ("M", 2, 4, 64), ("S", 3, 5, 96),
-    ("XS", 2, 4, 78),     # odd extents end to end: 78 -> 39 -> 20 -> 10 -> 5 -> 3 (X3D-L's 39 -> 20 TF-SAME pads, odd stride-2 planes)
-    ("M", 2, 16, 112),    # T = 16 and 56 / 28 / 14 / 7 planes: the deep-prefetch depthwise variants (dw_pd.hip) inside the model
-])
+@pytest.mark.parametrize("name,n,t,s", S.MODEL_TRAIN_FP32)
 def test_train_step_fp32(gpu, name, n, t, s):
     """fwd + bwd in training mode (batch statistics, fixed dropout mask) against oracle autograd."""
     from oracle import x3d_oracle as O
@@ -106,8 +115,9 @@ def test_train_step_fp32(gpu, name, n, t, s):
     # free-running oracle forward: activations and probabilities
     taps = {}
     st = O.BNState()
+    free_masks = O.RecordMasks()
     probs_free = O.forward({k: v.clone() for k, v in params.items()}, x, arch, training=True, dropout_mask=mask,
-                           state=st, taps=taps)
+                           state=st, taps=taps, relu_masks=free_masks)
     _scaled("conv1/out", pl.y0, taps["conv1/out"], 2e-5)
     for B in pl.blocks:
         pre = O.block_prefix(B.spec)
@@ -119,10 +129,16 @@ def test_train_step_fp32(gpu, name, n, t, s):
     for k, v in st.new_moving.items():
         report(k, m.params[k], v, 1e-4, 1e-5)
 
-    # gradients and update with the device's ReLU sign patterns
+    # gradients and update with the device's ReLU sign patterns -- which may differ from the free-running oracle's only
+    # where a pre-activation is within fp32 rounding of zero: at most 1e-5 of the sites (a systematic sign error near
+    # zero would show here instead of being absorbed by the hand-over)
+    dev_masks = hip_relu_masks(pl)
+    frac, bad, tot = relu_mask_mismatch(dev_masks, free_masks)
+    assert set(free_masks) == set(dev_masks)
+    assert frac <= 1e-5, f"{bad} of {tot} ReLU signs differ between the device and the free-running oracle"
     ref_p = {k: v.clone() for k, v in params.items()}
     r = O.train_step(ref_p, x, labels, arch, lr=0.05, momentum=0.9, dropout_mask=mask, apply_update=True,
-                     relu_masks=hip_relu_masks(pl))
+                     relu_masks=dev_masks)
     loss = pl.loss_rows.mean() + m.regularization_loss().float()
     report("loss", loss.view(1), r["loss"].view(1), 1e-5, 1e-5)
     for k, g_ref in r["grads"].items():
@@ -161,13 +177,9 @@ def test_train_matches_committed_golden_vector(gpu):
         assert abs(g.norm().item() - nrm) < 5e-2 * nrm, f"{k}: |g| {g.norm().item()} vs {nrm}"
 
 
-@pytest.mark.parametrize("name,n,t,s", [
-    ("S", 3, 5, 96),      # odd point counts: scalar / generic kernel paths
-    ("M", 2, 4, 128),     # every P a multiple of 8, 16-byte aligned rows: the fast paths (vector GEMMs, fused pointwise
-                          # backward, packed panels, vector depthwise staging) -- the ones the benchmark runs
-    ("XL", 2, 4, 64),     # XL widths (72/162/306/630...: off the 32-grid, K > 432), 55 blocks, SE parity across stages
-])
-def test_train_step_bf16_block_by_block(gpu, name, n, t, s):
+@pytest.mark.parametrize("dtype", S.HALF_DTYPES)
+@pytest.mark.parametrize("name,n,t,s", S.MODEL_TRAIN_HALF)
+def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     """bf16 activation storage (fp32 arithmetic), checked with TEACHER FORCING: every residual block of the
     device run is replayed on the oracle from the device's own stored block input (forward) and the device's
     own stored upstream gradient (backward), with the oracle rounding to bf16 at the tensors the device
@@ -179,30 +191,33 @@ def test_train_step_bf16_block_by_block(gpu, name, n, t, s):
     from oracle import x3d_oracle as O
     cfg, arch, params = _setup(name)
     torch.manual_seed(2)
-    x = torch.randn(n, t, s, s, 3).bfloat16().float()
+    x = torch.randn(n, t, s, s, 3).to(dtype).float()
     labels = torch.randint(0, arch.num_classes, (n,))
     mask = (torch.rand(n, arch.fc1_out) >= arch.dropout_rate).float()
-    m = _model(cfg, params, torch.bfloat16, gpu)
+    m = _model(cfg, params, dtype, gpu)
     m.set_dropout_mask(mask)
-    pl = m.forward_backward(x.to(gpu), labels.to(gpu))        # builds the plan, full step
+    # fp16 gradients get the reference's loss scaling (LossScaleOptimizer, train.py:99-100): a power of two, so the oracle
+    # replay -- fed the device's own (scaled) upstream gradient per block -- rounds exactly as the device does
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    pl = m.forward_backward(x.to(gpu), labels.to(gpu), loss_scale=ls)        # builds the plan, full step
     torch.cuda.synchronize()
     assert torch.isfinite(pl.loss_rows).all() and torch.isfinite(m.flat_grads).all()
     masks = hip_relu_masks(pl)
-    st = O.Storage(torch.bfloat16)
+    st = O.Storage(dtype)
     # replay the backward block by block, capturing each block's upstream gradient before it is overwritten
     m.flat_grads.zero_()
     pl.zero_buf.zero_()
     pl.run(pl.fwd, 0, pl.grad_scale_slot)
     from x3d_tf_amd import hip
     hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
-             pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), 1.0 / n, n, arch.num_classes)
+             pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), ls / n, n, arch.num_classes)
     pos = 0
     worst = dict(y=0.0, dx=0.0, dw=0.0)
     errs = {}
     for B in reversed(pl.blocks):
         pl.run(pl.bwd, pos, B.bwd_start)
         torch.cuda.synchronize()
-        dy = B.dy_view.float().cpu().clone()
+        dy = B.dy_view.float().cpu().clone()       # carries the loss scale, like everything downstream of it
         pl.run(pl.bwd, B.bwd_start, B.bwd_stop)
         torch.cuda.synchronize()
         pos = B.bwd_stop
@@ -213,19 +228,21 @@ def test_train_step_bf16_block_by_block(gpu, name, n, t, s):
         leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in params.items()}
         xin = B.x.float().cpu().clone().requires_grad_(True)
         y_ref = O.res_block(xin, leaf, B.spec, arch, True, O.BNState(), None, masks, st)
-        worst["y"] = max(worst["y"], _scaled(pre + "/out", B.y, y_ref, 2e-2))
+        atol_ = 2e-2 if dtype == torch.bfloat16 else 3e-3
+        worst["y"] = max(worst["y"], _scaled(pre + "/out", B.y, y_ref, atol_))
         grads = torch.autograd.grad(y_ref, [xin] + [leaf[k] for k in names], grad_outputs=dy)
         dx_ref = grads[0]
         if B.spec.has_shortcut_conv or True:
-            _scaled(pre + "/dx", dx_dev, dx_ref, 2e-2)
+            _scaled(pre + "/dx", dx_dev, dx_ref, atol_)
         for k, g_ref in zip(names, grads[1:]):
             e = rel_l2(m.grads[k], g_ref)
             worst["dw"] = max(worst["dw"], e)
             errs[k] = e
     print("bf16 teacher-forced worst:", worst, sorted(errs.items(), key=lambda kv: -kv[1])[:4])
-    bad = {k: e for k, e in errs.items() if e > 6e-2}
-    assert not bad, f"relative L2 error beyond 6 % (teacher-forced, bf16): {bad}"
-    assert sorted(errs.values())[len(errs) // 2] < 1.5e-2        # median
+    lim, med = (6e-2, 1.5e-2) if dtype == torch.bfloat16 else (1e-2, 2.5e-3)
+    bad = {k: e for k, e in errs.items() if e > lim}
+    assert not bad, f"relative L2 error beyond {lim} (teacher-forced, {dtype}): {bad}"
+    assert sorted(errs.values())[len(errs) // 2] < med        # median
 
 
 def test_train_step_bf16_end_to_end_sanity(gpu):
@@ -320,3 +337,103 @@ def test_trainer_checkpoint_resume(gpu, tmp_path):
     for k in m.grads:   # the continued step agrees to fp32 atomic-summation order (weight gradients use fp32 atomics)
         d = (m.params[k] - m2.params[k]).abs().max().item()
         assert d <= 1e-5 * max(1.0, m.params[k].abs().max().item()), (k, d)
+
+
+def test_full_size_headline_plan_properties(gpu):
+    """BASELINE config 3 at FULL size (X3D-M, 64 clips of 16x224x224, bf16 -- the plan bench.py times), checked through
+    size-independent properties, since no CPU oracle finishes this size:
+      * loss and every gradient finite;
+      * the BatchNorm batch statistics the kernels' epilogues accumulated equal an fp64 reduction of the stored tensors;
+      * linearity of the explicit backward pass: doubling the upstream gradient (loss_scale = 2) doubles every gradient;
+      * per-sample independence in inference mode (moving statistics): the 64-clip plan gives the same probabilities as
+        eight 8-clip plans -- tile / workgroup partitioning across samples does not leak between clips."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.params import init_params, randomize_bn_
+    cfg = x.get_config("M", ["TEST.NUM_TEMPORAL_VIEWS", 1, "TEST.NUM_SPATIAL_CROPS", 1])
+    arch = x.build_arch(cfg)
+    m = X3D(cfg, dtype=torch.bfloat16, device=gpu, seed=0)
+    m.load_state_dict(randomize_bn_(init_params(arch, seed=3), seed=4))
+    n, t, s = 64, 16, 224
+    g = torch.Generator(device=gpu)
+    g.manual_seed(7)
+    clips = torch.randn((n, t, s, s, 3), generator=g, device=gpu).to(torch.bfloat16)
+    labels = torch.randint(0, arch.num_classes, (n,), generator=g, device=gpu)
+    mask = (torch.rand((n, arch.fc1_out), generator=g, device=gpu) >= arch.dropout_rate).float()
+    m.set_dropout_mask(mask)
+    moving0 = m.moving_stats_flat().clone()
+    pl = m.forward_backward(clips, labels)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pl.loss_rows).all() and torch.isfinite(m.flat_grads).all()
+    assert 4.0 < pl.loss_rows.mean().item() < 9.0           # ~ln(400) = 5.99 for a random-init classifier
+    g1 = m.flat_grads.clone()
+    # batch statistics: stage 2 (112^2 and 56^2 planes), stage 4 (14^2), stage 5 (7^2)
+    for bi in (0, 1, 12, len(pl.blocks) - 1):
+        B = pl.blocks[bi]
+        for raw, bn in ((B.a_raw, B.bn_a), (B.b_raw, B.bn_b), (B.c_raw, B.bn_c)):
+            d = raw.double()
+            mean = d.mean((0, 2, 3, 4))
+            var = d.var((0, 2, 3, 4), unbiased=False)
+            del d
+            mi = bn.mi.double()
+            scale = max(mean.abs().max().item(), var.sqrt().max().item())
+            report(f"block {bi} {bn.prefix} mean", mi[:, 0], mean, 0, 2e-4 * scale)
+            report(f"block {bi} {bn.prefix} invstd", mi[:, 1], 1 / torch.sqrt(var + arch.bn_eps), 5e-4, 0)
+    # linearity
+    m.moving_stats_flat().copy_(moving0)
+    pl = m.forward_backward(clips, labels, loss_scale=2.0)
+    torch.cuda.synchronize()
+    g2 = m.flat_grads
+    num = (g2 - 2 * g1).norm().item()
+    assert num <= 2e-3 * (2 * g1).norm().item(), f"backward pass not linear in the upstream gradient: {num}"
+    # per-sample independence (inference)
+    m.moving_stats_flat().copy_(moving0)
+    full = m(clips, training=False).clone()
+    assert tuple(full.shape) == (n, arch.num_classes) and torch.isfinite(full).all()
+    parts = torch.cat([m(clips[i:i + 8], training=False).clone() for i in range(0, n, 8)], 0)
+    report("probs 64 vs 8x8", full, parts, 0, 1e-6)
+    m.release_plans()
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_trainer_fp16_loss_scaling_and_adam(gpu, opt):
+    """reference train.py:88-100: SGD(nesterov) / Adam, wrapped in LossScaleOptimizer under mixed_float16.  fp16 storage:
+    dynamic loss scale (2^15, halved + step skipped on a non-finite gradient); the update applies the UNSCALED gradient:
+    it matches a step taken at loss scale 1024 to fp16 noise, and an fp64 restatement of the optimizer formula exactly."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.train import Trainer
+    cfg = x.get_config("XS", ["TRAIN.OPTIMIZER", opt, "NETWORK.NUM_CLASSES", 11])
+    arch = x.build_arch(cfg)
+    gen = torch.Generator().manual_seed(3)
+    clips = torch.randn(2, 4, 64, 64, 3, generator=gen).to(gpu)
+    labels = torch.randint(0, 11, (2,), generator=gen).to(gpu)
+    m = X3D(cfg, dtype=torch.float16, device=gpu, seed=5)
+    m.set_dropout_mask(torch.ones(2, arch.fc1_out))
+    tr = Trainer(m, cfg)
+    assert tr.dynamic_scale and tr.loss_scale == 2.0 ** 15 and tr.optimizer == opt
+    w0 = m.flat_params[:m.n_trainable_flat].double().cpu().clone()
+    lr = 0.01
+    tr.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 0 and tr.opt_step == 1 and torch.isfinite(m.flat_params).all()
+    # fp64 restatement of the update from the gradient buffer the step left behind (scaled by the loss scale)
+    gsc = m.flat_grads.double().cpu() / tr.loss_scale
+    gsc = gsc + 2 * arch.weight_decay * w0 * m.l2_mask.double().cpu()
+    if opt == "sgd":
+        v = -lr * gsc
+        want = w0 + cfg.TRAIN.MOMENTUM * v - lr * gsc
+    else:
+        mm, vv = 0.1 * gsc, 0.001 * gsc * gsc
+        want = w0 - lr * (1 - 0.999) ** 0.5 / (1 - 0.9) * mm / (vv.sqrt() + 1e-7)
+    got = m.flat_params[:m.n_trainable_flat].double().cpu()
+    assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    # an overflowing loss scale: the step is skipped, the scale halved, the weights untouched
+    tr.loss_scale = 2.0 ** 40
+    before = m.flat_params.clone()
+    tr.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 1 and tr.loss_scale == 2.0 ** 39 and tr.opt_step == 1
+    assert torch.equal(before[:m.n_trainable_flat], m.flat_params[:m.n_trainable_flat])
+    with pytest.raises(NotImplementedError):
+        Trainer(m, x.get_config("XS", ["TRAIN.OPTIMIZER", "rmsprop"]))

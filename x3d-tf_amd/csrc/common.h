@@ -14,6 +14,33 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// 16-bit storage types (X3D_BF16 / X3D_F16): vector types, the matrix-core instruction and the name used in kernel
+// descriptions.  Every 16-bit kernel is a template over H; arithmetic around the matrix cores is fp32 either way.
+template <typename H> struct HV;
+template <> struct HV<bf16> {
+  typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2;
+  static constexpr const char* name = "bf16";
+};
+template <> struct HV<f16> {
+  typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2;
+  static constexpr const char* name = "f16";
+};
+template <typename T> struct TypeName { static constexpr const char* v = HV<T>::name; };
+template <> struct TypeName<float> { static constexpr const char* v = "float"; };
+// D[32x32] += A[32x16] * B[16x32]: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same operand layout, same rate)
+template <typename H>
+__device__ __forceinline__ f32x16 mfma16(typename HV<H>::x8 a, typename HV<H>::x8 b, f32x16 c) {
+  if constexpr (__is_same(H, bf16)) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// dtype code of the C ABI -> is it one of the 16-bit storage types
+static inline bool x3d_is_half(int dtype) { return dtype == X3D_BF16 || dtype == X3D_F16; }
+static inline bool x3d_dtype_ok(int dtype) { return dtype == X3D_F32 || x3d_is_half(dtype); }
 
 #define WAVE 64
 
@@ -44,6 +71,16 @@ void x3d_set_error(const char* fmt, ...);
 struct X3dDescribe { char* out; int cap; };
 extern thread_local X3dDescribe x3d_describe;
 
+// dry-run dispatch (x3d_dw3d_kernel_name / x3d_pw_kernel_name): a launcher that reaches this line with the describe buffer
+// set writes the name of the instantiation it chose and returns instead of launching (no HIP call has been made)
+#define X3D_DESCRIBE(...)                                              \
+  do {                                                                 \
+    if (x3d_describe.out) {                                            \
+      snprintf(x3d_describe.out, x3d_describe.cap, __VA_ARGS__);       \
+      return X3D_OK;                                                   \
+    }                                                                  \
+  } while (0)
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
@@ -53,14 +90,16 @@ static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)v; }
 // value as it will read back from HBM (used so batch statistics describe the stored tensor)
 template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f<T>(from_f<T>(v)); }
 
 // VEC contiguous elements -> fp32 registers (VEC in {1,2,4,8}; caller guarantees alignment)
-template <typename T, int VEC> struct VecIO;
+template <typename T, int VEC> struct VecIO;   // primary template (below): 16-bit types; float specialised
 template <int VEC> struct VecIO<float, VEC> {
   static __device__ __forceinline__ void load(const float* p, float (&o)[VEC]) {
     if constexpr (VEC == 8) {
@@ -91,35 +130,36 @@ template <int VEC> struct VecIO<float, VEC> {
     } else { *p = v[0]; }
   }
 };
-template <int VEC> struct VecIO<bf16, VEC> {
-  static __device__ __forceinline__ void load(const bf16* p, float (&o)[VEC]) {
+template <typename H, int VEC> struct VecIO {   // the 16-bit storage types
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
+  static __device__ __forceinline__ void load(const H* p, float (&o)[VEC]) {
     if constexpr (VEC == 8) {
-      bf16x8 a = *(const bf16x8*)p;
+      hx8 a = *(const hx8*)p;
 #pragma unroll
       for (int i = 0; i < 8; i++) o[i] = (float)a[i];
     } else if constexpr (VEC == 4) {
-      bf16x4 a = *(const bf16x4*)p;
+      hx4 a = *(const hx4*)p;
 #pragma unroll
       for (int i = 0; i < 4; i++) o[i] = (float)a[i];
     } else if constexpr (VEC == 2) {
-      bf16x2 a = *(const bf16x2*)p; o[0] = (float)a[0]; o[1] = (float)a[1];
+      hx2 a = *(const hx2*)p; o[0] = (float)a[0]; o[1] = (float)a[1];
     } else { o[0] = (float)*p; }
   }
-  static __device__ __forceinline__ void store(bf16* p, const float (&v)[VEC]) {
+  static __device__ __forceinline__ void store(H* p, const float (&v)[VEC]) {
     if constexpr (VEC == 8) {
-      bf16x8 a;
+      hx8 a;
 #pragma unroll
-      for (int i = 0; i < 8; i++) a[i] = (bf16)v[i];
-      *(bf16x8*)p = a;
+      for (int i = 0; i < 8; i++) a[i] = (H)v[i];
+      *(hx8*)p = a;
     } else if constexpr (VEC == 4) {
-      bf16x4 a;
+      hx4 a;
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = (bf16)v[i];
-      *(bf16x4*)p = a;
+      for (int i = 0; i < 4; i++) a[i] = (H)v[i];
+      *(hx4*)p = a;
     } else if constexpr (VEC == 2) {
-      bf16x2 a; a[0] = (bf16)v[0]; a[1] = (bf16)v[1];
-      *(bf16x2*)p = a;
-    } else { *p = (bf16)v[0]; }
+      hx2 a; a[0] = (H)v[0]; a[1] = (H)v[1];
+      *(hx2*)p = a;
+    } else { *p = (H)v[0]; }
   }
 };
 
@@ -146,9 +186,9 @@ static inline int pick_vec(int elem_bytes, long long extent, const void* p0, con
 // gathered elements in order, so output j of the vector is element 2*j whatever GV is.
 // Caller guarantees: W % (2*GV) == 0, Wo % GV == 0, base 4*GV-byte aligned, all 8 outputs inside the tensor.
 // ---------------------------------------------------------------------------------------------
-template <int GV>
-__device__ __forceinline__ void strided_gather16(const bf16* base, long long p, int H, int W, int Ho, int Wo,
-                                                 bf16x8& lo, bf16x8& hi) {
+template <int GV, typename HT>
+__device__ __forceinline__ void strided_gather16(const HT* base, long long p, int H, int W, int Ho, int Wo,
+                                                 typename HV<HT>::x8& lo, typename HV<HT>::x8& hi) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   const int hw = Ho * Wo;                  // p < 2^31 (per-sample point index): 32-bit divisions
@@ -158,7 +198,7 @@ __device__ __forceinline__ void strided_gather16(const bf16* base, long long p, 
   unsigned int w[8];
 #pragma unroll
   for (int gi = 0; gi < 8 / GV; gi++) {
-    const bf16* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2;
+    const HT* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2;
     if constexpr (GV == 4) {
       const u32x4 v = *(const u32x4*)src;
       w[gi * 4] = v[0]; w[gi * 4 + 1] = v[1]; w[gi * 4 + 2] = v[2]; w[gi * 4 + 3] = v[3];
@@ -172,8 +212,8 @@ __device__ __forceinline__ void strided_gather16(const bf16* base, long long p, 
     if (wo >= Wo) { wo = 0; if (++ho >= Ho) { ho = 0; ++t; } }
   }
   const u32x4 l = {w[0], w[1], w[2], w[3]}, h = {w[4], w[5], w[6], w[7]};
-  lo = __builtin_bit_cast(bf16x8, l);
-  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(typename HV<HT>::x8, l);
+  hi = __builtin_bit_cast(typename HV<HT>::x8, h);
 }
 // largest group size the gather supports for a stride-2 source of row length W sampled to Wo (0: use the scalar path)
 static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {

@@ -294,7 +294,7 @@ template <typename T, int S, int SW, int CV>
 static void dw_bwd_launch_cv(const DwBwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
   if (x3d_describe.out) {
     const bool gen = nsv > 2;
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_kernel<%s, %d, %d, %d, %d>", TypeName<T>::v,
              S, SW, gen ? 0 : (nsv <= 1 ? 1 : 2), gen ? 0 : CV);
     return;
   }
@@ -353,7 +353,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   static const char* pd_s2 = getenv("X3D_DW_PD_S2");
   const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : (pd_s2 ? atoi(pd_s2) : 2));
   if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
-    if (dw_bwd_pd_launch(a, (int)sizeof(T), S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
+    if (dw_bwd_pd_launch(a, f->dtype, S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;
       X3D_LAUNCH_CHECK("dw3d_bwd");
       return X3D_OK;
@@ -375,9 +375,11 @@ extern "C" int x3d_dw3d_bwd(const x3d_dw3d_bwd_args* f, void* stream) {
                   f->a_sums && f->dw, "dw3d_bwd: null pointer");
   X3D_REQUIRE(f->stride == 1 || f->stride == 2, "dw3d_bwd: stride must be 1 or 2");
   X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_bwd: bad extents");
-  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_bwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(f->dtype), "dw3d_bwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   if (f->dtype == X3D_F32)
     return f->stride == 1 ? dw_bwd_launch<float, 1>(f, st) : dw_bwd_launch<float, 2>(f, st);
+  if (f->dtype == X3D_F16)
+    return f->stride == 1 ? dw_bwd_launch<f16, 1>(f, st) : dw_bwd_launch<f16, 2>(f, st);
   return f->stride == 1 ? dw_bwd_launch<bf16, 1>(f, st) : dw_bwd_launch<bf16, 2>(f, st);
 }

@@ -43,6 +43,9 @@ template <> __device__ __forceinline__ float raw_get<float>(const Raw& r, int e)
 template <> __device__ __forceinline__ float raw_get<bf16>(const Raw& r, int e) {
   return __uint_as_float(((r.w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
 }
+template <> __device__ __forceinline__ float raw_get<f16>(const Raw& r, int e) {   // v_cvt_f32_f16 (with op_sel for the high half)
+  return (float)__builtin_bit_cast(f16, (unsigned short)(r.w[e >> 1] >> (16 * (e & 1))));
+}
 
 // ---- argument blocks shared by the streaming kernels (dw_fwd.hip / dw_bwd.hip) and their deep-prefetch
 // variants for small planes (dw_pd.hip)
@@ -65,9 +68,9 @@ struct DwBwdArgs {
 // 4 for SW <= 2 (rows of < 20 outputs), else 1 (one-plane-ahead kernels).  X3D_DW_PD=1 switches them off (A/B hook).
 int dw_pick_pd(int SW);
 // deep-prefetch launchers (dw_pd.hip); return false when the shape is not covered (caller falls back)
-bool dw_fwd_pd_launch(const DwFwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+bool dw_fwd_pd_launch(const DwFwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st);
-bool dw_bwd_pd_launch(const DwBwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st);
 
 // ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
@@ -99,8 +102,8 @@ template <typename T, int N> __device__ __forceinline__ void raw_pack(Raw& r, co
   } else {
 #pragma unroll
     for (int i = 0; i < (N + 1) / 2; i++) {
-      const uint32_t lo = __builtin_bit_cast(unsigned short, (bf16)v[2 * i]);
-      const uint32_t hi = (2 * i + 1 < N) ? (uint32_t)__builtin_bit_cast(unsigned short, (bf16)v[2 * i + 1]) : 0u;
+      const uint32_t lo = __builtin_bit_cast(unsigned short, (T)v[2 * i]);
+      const uint32_t hi = (2 * i + 1 < N) ? (uint32_t)__builtin_bit_cast(unsigned short, (T)v[2 * i + 1]) : 0u;
       r.w[i] = lo | (hi << 16);
     }
   }

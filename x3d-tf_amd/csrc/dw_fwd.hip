@@ -155,7 +155,7 @@ template <typename T, int S, int SW, int CV>
 static void dw_fwd_launch_cv(const DwFwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
   if (x3d_describe.out) {
     const bool gen = nsv > 4;
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_kernel<%s, %d, %d, %d, %d>", TypeName<T>::v,
              S, SW, gen ? 0 : (nsv <= 2 ? 2 : 4), gen ? 0 : CV);
     return;
   }
@@ -199,7 +199,7 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   // small planes: deep-prefetch variant (dw_pd.hip) when one staging vector per thread covers the tile
   const int pd = dw_pick_pd(SW);
   if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
-    if (dw_fwd_pd_launch(a, (int)sizeof(T), S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
+    if (dw_fwd_pd_launch(a, f->dtype, S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;
       X3D_LAUNCH_CHECK("dw3d_fwd");
       return X3D_OK;
@@ -228,12 +228,14 @@ extern "C" int x3d_dw3d_fwd(const x3d_dw3d_fwd_args* f, void* stream) {
   X3D_REQUIRE(f && f->x && f->w && f->y, "dw3d_fwd: null pointer");
   X3D_REQUIRE(f->stride == 1 || f->stride == 2, "dw3d_fwd: stride must be 1 or 2");
   X3D_REQUIRE(f->N > 0 && f->C > 0 && f->T > 0 && f->H > 0 && f->W > 0, "dw3d_fwd: bad extents");
-  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "dw3d_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(f->dtype), "dw3d_fwd: bad dtype");
   X3D_REQUIRE(f->in_act == X3D_ACT_NONE || f->in_act == X3D_ACT_RELU, "dw3d_fwd: prologue act must be none/relu");
   X3D_REQUIRE(!f->in_bn || bn_fold_valid(f->in_bn), "dw3d_fwd: incomplete x3d_bn_fold");
   hipStream_t st = (hipStream_t)stream;
   if (f->dtype == X3D_F32)
     return f->stride == 1 ? dw_fwd_launch<float, 1>(f, st) : dw_fwd_launch<float, 2>(f, st);
+  if (f->dtype == X3D_F16)
+    return f->stride == 1 ? dw_fwd_launch<f16, 1>(f, st) : dw_fwd_launch<f16, 2>(f, st);
   return f->stride == 1 ? dw_fwd_launch<bf16, 1>(f, st) : dw_fwd_launch<bf16, 2>(f, st);
 }
 

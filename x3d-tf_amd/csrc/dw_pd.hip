@@ -671,7 +671,7 @@ int dw_pick_pd(int SW) {   // depth 4 for strips of 1 / 2 outputs; wider strips 
 #define DW_PD_DESCRIBE(KIND)                                                                                   \
   if (x3d_describe.out) {                                                                                      \
     snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_" KIND "_pd_kernel<%s, %d, %d, %d, %d>",                \
-             sizeof(T) == 2 ? "bf16" : "float", S, SW, CV, PD);                                                \
+             TypeName<T>::v, S, SW, CV, PD);                                                \
     return true;                                                                                               \
   }
 
@@ -690,7 +690,7 @@ static bool bwd_go(const DwBwdArgs& a, unsigned grid, int bd, size_t lds, hipStr
   if constexpr (S == 1 && SW == 2) {
     if (!(roles && atoi(roles) == 0)) {
       if (x3d_describe.out) {
-        snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_s1_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "bf16" : "float",
+        snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_s1_kernel<%s, %d, %d, %d, %d>", TypeName<T>::v,
                  SW, CV, 3, 6);
         return true;
       }
@@ -740,13 +740,15 @@ static bool bwd_pd_t(const DwBwdArgs& a, int S, int SW, int cv, int pd, unsigned
   return false;
 }
 
-bool dw_fwd_pd_launch(const DwFwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+bool dw_fwd_pd_launch(const DwFwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st) {
-  return elem_bytes == 2 ? fwd_pd_t<bf16>(a, S, SW, cv, pd, grid, bd, lds, st)
-                         : fwd_pd_t<float>(a, S, SW, cv, pd, grid, bd, lds, st);
+  return dtype == X3D_BF16 ? fwd_pd_t<bf16>(a, S, SW, cv, pd, grid, bd, lds, st)
+         : dtype == X3D_F16 ? fwd_pd_t<f16>(a, S, SW, cv, pd, grid, bd, lds, st)
+                            : fwd_pd_t<float>(a, S, SW, cv, pd, grid, bd, lds, st);
 }
-bool dw_bwd_pd_launch(const DwBwdArgs& a, int elem_bytes, int S, int SW, int cv, int pd, unsigned grid, int bd,
+bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st) {
-  return elem_bytes == 2 ? bwd_pd_t<bf16>(a, S, SW, cv, pd, grid, bd, lds, st)
-                         : bwd_pd_t<float>(a, S, SW, cv, pd, grid, bd, lds, st);
+  return dtype == X3D_BF16 ? bwd_pd_t<bf16>(a, S, SW, cv, pd, grid, bd, lds, st)
+         : dtype == X3D_F16 ? bwd_pd_t<f16>(a, S, SW, cv, pd, grid, bd, lds, st)
+                            : bwd_pd_t<float>(a, S, SW, cv, pd, grid, bd, lds, st);
 }

@@ -275,7 +275,7 @@ extern "C" int x3d_tail_fwd(const void* c_raw, const float* c_scale_shift, const
                             const float* r_scale_shift, void* y, int N, int C, long long P, int dtype,
                             void* stream) {
   X3D_REQUIRE(c_raw && c_scale_shift && y && N > 0 && C > 0 && P > 0, "tail_fwd: bad args");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "tail_fwd: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, c_raw, shortcut, y));
   hipStream_t st = (hipStream_t)stream;
@@ -286,6 +286,9 @@ extern "C" int x3d_tail_fwd(const void* c_raw, const float* c_scale_shift, const
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
     else hipLaunchKernelGGL((tail_fwd_kernel<float, 1, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else if (dtype == X3D_F16) {
+    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<f16, 8, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
+    else hipLaunchKernelGGL((tail_fwd_kernel<f16, 1, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
   } else {
     if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
     else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1, false>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
@@ -300,7 +303,7 @@ extern "C" int x3d_tail_fwd_bn(const void* c_raw, const x3d_bn_fold* c_bn, const
   X3D_REQUIRE(c_raw && y && N > 0 && C > 0 && P > 0, "tail_fwd_bn: bad args");
   X3D_REQUIRE(bn_fold_valid(c_bn), "tail_fwd_bn: incomplete x3d_bn_fold for bn_c");
   X3D_REQUIRE(!r_bn || (shortcut && bn_fold_valid(r_bn)), "tail_fwd_bn: incomplete x3d_bn_fold for bn_r");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_fwd_bn: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "tail_fwd_bn: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, c_raw, shortcut, y));
   hipStream_t st = (hipStream_t)stream;
@@ -313,6 +316,9 @@ extern "C" int x3d_tail_fwd_bn(const void* c_raw, const x3d_bn_fold* c_bn, const
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((tail_fwd_kernel<float, 4, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
     else hipLaunchKernelGGL((tail_fwd_kernel<float, 1, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else if (dtype == X3D_F16) {
+    if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<f16, 8, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
+    else hipLaunchKernelGGL((tail_fwd_kernel<f16, 1, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
   } else {
     if (vec == 8) hipLaunchKernelGGL((tail_fwd_kernel<bf16, 8, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
     else hipLaunchKernelGGL((tail_fwd_kernel<bf16, 1, true>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
@@ -326,7 +332,7 @@ extern "C" int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const 
                             double* sums_r, int N, int C, long long P, int dtype, void* stream) {
   X3D_REQUIRE(dy_g && y && c_raw && sums_c && N > 0 && C > 0 && P > 0, "tail_bwd: bad args");
   X3D_REQUIRE(!r_raw || sums_r, "tail_bwd: sums_r required with r_raw");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "tail_bwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "tail_bwd: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, dy_g, y, c_raw, r_raw));
   hipStream_t st = (hipStream_t)stream;
@@ -335,6 +341,9 @@ extern "C" int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const 
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((tail_bwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
     else hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else if (dtype == X3D_F16) {
+    if (vec == 8) hipLaunchKernelGGL((tail_bwd_kernel<f16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
+    else hipLaunchKernelGGL((tail_bwd_kernel<f16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
   } else {
     if (vec == 8) hipLaunchKernelGGL((tail_bwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
     else hipLaunchKernelGGL((tail_bwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
@@ -349,7 +358,7 @@ extern "C" int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const 
                                       long long P, int dtype, void* stream) {
   X3D_REQUIRE((dy != nullptr) != (dpool != nullptr), "relu_bn_bwd_reduce: exactly one of dy / dpool");
   X3D_REQUIRE(yraw && scale_shift && g && sums && N > 0 && C > 0 && P > 0, "relu_bn_bwd_reduce: bad args");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "relu_bn_bwd_reduce: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "relu_bn_bwd_reduce: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, dy, yraw, g));
   hipStream_t st = (hipStream_t)stream;
@@ -358,6 +367,9 @@ extern "C" int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const 
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
     else hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else if (dtype == X3D_F16) {
+    if (vec == 8) hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<f16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
+    else hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<f16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
   } else {
     if (vec == 8) hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
     else hipLaunchKernelGGL((relu_bn_bwd_reduce_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
@@ -370,7 +382,7 @@ extern "C" int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const 
 extern "C" int x3d_pool_fwd(const void* x_raw, const float* scale_shift, float* pooled, int N, int C,
                             long long P, int dtype, void* stream) {
   X3D_REQUIRE(x_raw && scale_shift && pooled && N > 0 && C > 0 && P > 0, "pool_fwd: bad args");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "pool_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "pool_fwd: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, x_raw));
   hipStream_t st = (hipStream_t)stream;
@@ -379,6 +391,9 @@ extern "C" int x3d_pool_fwd(const void* x_raw, const float* scale_shift, float* 
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
     else hipLaunchKernelGGL((pool_fwd_kernel<float, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
+  } else if (dtype == X3D_F16) {
+    if (vec == 8) hipLaunchKernelGGL((pool_fwd_kernel<f16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
+    else hipLaunchKernelGGL((pool_fwd_kernel<f16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(f16));
   } else {
     if (vec == 8) hipLaunchKernelGGL((pool_fwd_kernel<bf16, 8>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
     else hipLaunchKernelGGL((pool_fwd_kernel<bf16, 1>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(bf16));
@@ -414,6 +429,12 @@ extern "C" int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int
     hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)src, (bf16*)dst, C, P);
   else if (src_dtype == X3D_BF16 && dst_dtype == X3D_F32)
     hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, st, (const bf16*)src, (float*)dst, C, P);
+  else if (src_dtype == X3D_F32 && dst_dtype == X3D_F16)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, f16>), grid, dim3(256), 0, st, (const float*)src, (f16*)dst, C, P);
+  else if (src_dtype == X3D_F16 && dst_dtype == X3D_F16)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, f16>), grid, dim3(256), 0, st, (const f16*)src, (f16*)dst, C, P);
+  else if (src_dtype == X3D_F16 && dst_dtype == X3D_F32)
+    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, float>), grid, dim3(256), 0, st, (const f16*)src, (float*)dst, C, P);
   else {
     x3d_set_error("nthwc_to_ncthw: bad dtype");
     return X3D_ERR_INVALID;

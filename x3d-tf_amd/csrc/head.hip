@@ -261,6 +261,14 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   if (tid == 0) { bc[0] = r2[0]; bc[1] = r2[1]; }
   __syncthreads();
   const float sumq = bc[0], sum_p_in = bc[1];
+  if (label < 0 || label >= M) {
+    // out-of-range label (TF raises InvalidArgument): never index with it -- the loss row is NaN (so the step's loss is
+    // visibly non-finite) and the sample contributes no gradient
+    if (tid == 0 && loss_rows) loss_rows[n] = __builtin_nanf("");
+    if (dlogits)
+      for (int j = tid; j < M; j += 256) dlogits[(long long)n * M + j] = 0.f;
+    return;
+  }
   const float py = expf(z[label] - mx) * inv;
   const float qy = fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f);
   const bool y_in = (py >= 1e-7f && py <= 1.f - 1e-7f);
@@ -328,6 +336,61 @@ extern "C" int x3d_sgd_nesterov(float* w, float* v, const float* g, const unsign
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                      v, g, l2_mask, lr, momentum, weight_decay, grad_scale, n);
   X3D_LAUNCH_CHECK("sgd_nesterov");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (tf.optimizers.Adam(learning_rate), the reference's other optimizer branch, train.py:93-95; Keras defaults
+// beta_1 = 0.9, beta_2 = 0.999, epsilon = 1e-7, no amsgrad):  g' = g*grad_scale + 2*wd*w (where l2_mask)
+//   m = b1*m + (1-b1)*g' ; v = b2*v + (1-b2)*g'^2 ; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)        [TF-3p]
+// One launch over the flat parameter buffer, like x3d_sgd_nesterov.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, const unsigned char* __restrict__ l2,
+                                                   float lr_t, float b1, float b2, float eps, float wd, float gscale,
+                                                   long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i] * gscale;
+  const float wi = w[i];
+  if (l2 && l2[i]) gi += 2.f * wd * wi;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+extern "C" int x3d_adam(float* w, float* m, float* v, const float* g, const unsigned char* l2_mask, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, long long step, long long n,
+                        void* stream) {
+  X3D_REQUIRE(w && m && v && g && n > 0 && step >= 1, "adam: bad args (step counts from 1)");
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream, w, m, v, g,
+                     l2_mask, (float)lr_t, beta1, beta2, eps, weight_decay, grad_scale, n);
+  X3D_LAUNCH_CHECK("adam");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LossScaleOptimizer support (train.py:99-100, Keras mixed_float16): are all gradients finite?  *flag (device int,
+// set to 1 by the caller) is cleared when any of the n values is inf / nan.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void all_finite_kernel(const float* __restrict__ g, long long n, int* flag) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(g[i]);
+    bad |= (u & 0x7f800000u) == 0x7f800000u;     // exponent all ones: inf or nan
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
+extern "C" int x3d_all_finite(const float* g, long long n, int* flag, void* stream) {
+  X3D_REQUIRE(g && flag && n > 0, "all_finite: bad args");
+  long long blocks = ceil_div_ll(n, 256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(all_finite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, flag);
+  X3D_LAUNCH_CHECK("all_finite");
   return X3D_OK;
 }
 

@@ -42,10 +42,11 @@ struct PwBwdArgs {
 #define FB_OP 132    // fp32 output slab pitch
 
 // MT: 32-row tiles of Ci (dX rows / dW columns); KT: 32-row tiles of Co (dY rows / dW rows)
-template <int MT, int KT, int EPI>
+template <typename H, int MT, int KT, int EPI>
 __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   constexpr int BN = FB_BN, YP = FB_YP, XP = FB_XP, OP = FB_OP;
   constexpr bool SWB = (EPI == X3D_EPI_SWISH_BWD);
   constexpr int NT = MT * KT;                       // dW tiles
@@ -60,9 +61,9 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
   // the widest `c` layers pass the slab in two 16-row halves: 8.4 KB less LDS keeps two workgroups per CU
   constexpr bool HALF_SLAB = SWB && MT == 4;
   constexpr size_t YS_B = (size_t)KT * 32 * YP * 2, XS_B = (size_t)MT * 32 * XP * 2, OS_B = (size_t)(HALF_SLAB ? 16 : 32) * OP * 4;
-  bf16* Ys = (bf16*)smem_raw;
-  bf16* Xs = (bf16*)(smem_raw + YS_B);
-  bf16* Ws = (bf16*)(smem_raw + YS_B + XS_B);
+  H* Ys = (H*)smem_raw;
+  H* Xs = (H*)(smem_raw + YS_B);
+  H* Ws = (H*)(smem_raw + YS_B + XS_B);
   float* Os = SWB ? (float*)(smem_raw + YS_B + XS_B + (size_t)MT * 32 * WP * 2) : (float*)smem_raw;
   // BN-backward coefficients {A, B, C, 0} per dY row in LDS (zeros for padded rows), read once per tile and row
   float* Cs = (float*)(smem_raw + YS_B + XS_B + (size_t)MT * 32 * WP * 2 + (SWB ? OS_B : 0));
@@ -80,15 +81,15 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 
   // ---- one-time LDS set-up: zero the dY / Xh tiles (padding rows stay zero), copy the weight panel
   {
-    bf16x8 zero;
+    hx8 zero;
 #pragma unroll
-    for (int e = 0; e < 8; e++) zero[e] = (bf16)0.f;
-    for (int i = tid; i < (int)((YS_B + XS_B) / 16); i += 256) ((bf16x8*)smem_raw)[i] = zero;
-    const bf16x8* src = (const bf16x8*)((const bf16*)a.wp + (long long)m0 * WP);
+    for (int e = 0; e < 8; e++) zero[e] = (H)0.f;
+    for (int i = tid; i < (int)((YS_B + XS_B) / 16); i += 256) ((hx8*)smem_raw)[i] = zero;
+    const hx8* src = (const hx8*)((const H*)a.wp + (long long)m0 * WP);
     const int nvec = MT * 32 * WP / 8;
     const int lim = max(0, min(MT * 32, a.wp_rows - m0)) * WP / 8;
 #pragma unroll 4
-    for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
+    for (int i = tid; i < nvec; i += 256) ((hx8*)Ws)[i] = i < lim ? src[i] : zero;
     for (int k = tid; k < KT * 32; k += 256) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       if (k < a.Co) { c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2]; }
@@ -98,21 +99,21 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
 
   // ---- register-staged prefetch of the next tile: row (tid>>4) + 16*i, 8 points at unit (tid&15)
   const int srow = tid >> 4, sunit = tid & 15;
-  bf16x8 rg[NVY], ry[NVY], rx[SWB ? 1 : NVX];
+  hx8 rg[NVY], ry[NVY], rx[SWB ? 1 : NVX];
   auto issue = [&](int tile) {
     const int n = tile / tiles_per_n;
     const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
-    bf16x8 z;
+    hx8 z;
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+    for (int e = 0; e < 8; e++) z[e] = (H)0.f;
 #pragma unroll
     for (int i = 0; i < NVY; i++) {
       const int k = srow + 16 * i;
       rg[i] = z; ry[i] = z;
       if (k < a.Co && p < a.P) {
         const long long o = ((long long)n * a.Co + k) * a.P + p;
-        rg[i] = *(const bf16x8*)((const T*)a.g + o);
-        ry[i] = *(const bf16x8*)((const T*)a.yraw + o);
+        rg[i] = *(const hx8*)((const T*)a.g + o);
+        ry[i] = *(const hx8*)((const T*)a.yraw + o);
       }
     }
     if constexpr (!SWB) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
       for (int i = 0; i < NVX; i++) {
         const int m = m0 + srow + 16 * i;
         rx[i] = z;
-        if (m < a.Ci && p < a.P) rx[i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Ci + m) * a.P + p);
+        if (m < a.Ci && p < a.P) rx[i] = *(const hx8*)((const T*)a.x + ((long long)n * a.Ci + m) * a.P + p);
       }
     }
   };
@@ -137,13 +138,13 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) v[e] = A * (float)rg[i][e] + B * (float)ry[i][e] + C;
-      VecIO<bf16, 8>::store(&Ys[k * YP + ((sunit ^ ((k >> 2) & 3)) << 3)], v);
+      VecIO<H, 8>::store(&Ys[k * YP + ((sunit ^ ((k >> 2) & 3)) << 3)], v);
     }
     if constexpr (!SWB) {
 #pragma unroll
       for (int i = 0; i < NVX; i++) {
         const int m = srow + 16 * i;
-        *(bf16x8*)&Xs[m * XP + sunit * 8] = rx[i];   // zeros where m >= Ci or p >= P
+        *(hx8*)&Xs[m * XP + sunit * 8] = rx[i];   // zeros where m >= Ci or p >= P
       }
     }
   };
@@ -195,15 +196,15 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
         const int cot = id / MT, cit = id - cot * MT;
         const int rowy = cot * 32 + r;
         const int swz = (rowy >> 2) & 3;
-        const bf16* yrow = Ys + rowy * YP;
-        const bf16* xrow = Xs + (cit * 32 + r) * XP + 8 * half;
+        const H* yrow = Ys + rowy * YP;
+        const H* xrow = Xs + (cit * 32 + r) * XP + 8 * half;
         constexpr int KSTEPS = (BN / 16) / NKS;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ks++) {
           const int u = (kpart * KSTEPS + ks) * 2 + half;
-          const bf16x8 af = *(const bf16x8*)(yrow + ((u ^ swz) << 3));
-          const bf16x8 bf = *(const bf16x8*)(xrow + (kpart * KSTEPS + ks) * 16);
-          acc_dw[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc_dw[s], 0, 0, 0);
+          const hx8 af = *(const hx8*)(yrow + ((u ^ swz) << 3));
+          const hx8 bf = *(const hx8*)(xrow + (kpart * KSTEPS + ks) * 16);
+          acc_dw[s] = mfma16<H>(af, bf, acc_dw[s]);
         }
       }
     }
@@ -233,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
       const s16x4_f b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Ys[(kk + tr_row) * YP + tr_off0]));
       const s16x4_f b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Ys[(kk + tr_row + 4) * YP + tr_off1]));
       const s16x8_f bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bs);
+      const hx8 bfrag = __builtin_bit_cast(hx8, bs);
 #pragma unroll
       for (int s = 0; s < MT; s++) {
-        const bf16x8 afrag = *(const bf16x8*)&Ws[(s * 32 + r) * WP + kk + 8 * half];
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[s], 0, 0, 0);
+        const hx8 afrag = *(const hx8*)&Ws[(s * 32 + r) * WP + kk + 8 * half];
+        acc[s] = mfma16<H>(afrag, bfrag, acc[s]);
       }
     }
     if constexpr (!SWB) wgrad_mfma();   // Xh came with the tile: finish with the dY tile before the slab reuses its LDS
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
     // every global load of the epilogue before its first store (vmcnt retires in order, stores included: a load
     // issued behind a store waits for the store's write latency)
     constexpr bool EPL8 = (EPI == X3D_EPI_ADD) || SWB;
-    bf16x8 epl8[EPL8 ? ROWS_PT : 1];
-    bf16x4 epl4[EPL8 ? 1 : ROWS_PT];
+    hx8 epl8[EPL8 ? ROWS_PT : 1];
+    hx4 epl4[EPL8 ? 1 : ROWS_PT];
     float esb[SWB ? ROWS_PT : 1], etb[SWB ? ROWS_PT : 1], egt[SWB ? ROWS_PT : 1];
     const bool epl4_vec = (a.eW & 7) == 0;
     // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills)
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
       const bool ok = m < a.Ci && p < a.P;
       if constexpr (EPL8) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) epl8[i][e] = (bf16)0.f;
-        if (ok) epl8[i] = *(const bf16x8*)((const T*)(SWB ? a.braw : a.add) + ((long long)n * a.Ci + m) * a.P + p);
+        for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
+        if (ok) epl8[i] = *(const hx8*)((const T*)(SWB ? a.braw : a.add) + ((long long)n * a.Ci + m) * a.P + p);
         if constexpr (SWB) {
           esb[i] = m < a.Ci ? a.b_ss[m * 2] : 0.f;
           etb[i] = m < a.Ci ? a.b_ss[m * 2 + 1] : 0.f;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
+        for (int e = 0; e < 4; e++) epl4[i][e] = (H)0.f;
         if (ok && epl4_vec) {
           const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
           const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
           const int rem = (int)p - t * hw;
           const int h = rem / a.eW, w = rem - h * a.eW;
           if ((h & 1) == 0)
-            epl4[i] = *(const bf16x4*)((const T*)a.add + ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
+            epl4[i] = *(const hx4*)((const T*)a.add + ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
         }
       }
     };
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a)
             st1[i] += dv;
             st2[i] += dv * b[e];
           }
-          VecIO<bf16, 8>::store(&Xs[ml * XP + oc], xh);
+          VecIO<H, 8>::store(&Xs[ml * XP + oc], xh);
         }
         VecIO<T, 8>::store((T*)a.dx + o, val);
       }
@@ -388,11 +389,12 @@ static inline size_t fb_lds_bytes(int MT, int KT, int Kp, bool swb) {
          (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0) + (size_t)KT * 32 * 16;
 }
 
-template <int MT, int KT, int EPI>
+template <typename H, int MT, int KT, int EPI>
 static int fb_launch(PwBwdArgs& a, hipStream_t st) {
   const size_t lds = fb_lds_bytes(MT, KT, a.Kp, EPI == X3D_EPI_SWISH_BWD);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd: needs %zu B of LDS", lds);
-  auto kern = pw_bwd_fused_kernel<MT, KT, EPI>;
+  X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d>", HV<H>::name, MT, KT, EPI);
+  auto kern = pw_bwd_fused_kernel<H, MT, KT, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -440,11 +442,11 @@ static inline bool fb_shape(int Ci, int Co, int* MT, int* KT) {
   return true;
 }
 
-template <int EPI>
+template <typename H, int EPI>
 static int fb_pick(PwBwdArgs& a, hipStream_t st) {
   int MT = 0, KT = 0;
   if (!fb_shape(a.Ci, a.Co, &MT, &KT)) { x3d_set_error("pw_bwd: unsupported tile shape"); return X3D_ERR_INVALID; }
-#define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<M_, K_, EPI>(a, st);
+#define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<H, M_, K_, EPI>(a, st);
   FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 3) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 3) FB_CASE(2, 4)
   FB_CASE(4, 1) FB_CASE(4, 2)
 #undef FB_CASE
@@ -454,7 +456,7 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
 
 // eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
 static bool fb_supported(const x3d_pw_bwd_args* b) {
-  if (b->dtype != X3D_BF16 || !b->w_panel || !b->coef || !b->yraw) return false;
+  if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw) return false;
   int MT = 0, KT = 0;
   if (!fb_shape(b->Cin, b->Cout, &MT, &KT)) return false;
   // slicing Ci re-stages the dY tile once per slice: worth it up to ~4 slices (x3d_pw_dgrad does the same per row block)
@@ -491,9 +493,16 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin; a.Kp = (b->Cout + 15) & ~15;
   a.P = (long long)b->T * b->H * b->W;
   hipStream_t st = (hipStream_t)stream;
+  if (b->dtype == X3D_F16) {
+    switch (b->epi) {
+      case X3D_EPI_ADD: return fb_pick<f16, X3D_EPI_ADD>(a, st);
+      case X3D_EPI_ADD_STRIDED: return fb_pick<f16, X3D_EPI_ADD_STRIDED>(a, st);
+      default: return fb_pick<f16, X3D_EPI_SWISH_BWD>(a, st);
+    }
+  }
   switch (b->epi) {
-    case X3D_EPI_ADD: return fb_pick<X3D_EPI_ADD>(a, st);
-    case X3D_EPI_ADD_STRIDED: return fb_pick<X3D_EPI_ADD_STRIDED>(a, st);
-    default: return fb_pick<X3D_EPI_SWISH_BWD>(a, st);
+    case X3D_EPI_ADD: return fb_pick<bf16, X3D_EPI_ADD>(a, st);
+    case X3D_EPI_ADD_STRIDED: return fb_pick<bf16, X3D_EPI_ADD_STRIDED>(a, st);
+    default: return fb_pick<bf16, X3D_EPI_SWISH_BWD>(a, st);
   }
 }

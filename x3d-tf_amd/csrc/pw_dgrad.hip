@@ -13,12 +13,44 @@ static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
   return X3D_ERR_INVALID;
 }
 
+template <typename H>
+static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int vec, hipStream_t st) {
+  const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
+  // stage 5: weights stationary.  The stage-4 shapes stay with the resident-panel kernel here: with two staged tensors
+  // the stationary kernel needs 132-146 VGPRs = one workgroup per CU (216 -> 96 dgrad: 58 -> 61 us)
+  // (strided shortcut gradient: even image width only -- pairs of points never straddle a row)
+  const int shp_ = (d->epi != X3D_EPI_ADD_STRIDED || (d->W % 2 == 0 && ((uintptr_t)d->add % 2) == 0)) ? pw_wst_shape(a, vec, ovec) : 0;
+  if (const int shp = shp_ <= 2 ? shp_ : 0) {
+    switch (d->epi) {
+      case X3D_EPI_ADD_STRIDED: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, shp, st);
+      case X3D_EPI_STORE: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_STORE>(a, shp, st);
+      case X3D_EPI_ADD: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_ADD>(a, shp, st);
+      case X3D_EPI_SWISH_BWD: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, shp, st);
+    }
+  }
+  if (d->epi != X3D_EPI_ADD_STRIDED && pw_ws_applies(a, vec, ovec)) {   // deep, narrow layers (stage 5)
+    switch (d->epi) {
+      case X3D_EPI_STORE: return pw_ws_launch<H, PRO_BNBWD, X3D_EPI_STORE>(a, st);
+      case X3D_EPI_ADD: return pw_ws_launch<H, PRO_BNBWD, X3D_EPI_ADD>(a, st);
+      case X3D_EPI_SWISH_BWD: return pw_ws_launch<H, PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st);
+    }
+  }
+  switch (d->epi) {  // bf16 storage: bf16 matrix cores
+    case X3D_EPI_STORE: return pw_bf16_launch_vec<H, PRO_BNBWD, X3D_EPI_STORE>(a, vec, ovec, st);
+    case X3D_EPI_ADD: return pw_bf16_launch_vec<H, PRO_BNBWD, X3D_EPI_ADD>(a, vec, ovec, st);
+    case X3D_EPI_ADD_STRIDED: return pw_bf16_launch_vec<H, PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, vec, ovec, st);
+    case X3D_EPI_SWISH_BWD: return pw_bf16_launch_vec<H, PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, vec, ovec, st);
+  }
+  x3d_set_error("pw_dgrad: unknown epilogue %d", d->epi);
+  return X3D_ERR_INVALID;
+}
+
 extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   X3D_REQUIRE(d && d->g && d->w && d->dx, "pw_dgrad: null pointer");
   X3D_REQUIRE(d->coef && d->yraw, "pw_dgrad: coef/yraw required (every conv on the path feeds a BN)");
   X3D_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0 && d->H > 0 && d->W > 0,
               "pw_dgrad: bad extents");
-  X3D_REQUIRE(d->dtype == X3D_F32 || d->dtype == X3D_BF16, "pw_dgrad: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(d->dtype), "pw_dgrad: bad dtype");
   if (d->epi == X3D_EPI_ADD || d->epi == X3D_EPI_ADD_STRIDED)
     X3D_REQUIRE(d->add, "pw_dgrad: epilogue needs `add`");
   if (d->epi == X3D_EPI_SWISH_BWD)
@@ -39,33 +71,7 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   const int vec = pick_vec(eb, a.P, d->g, d->yraw);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == X3D_F32) return pw_dgrad_dispatch<float>(a, d->epi, vec, st);
-  const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
-  // stage 5: weights stationary.  The stage-4 shapes stay with the resident-panel kernel here: with two staged tensors
-  // the stationary kernel needs 132-146 VGPRs = one workgroup per CU (216 -> 96 dgrad: 58 -> 61 us)
-  // (strided shortcut gradient: even image width only -- pairs of points never straddle a row)
-  const int shp_ = (d->epi != X3D_EPI_ADD_STRIDED || (d->W % 2 == 0 && ((uintptr_t)d->add % 2) == 0)) ? pw_wst_shape(a, vec, ovec) : 0;
-  if (const int shp = shp_ <= 2 ? shp_ : 0) {
-    switch (d->epi) {
-      case X3D_EPI_ADD_STRIDED: return pw_wst_launch<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, shp, st);
-      case X3D_EPI_STORE: return pw_wst_launch<PRO_BNBWD, X3D_EPI_STORE>(a, shp, st);
-      case X3D_EPI_ADD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_ADD>(a, shp, st);
-      case X3D_EPI_SWISH_BWD: return pw_wst_launch<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, shp, st);
-    }
-  }
-  if (d->epi != X3D_EPI_ADD_STRIDED && pw_ws_applies(a, vec, ovec)) {   // deep, narrow layers (stage 5)
-    switch (d->epi) {
-      case X3D_EPI_STORE: return pw_ws_launch<PRO_BNBWD, X3D_EPI_STORE>(a, st);
-      case X3D_EPI_ADD: return pw_ws_launch<PRO_BNBWD, X3D_EPI_ADD>(a, st);
-      case X3D_EPI_SWISH_BWD: return pw_ws_launch<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st);
-    }
-  }
-  switch (d->epi) {  // bf16 storage: bf16 matrix cores
-    case X3D_EPI_STORE: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_STORE>(a, vec, ovec, st);
-    case X3D_EPI_ADD: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_ADD>(a, vec, ovec, st);
-    case X3D_EPI_ADD_STRIDED: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, vec, ovec, st);
-    case X3D_EPI_SWISH_BWD: return pw_bf16_launch_vec<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, vec, ovec, st);
-  }
-  x3d_set_error("pw_dgrad: unknown epilogue %d", d->epi);
-  return X3D_ERR_INVALID;
+  return d->dtype == X3D_F16 ? pw_dgrad_h16<f16>(a, d, eb, vec, st) : pw_dgrad_h16<bf16>(a, d, eb, vec, st);
 }
+
 

@@ -1,12 +1,23 @@
 // x3d_pw_fwd: pointwise convolution forward (see pw_gemm.h)
 #include "pw_gemm_wst.h"
 
+template <typename H>
+static int pw_fwd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st) {
+  const int shp_ = pw_wst_shape(a, vec, ovec);       // stage 4 / 5: weights stationary in registers
+  if (const int shp = (shp_ == 5 && pro) ? 0 : shp_)  // (shape 5 with a prologue: 129 VGPRs, one workgroup per CU)
+    return pro ? pw_wst_launch<H, PRO_AFFINE, EPI_STATS>(a, shp, st) : pw_wst_launch<H, PRO_NONE, EPI_STATS>(a, shp, st);
+  if (pw_ws_applies(a, vec, ovec))   // deep, narrow layers (stage 5): weights streamed, 32-point tiles
+    return pro ? pw_ws_launch<H, PRO_AFFINE, EPI_STATS>(a, st) : pw_ws_launch<H, PRO_NONE, EPI_STATS>(a, st);
+  return pro ? pw_bf16_launch_vec<H, PRO_AFFINE, EPI_STATS>(a, vec, ovec, st)
+             : pw_bf16_launch_vec<H, PRO_NONE, EPI_STATS>(a, vec, ovec, st);
+}
+
 extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   X3D_REQUIRE(f && f->x && f->w && f->y, "pw_fwd: null pointer");
   X3D_REQUIRE(f->stride == 1 || f->stride == 2, "pw_fwd: stride must be 1 or 2");
   X3D_REQUIRE(f->N > 0 && f->Cin > 0 && f->Cout > 0 && f->T > 0 && f->H > 0 && f->W > 0,
               "pw_fwd: bad extents");
-  X3D_REQUIRE(f->dtype == X3D_F32 || f->dtype == X3D_BF16, "pw_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(f->dtype), "pw_fwd: bad dtype");
   X3D_REQUIRE(!(f->stride > 1 && f->in_scale_shift), "pw_fwd: strided input takes no prologue");
   X3D_REQUIRE(((uintptr_t)f->w_panel % 16) == 0, "pw_fwd: w_panel must be 16-byte aligned");
   PwGemmArgs a;
@@ -29,14 +40,23 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   if (f->dtype == X3D_F32)
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
-  // bf16 storage: bf16 matrix cores (fp32 accumulate)
+  // 16-bit storage: bf16 / f16 matrix cores (fp32 accumulate)
   const int ovec = pick_vec(eb, a.P, f->y);
-  const int shp_ = pw_wst_shape(a, vec, ovec);       // stage 4 / 5: weights stationary in registers
-  if (const int shp = (shp_ == 5 && pro) ? 0 : shp_)  // (shape 5 with a prologue: 129 VGPRs, one workgroup per CU)
-    return pro ? pw_wst_launch<PRO_AFFINE, EPI_STATS>(a, shp, st) : pw_wst_launch<PRO_NONE, EPI_STATS>(a, shp, st);
-  if (pw_ws_applies(a, vec, ovec))   // deep, narrow layers (stage 5): weights streamed, 32-point tiles
-    return pro ? pw_ws_launch<PRO_AFFINE, EPI_STATS>(a, st) : pw_ws_launch<PRO_NONE, EPI_STATS>(a, st);
-  return pro ? pw_bf16_launch_vec<PRO_AFFINE, EPI_STATS>(a, vec, ovec, st)
-             : pw_bf16_launch_vec<PRO_NONE, EPI_STATS>(a, vec, ovec, st);
+  return f->dtype == X3D_F16 ? pw_fwd_h16<f16>(a, vec, ovec, pro, st) : pw_fwd_h16<bf16>(a, vec, ovec, pro, st);
 }
 
+
+// dry-run dispatch of the four pointwise entry points (include/x3d_hip.h): the launchers stop at X3D_DESCRIBE
+extern "C" int x3d_pw_kernel_name(const x3d_pw_fwd_args* fwd, const x3d_pw_dgrad_args* dgrad, const x3d_pw_wgrad_args* wgrad,
+                                  const x3d_pw_bwd_args* bwd, char* out, int cap) {
+  X3D_REQUIRE(out && cap > 0, "pw_kernel_name: no output buffer");
+  X3D_REQUIRE((fwd != nullptr) + (dgrad != nullptr) + (wgrad != nullptr) + (bwd != nullptr) == 1,
+              "pw_kernel_name: exactly one argument struct");
+  out[0] = 0;
+  x3d_describe = {out, cap};
+  const int rc = fwd ? x3d_pw_fwd(fwd, nullptr) : dgrad ? x3d_pw_dgrad(dgrad, nullptr) : wgrad ? x3d_pw_wgrad(wgrad, nullptr)
+                                                                                       : x3d_pw_bwd(bwd, nullptr);
+  x3d_describe = {nullptr, 0};
+  if (rc == X3D_OK && out[0] == 0) { x3d_set_error("pw_kernel_name: the dispatch launched nothing"); return X3D_ERR_INVALID; }
+  return rc;
+}

@@ -271,6 +271,7 @@ static int pw_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   if (tpb > tiles_per_n) tpb = (int)tiles_per_n;
   a.tiles_per_block = tpb;
   const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
+  X3D_DESCRIBE("pw_gemm_kernel<float, %d, %d, %d, %d, %d, %d>", VEC, MT, NT, PRO, EPI, (int)STRIDED);
   auto kern = pw_gemm_kernel<T, VEC, MT, NT, PRO, EPI, STRIDED>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;  // per instantiation

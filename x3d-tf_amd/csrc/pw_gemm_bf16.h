@@ -30,10 +30,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define PWB_XP (PWB_BN + 32)   // X pitch (elements)
 #define PWB_OP (PWB_BN + 4)    // output-tile pitch (floats)
 
-template <int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
+template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   constexpr int BM = MT * 32, BN = PWB_BN, XP = PWB_XP, OP = PWB_OP, KCH = PWB_KCH;
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   // buffer stores with a static count per tile (see the epilogue); M*P*2 < 2^31 bytes is checked by the host
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   // the activation chunk and the fp32 output tile are never live together: they share one LDS region
   // (a 34 KB saving that keeps two workgroups per CU up to K ~ 300)
   constexpr size_t XO_BYTES = ((size_t)KCH * XP * 2 > (size_t)SLAB * 32 * OP * 4) ? (size_t)KCH * XP * 2 : (size_t)SLAB * 32 * OP * 4;
-  bf16* Xs = (bf16*)smem_raw;                         // [KCH][XP]
+  H* Xs = (H*)smem_raw;                         // [KCH][XP]
   float* Os = (float*)smem_raw;                       // [SLAB * 32][OP]   (aliases Xs)
-  bf16* Ws = (bf16*)(smem_raw + XO_BYTES);            // [BM][WP]
+  H* Ws = (H*)(smem_raw + XO_BYTES);            // [BM][WP]
   // per-row prologue coefficients in LDS ([Kp][4] floats, zero for padded rows): AFFINE {s*gate, t*gate}, BNBWD
   // {A, B, C}.  Read from global inside the prologue they cost an exposed L2 round trip per chunk.
   float* Cs = (float*)(smem_raw + XO_BYTES + (size_t)BM * (a.KC + 8) * 2);
@@ -72,14 +73,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   // along their contiguous axis with the widest aligned vector (4/2/1 floats).
   if (a.wp) {
     // packed panel: the LDS image itself, rows m0.. of pitch WP -> a flat 16-byte copy (rows past the panel: zero)
-    const bf16x8* src = (const bf16x8*)((const bf16*)a.wp + (long long)m0 * WP);
+    const hx8* src = (const hx8*)((const H*)a.wp + (long long)m0 * WP);
     const int nvec = BM * WP / 8;
     const int lim = max(0, min(BM, a.wp_rows - m0)) * WP / 8;
-    bf16x8 zero;
+    hx8 zero;
 #pragma unroll
-    for (int e = 0; e < 8; e++) zero[e] = (bf16)0.f;
+    for (int e = 0; e < 8; e++) zero[e] = (H)0.f;
 #pragma unroll 4
-    for (int i = tid; i < nvec; i += 256) ((bf16x8*)Ws)[i] = i < lim ? src[i] : zero;
+    for (int i = tid; i < nvec; i += 256) ((hx8*)Ws)[i] = i < lim ? src[i] : zero;
   } else {
     const int wv = a.wvec;
     if (a.wsk == 1) {            // forward: source rows are k-contiguous -> one LDS row segment per vector
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         const int m = i / kv, k = (i - m * kv) * wv;
         const int gm = m0 + m;
         const float* src = a.w + (long long)gm * a.wsm + k;
-        bf16* dst = &Ws[m * WP + k];
-        for (int e = 0; e < wv; e += 1) dst[e] = (bf16)0.f;
+        H* dst = &Ws[m * WP + k];
+        for (int e = 0; e < wv; e += 1) dst[e] = (H)0.f;
         if (gm < a.M && k < a.K) {
-          if (wv == 4) { const f32x4 v = *(const f32x4*)src; dst[0] = (bf16)v[0]; dst[1] = (bf16)v[1]; dst[2] = (bf16)v[2]; dst[3] = (bf16)v[3]; }
-          else if (wv == 2) { const float2 v = *(const float2*)src; dst[0] = (bf16)v.x; dst[1] = (bf16)v.y; }
-          else dst[0] = (bf16)src[0];
+          if (wv == 4) { const f32x4 v = *(const f32x4*)src; dst[0] = (H)v[0]; dst[1] = (H)v[1]; dst[2] = (H)v[2]; dst[3] = (H)v[3]; }
+          else if (wv == 2) { const float2 v = *(const float2*)src; dst[0] = (H)v.x; dst[1] = (H)v.y; }
+          else dst[0] = (H)src[0];
         }
       }
     } else {                     // dgrad: source rows are m-contiguous -> a vector scatters over wv LDS rows
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           if (wv == 4 && gm + 3 < a.M) { const f32x4 t = *(const f32x4*)src; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
           else for (int e = 0; e < wv; e++) if (gm + e < a.M) v[e] = src[e];
         }
-        for (int e = 0; e < wv; e++) Ws[(m + e) * WP + k] = (bf16)v[e];
+        for (int e = 0; e < wv; e++) Ws[(m + e) * WP + k] = (H)v[e];
       }
     }
   }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   if (tile_begin < tile_end) fill_coef(tile_begin / tiles_per_n);
 
   // ---- register-staged prefetch of one [kc][BN] chunk
-  bf16x8 xr[NSV], yr[(PRO == PRO_BNBWD || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
+  hx8 xr[NSV], yr[(PRO == PRO_BNBWD || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
   float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && PRO == PRO_BNBWD) ? NSV : 1];
   auto issue_loads = [&](int tile, int kc_idx) {
     const int n = tile / tiles_per_n;
@@ -152,9 +153,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const long long p = p0 + (long long)pv * VEC;
       const bool ok = (k < kc) && (gk < a.K) && (p < a.P);
       if constexpr (VEC == 8) {
-        bf16x8 z;
+        hx8 z;
 #pragma unroll
-        for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+        for (int e = 0; e < 8; e++) z[e] = (H)0.f;
         xr[i] = z;
         if constexpr (PRO == PRO_BNBWD) yr[i] = z;
         if constexpr (STRIDED) yr[i] = z;
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           } else {
             // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
             const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
-            xr[i] = *(const bf16x8*)((const T*)a.x + o);
-            if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+            xr[i] = *(const hx8*)((const T*)a.x + o);
+            if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
           }
         }
       } else {
@@ -199,15 +200,15 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       const int k = v / VPR, pv = v - k * VPR;
       if (k >= kc) continue;
       const int gk = k0 + k;
-      bf16* dst = &Xs[k * XP + pv * VEC];
+      H* dst = &Xs[k * XP + pv * VEC];
       if constexpr (PRO == PRO_NONE) {
         if constexpr (VEC == 8 && STRIDED) {
-          bf16x8 o;
+          hx8 o;
 #pragma unroll
           for (int e = 0; e < 4; e++) { o[e] = xr[i][2 * e]; o[4 + e] = yr[i][2 * e]; }
-          *(bf16x8*)dst = o;
-        } else if constexpr (VEC == 8) *(bf16x8*)dst = xr[i];
-        else dst[0] = (bf16)xs1[i];
+          *(hx8*)dst = o;
+        } else if constexpr (VEC == 8) *(hx8*)dst = xr[i];
+        else dst[0] = (H)xs1[i];
       } else {
         float val[VEC];
         if constexpr (VEC == 8) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
             val[e] = cf[0] * val[e] + cf[1] * y2 + cf[2];
           }
         }
-        VecIO<bf16, VEC>::store(dst, val);
+        VecIO<H, VEC>::store(dst, val);
       }
     }
   };
@@ -326,11 +327,11 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row) * XP + tr_col]));
         const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row + 4) * XP + tr_col]));
         const s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bs);
+        const hx8 bfrag = __builtin_bit_cast(hx8, bs);
 #pragma unroll
         for (int s = 0; s < MT; s++) {
-          const bf16x8 afrag = *(const bf16x8*)&Ws[(s * 32 + r) * WP + k0 + kk + 8 * half];
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[s], 0, 0, 0);
+          const hx8 afrag = *(const hx8*)&Ws[(s * 32 + r) * WP + k0 + kk + 8 * half];
+          acc[s] = mfma16<H>(afrag, bfrag, acc[s]);
         }
       }
     }
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     // the (older) prefetch, and nothing ever waits on a store.
     constexpr bool EPL8 = (OVEC == 8) && (EPI == X3D_EPI_ADD || EPI == X3D_EPI_SWISH_BWD);
     constexpr bool EPL4 = (OVEC == 8) && (EPI == X3D_EPI_ADD_STRIDED);
-    bf16x8 epl8[EPL8 ? ROWS_PT : 1];
-    bf16x4 epl4[EPL4 ? ROWS_PT : 1];
+    hx8 epl8[EPL8 ? ROWS_PT : 1];
+    hx4 epl4[EPL4 ? ROWS_PT : 1];
     // the 8 points of a vector (p % 8 == 0) split into groups of egv points that stay inside one image row; each group's
     // even pixels receive egv / 2 contiguous half-resolution values.  egv = 8 / 4 / 2 by the row length; 0 (odd rows): scalar
     const int egv = !EPL4 ? 0 : ((a.eW & 7) == 0 ? 8 : ((a.eW & 3) == 0 ? 4 : ((a.eW & 1) == 0 ? 2 : 0)));
@@ -373,14 +374,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         const long long p = p0 + oc;
         if constexpr (EPL8) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) epl8[i][e] = (bf16)0.f;
+          for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
           if (m < a.M && p < a.P) {
             const long long o = ((long long)n * a.M + m) * a.P + p;
-            epl8[i] = *(const bf16x8*)((const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o);
+            epl8[i] = *(const hx8*)((const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o);
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) epl4[i][e] = (bf16)0.f;
+          for (int e = 0; e < 4; e++) epl4[i][e] = (H)0.f;
           if (epl4_vec && m < a.M && p < a.P) {
             const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
               const int t = (int)p / hw;
               const int rem = (int)p - t * hw;
               const int h = rem / a.eW, w = rem - h * a.eW;
-              if ((h & 1) == 0) epl4[i] = *(const bf16x4*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
+              if ((h & 1) == 0) epl4[i] = *(const hx4*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
             } else if (egv == 4) {
 #pragma unroll
               for (int gq = 0; gq < 2; gq++) {
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
                 const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
                 if ((h & 1) == 0) {
-                  const bf16x2 v2 = *(const bf16x2*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
+                  const hx2 v2 = *(const hx2*)(abase + ((long long)t * Hh + (h >> 1)) * Wh + (w >> 1));
                   epl4[i][2 * gq] = v2[0]; epl4[i][2 * gq + 1] = v2[1];
                 }
               }
@@ -504,9 +505,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         }
       }
       if constexpr (BSTORE) {
-        bf16x8 ov;
+        hx8 ov;
 #pragma unroll
-        for (int e = 0; e < 8; e++) ov[e] = (bf16)val[e];
+        for (int e = 0; e < 8; e++) ov[e] = (H)val[e];
         // byte offset inside sample n's [M][P] matrix; 0x80000000 is past num_records -> the store is discarded
         const unsigned off = rvalid ? (unsigned)(((long long)m * a.P + p) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), yrsrc, off, 0, 0);
@@ -555,7 +556,7 @@ static inline int pw_bf16_pick_mt(int M, int K) {
   return 2;
 }
 
-template <int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
+template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, BN = PWB_BN;
   a.KC = (a.K + 15) & ~15;
@@ -565,7 +566,8 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
   X3D_REQUIRE((long long)a.M * a.P * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
-  auto kern = pw_gemm_bf16_kernel<VEC, MT, PRO, EPI, STRIDED, OVEC>;
+  X3D_DESCRIBE("pw_gemm_bf16_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, VEC, MT, PRO, EPI, STRIDED, OVEC);
+  auto kern = pw_gemm_bf16_kernel<H, VEC, MT, PRO, EPI, STRIDED, OVEC>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -612,35 +614,35 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <int VEC, int PRO, int EPI, int STRIDED, int OVEC>
+template <typename H, int VEC, int PRO, int EPI, int STRIDED, int OVEC>
 static int pw_bf16_launch_tile(PwGemmArgs& a, hipStream_t st) {
   int mt = pw_bf16_pick_mt(a.M, a.K);
   if constexpr (VEC == 1) mt = mt > 2 ? 2 : mt;   // scalar fallback path: 32 staging registers per chunk, keep the panel small
   switch (mt) {
-    case 7: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 7, PRO, EPI, STRIDED, OVEC>(a, st);
-    case 4: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 4, PRO, EPI, STRIDED, OVEC>(a, st);
-    case 3: if constexpr (VEC != 1) return pw_bf16_launch_cfg<VEC, 3, PRO, EPI, STRIDED, OVEC>(a, st);
-    case 2: return pw_bf16_launch_cfg<VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
-    default: return pw_bf16_launch_cfg<VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 7: if constexpr (VEC != 1) return pw_bf16_launch_cfg<H, VEC, 7, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 4: if constexpr (VEC != 1) return pw_bf16_launch_cfg<H, VEC, 4, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 3: if constexpr (VEC != 1) return pw_bf16_launch_cfg<H, VEC, 3, PRO, EPI, STRIDED, OVEC>(a, st);
+    case 2: return pw_bf16_launch_cfg<H, VEC, 2, PRO, EPI, STRIDED, OVEC>(a, st);
+    default: return pw_bf16_launch_cfg<H, VEC, 1, PRO, EPI, STRIDED, OVEC>(a, st);
   }
 }
 
 // vec: common alignment (elements) of the streamed inputs; ovec: of the outputs / epilogue tensors
-template <int PRO, int EPI>
+template <typename H, int PRO, int EPI>
 static int pw_bf16_launch_vec(PwGemmArgs& a, int vec, int ovec, hipStream_t st) {
   if (a.stride > 1) {
     if constexpr (PRO == PRO_NONE && EPI == EPI_STATS) {
       const int gv = (a.stride == 2 && vec >= 1 && ovec >= 8) ? strided_gather_gv(a.W, a.Wo, a.P, a.x) : 0;
-      if (gv == 4) return pw_bf16_launch_tile<8, PRO, EPI, 4, 8>(a, st);
-      if (gv == 2) return pw_bf16_launch_tile<8, PRO, EPI, 2, 8>(a, st);
-      if (gv == 1) return pw_bf16_launch_tile<8, PRO, EPI, 1, 8>(a, st);
-      if (ovec >= 8) return pw_bf16_launch_tile<1, PRO, EPI, 1, 8>(a, st);
-      return pw_bf16_launch_tile<1, PRO, EPI, 1, 1>(a, st);
+      if (gv == 4) return pw_bf16_launch_tile<H, 8, PRO, EPI, 4, 8>(a, st);
+      if (gv == 2) return pw_bf16_launch_tile<H, 8, PRO, EPI, 2, 8>(a, st);
+      if (gv == 1) return pw_bf16_launch_tile<H, 8, PRO, EPI, 1, 8>(a, st);
+      if (ovec >= 8) return pw_bf16_launch_tile<H, 1, PRO, EPI, 1, 8>(a, st);
+      return pw_bf16_launch_tile<H, 1, PRO, EPI, 1, 1>(a, st);
     } else {
       x3d_set_error("pw: strided gather only in forward");
       return X3D_ERR_INVALID;
     }
   }
-  if (vec >= 8 && ovec >= 8) return pw_bf16_launch_tile<8, PRO, EPI, 0, 8>(a, st);
-  return pw_bf16_launch_tile<1, PRO, EPI, 0, 1>(a, st);
+  if (vec >= 8 && ovec >= 8) return pw_bf16_launch_tile<H, 8, PRO, EPI, 0, 8>(a, st);
+  return pw_bf16_launch_tile<H, 1, PRO, EPI, 0, 1>(a, st);
 }

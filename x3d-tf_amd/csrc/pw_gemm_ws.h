@@ -24,17 +24,18 @@
 #define WS_OCC 2
 #endif
 
-template <int PRO, int EPI>
+template <typename H, int PRO, int EPI>
 __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   constexpr int BN = WS_BN, G = WS_G, OP = WS_OP;
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
   constexpr int NSV = 7;                                // staging vectors per thread: Kp * 4 / 256 <= 7 (Kp <= 448)
   const int Kp = a.KC, WP = Kp + 8;
   const int ksteps = Kp / 16;
-  bf16* Xs = (bf16*)smem_raw;                                                // [Kp][32]
+  H* Xs = (H*)smem_raw;                                                // [Kp][32]
   float* Cs = (float*)(smem_raw + (size_t)Kp * 64);                          // [Kp][CSW]
   float* Os = (float*)(smem_raw + (size_t)Kp * 64 + (size_t)Kp * 16);        // [4 waves][32][OP]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
   if (tile_begin < tile_end) fill_coef(tile_begin / tiles_per_n);
 
   // ---- staging: vector v = tid + 256*i -> row v >> 2, 8 points at unit v & 3
-  bf16x8 xr[NSV], yr[PRO == PRO_BNBWD ? NSV : 1];
+  hx8 xr[NSV], yr[PRO == PRO_BNBWD ? NSV : 1];
   auto issue_loads = [&](int tile) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
@@ -76,15 +77,15 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
       const int v = tid + i * 256;
       const int k = v >> 2;
       const long long p = p0 + (v & 3) * 8;
-      bf16x8 z;
+      hx8 z;
 #pragma unroll
-      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+      for (int e = 0; e < 8; e++) z[e] = (H)0.f;
       xr[i] = z;
       if constexpr (PRO == PRO_BNBWD) yr[i] = z;
       if (k < a.K && p < a.P) {
         const long long o = ((long long)n * a.K + k) * a.P + p;
-        xr[i] = *(const bf16x8*)((const T*)a.x + o);
-        if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+        xr[i] = *(const hx8*)((const T*)a.x + o);
+        if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
       }
     }
   };
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
       const int v = tid + i * 256;
       const int k = v >> 2;
       if (k >= Kp) continue;
-      bf16* dst = &Xs[k * BN + (v & 3) * 8];
+      H* dst = &Xs[k * BN + (v & 3) * 8];
       if constexpr (PRO == PRO_NONE) {
-        *(bf16x8*)dst = xr[i];
+        *(hx8*)dst = xr[i];
       } else {
         float val[8];
 #pragma unroll
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] = cf[0] * val[e] + cf[1] * (float)yr[i][e] + cf[2];
         }
-        VecIO<bf16, 8>::store(dst, val);
+        VecIO<H, 8>::store(dst, val);
       }
     }
   };
@@ -175,27 +176,27 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
       if (mi >= mt) break;
       // ---- 32x32 block mi: A from the packed panel in global memory, groups of G k-steps, double buffered
       // tiled image behind the row-major one (pw_pack.hip): k-step ks of row block mi = 64 lanes x 16 B, contiguous
-      const bf16* wrow = (const bf16*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * ksteps * 64 + lane) * 8;
+      const H* wrow = (const H*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * ksteps * 64 + lane) * 8;
       f32x16 acc;
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[j] = 0.f;
-      bf16x8 A0[G], A1[G];
+      hx8 A0[G], A1[G];
       // a group of G k-steps is either whole (no per-step test, unconditional loads: every group but possibly the last)
       // or ragged; one uniform branch per GROUP picks the variant -- the per-step tests were 2 scalar branches per MFMA
-      auto loadA = [&](bf16x8 (&A)[G], int ks0, auto FULL) {
+      auto loadA = [&](hx8 (&A)[G], int ks0, auto FULL) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
           if constexpr (decltype(FULL)::value) {
-            A[j] = *(const bf16x8*)(wrow + (ks0 + j) * 512);
+            A[j] = *(const hx8*)(wrow + (ks0 + j) * 512);
           } else {
-            bf16x8 z;
+            hx8 z;
 #pragma unroll
-            for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-            A[j] = (ks0 + j < ksteps) ? *(const bf16x8*)(wrow + (ks0 + j) * 512) : z;
+            for (int e = 0; e < 8; e++) z[e] = (H)0.f;
+            A[j] = (ks0 + j < ksteps) ? *(const hx8*)(wrow + (ks0 + j) * 512) : z;
           }
         }
       };
-      auto mmaA = [&](const bf16x8 (&A)[G], int ks0, auto FULL) {
+      auto mmaA = [&](const hx8 (&A)[G], int ks0, auto FULL) {
 #pragma unroll
         for (int j = 0; j < G; j++) {
           if (decltype(FULL)::value || ks0 + j < ksteps) {
@@ -203,15 +204,15 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
             const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row) * BN + tr_col]));
             const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Xs[(kk + tr_row + 4) * BN + tr_col]));
             const s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], __builtin_bit_cast(bf16x8, bs), acc, 0, 0, 0);
+            acc = mfma16<H>(A[j], __builtin_bit_cast(hx8, bs), acc);
           }
         }
       };
-      auto load_g = [&](bf16x8 (&A)[G], int ks0) {
+      auto load_g = [&](hx8 (&A)[G], int ks0) {
         if (ks0 + G <= ksteps) loadA(A, ks0, std::true_type{});
         else if (ks0 < ksteps) loadA(A, ks0, std::false_type{});
       };
-      auto mma_g = [&](const bf16x8 (&A)[G], int ks0) {
+      auto mma_g = [&](const hx8 (&A)[G], int ks0) {
         if (ks0 + G <= ksteps) mmaA(A, ks0, std::true_type{});
         else if (ks0 < ksteps) mmaA(A, ks0, std::false_type{});
       };
@@ -292,11 +293,12 @@ static inline bool pw_ws_applies(const PwGemmArgs& a, int vec, int ovec) {
   return tiles128 <= 1024 && a.K >= 320 && a.M <= 256;
 }
 
-template <int PRO, int EPI>
+template <typename H, int PRO, int EPI>
 static int pw_ws_launch(PwGemmArgs& a, hipStream_t st) {
   a.KC = (a.K + 15) & ~15;
   const size_t lds = pw_ws_lds_bytes(a.K);
-  auto kern = pw_gemm_ws_kernel<PRO, EPI>;
+  X3D_DESCRIBE("pw_gemm_ws_kernel<%s, %d, %d>", HV<H>::name, PRO, EPI);
+  auto kern = pw_gemm_ws_kernel<H, PRO, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -18,17 +18,18 @@
 // the four SIMDs evenly loaded), the first NW of them own row blocks
 #define WST_NWT 8
 
-template <int PRO, int EPI, int NW, int RB, int KS, int OCC>
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC>
 __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemmArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   constexpr int BN = WS_BN, OP = WS_OP, NT = WST_NWT * 64, Kp = KS * 16, WP = Kp + 8;
   static_assert(NW <= WST_NWT, "MFMA waves are a subset of the workgroup");
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
   constexpr int NSV = (Kp * 4 + NT - 1) / NT;             // staging vectors (8 points) per thread
-  bf16* Xs = (bf16*)smem_raw;                                               // [2][Kp][32]
+  H* Xs = (H*)smem_raw;                                               // [2][Kp][32]
   float* Cs = (float*)(smem_raw + (size_t)2 * Kp * 64);                     // [Kp][CSW]
   float* Os = (float*)(smem_raw + (size_t)2 * Kp * 64 + (size_t)Kp * 16);   // [NW waves][32][OP]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -42,19 +43,19 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   float* myOs = Os + wid * 32 * OP;
 
   // ---- the stationary operand
-  bf16x8 A[RB][KS];
+  hx8 A[RB][KS];
 #pragma unroll
   for (int j = 0; j < RB; j++) {
     const int mi = wid + NW * j;
     if (wid < NW && mi < mt) {
-      const bf16* wt = (const bf16*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * KS * 64 + lane) * 8;
+      const H* wt = (const H*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * KS * 64 + lane) * 8;
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) A[j][ks] = *(const bf16x8*)(wt + ks * 512);
+      for (int ks = 0; ks < KS; ks++) A[j][ks] = *(const hx8*)(wt + ks * 512);
     } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-        for (int e = 0; e < 8; e++) A[j][ks][e] = (bf16)0.f;
+        for (int e = 0; e < 8; e++) A[j][ks][e] = (H)0.f;
     }
   }
 
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   // epilogue, barrier, MFMAs) covers their latency.  Tiles past the end re-load the last tile (unconditional: the
   // number of loads in flight stays static and the compiler can wait with an exact vmcnt).
   constexpr int NSY = PRO == PRO_BNBWD ? NSV : 1;
-  bf16x8 xr0[NSV], yr0[NSY], xr1[NSV], yr1[NSY];
-  auto issue_loads = [&](int tile_, bf16x8 (&xr)[NSV], bf16x8 (&yr)[NSY]) {
+  hx8 xr0[NSV], yr0[NSY], xr1[NSV], yr1[NSY];
+  auto issue_loads = [&](int tile_, hx8 (&xr)[NSV], hx8 (&yr)[NSY]) {
     const int tile = min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
@@ -95,11 +96,11 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const long long p = p0 + (v & 3) * 8;
       const bool ok = k < a.K && p < a.P;
       const long long o = ok ? ((long long)n * a.K + k) * a.P + p : 0;
-      xr[i] = *(const bf16x8*)((const T*)a.x + o);
-      if constexpr (PRO == PRO_BNBWD) yr[i] = *(const bf16x8*)((const T*)a.x2 + o);
+      xr[i] = *(const hx8*)((const T*)a.x + o);
+      if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
     }
   };
-  auto commit = [&](int tile, bf16* dstbuf, const bf16x8 (&xr)[NSV], const bf16x8 (&yr)[NSY]) {
+  auto commit = [&](int tile, H* dstbuf, const hx8 (&xr)[NSV], const hx8 (&yr)[NSY]) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -108,12 +109,12 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const int k = v >> 2;
       if (k >= Kp) continue;
       const bool ok = k < a.K && p0 + (v & 3) * 8 < a.P;
-      bf16* dst = &dstbuf[k * BN + (v & 3) * 8];
-      bf16x8 z;
+      H* dst = &dstbuf[k * BN + (v & 3) * 8];
+      hx8 z;
 #pragma unroll
-      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+      for (int e = 0; e < 8; e++) z[e] = (H)0.f;
       if constexpr (PRO == PRO_NONE) {
-        *(bf16x8*)dst = ok ? xr[i] : z;
+        *(hx8*)dst = ok ? xr[i] : z;
       } else {
         float val[8];
 #pragma unroll
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] = 0.f;
         }
-        VecIO<bf16, 8>::store(dst, val);
+        VecIO<H, 8>::store(dst, val);
       }
     }
   };
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   issue_loads(tile_begin + 2, xr0, yr0);
 
   // one tile: MFMAs of `tile`, commit of tile + 1 out of the register set (xr, yr), re-load that set with tile + 3
-  auto step = [&](int tile, int cur, bf16x8 (&xr)[NSV], bf16x8 (&yr)[NSY]) {
+  auto step = [&](int tile, int cur, hx8 (&xr)[NSV], hx8 (&yr)[NSY]) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     if (n != n_prev) {
@@ -193,9 +194,9 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     n_prev = n;
 
     // ---- epilogue operands of this tile, in flight during the MFMAs
-    bf16x8 eo[EPI_LOADS ? RB : 1][2];
+    hx8 eo[EPI_LOADS ? RB : 1][2];
     f32x16 acc[RB];
-    bf16 es[EPI == X3D_EPI_ADD_STRIDED ? RB : 1][2][4];      // strided shortcut gradient: one value per even pixel
+    H es[EPI == X3D_EPI_ADD_STRIDED ? RB : 1][2][4];      // strided shortcut gradient: one value per even pixel
     if (wid < NW) {
     if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
       // dx [eH x eW] receives `add` [ceil(eH/2) x ceil(eW/2)] on its even pixels.  eW is even (dispatch): the 8 points of
@@ -213,8 +214,8 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
             const int t = pe / hw, rem = pe - t * hw;
             const int h = rem / a.eW, w = rem - h * a.eW;
             const bool ok = m < a.M && pe < (int)a.P && (h & 1) == 0;
-            const bf16 v = abase[ok ? (t * Hh + (h >> 1)) * Wh + (w >> 1) : 0];
-            es[j][hv][gq] = ok ? v : (bf16)0.f;
+            const H v = abase[ok ? (t * Hh + (h >> 1)) * Wh + (w >> 1) : 0];
+            es[j][hv][gq] = ok ? v : (H)0.f;
           }
       }
     }
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.P + p : 0;
-          eo[j][hv] = *(const bf16x8*)(src + o);
+          eo[j][hv] = *(const hx8*)(src + o);
         }
       }
     }
 
     // ---- MFMAs: B operand from the current LDS tile, A from registers
-    const bf16* xb = Xs + cur * (Kp * BN) + tr_off;
+    const H* xb = Xs + cur * (Kp * BN) + tr_off;
 #pragma unroll
     for (int j = 0; j < RB; j++)
 #pragma unroll
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb + ks * 16 * BN));
       const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xb + (ks * 16 + 4) * BN));
       const s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      const bf16x8 bv = __builtin_bit_cast(bf16x8, bs);
+      const hx8 bv = __builtin_bit_cast(hx8, bs);
 #pragma unroll
-      for (int j = 0; j < RB; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][ks], bv, acc[j], 0, 0, 0);
+      for (int j = 0; j < RB; j++) acc[j] = mfma16<H>(A[j][ks], bv, acc[j]);
     }
 
     }   // wid < NW
@@ -349,11 +350,12 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   return 0;
 }
 
-template <int PRO, int EPI, int NW, int RB, int KS, int OCC>
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC>
 static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   a.KC = KS * 16;
   const size_t lds = pw_wst_lds_bytes<NW, KS>();
-  auto kern = pw_gemm_wst_kernel<PRO, EPI, NW, RB, KS, OCC>;
+  X3D_DESCRIBE("pw_gemm_wst_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, PRO, EPI, NW, RB, KS, OCC);
+  auto kern = pw_gemm_wst_kernel<H, PRO, EPI, NW, RB, KS, OCC>;
   static bool attr_set = false;
   static int cus = 256;
   if (!attr_set) {
@@ -373,13 +375,13 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <int PRO, int EPI>
+template <typename H, int PRO, int EPI>
 static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
   switch (shape) {
-    case 1: return pw_wst_launch_t<PRO, EPI, 6, 1, 27, 1>(a, st);
-    case 2: return pw_wst_launch_t<PRO, EPI, 7, 2, 12, 1>(a, st);
-    case 3: return pw_wst_launch_t<PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
-    case 4: return pw_wst_launch_t<PRO, EPI, 7, 1, 6, 2>(a, st);
-    default: return pw_wst_launch_t<PRO, EPI, 7, 2, 6, 2>(a, st);
+    case 1: return pw_wst_launch_t<H, PRO, EPI, 6, 1, 27, 1>(a, st);
+    case 2: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 12, 1>(a, st);
+    case 3: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
+    case 4: return pw_wst_launch_t<H, PRO, EPI, 7, 1, 6, 2>(a, st);
+    default: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 6, 2>(a, st);
   }
 }

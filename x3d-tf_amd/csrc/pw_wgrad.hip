@@ -146,6 +146,7 @@ static int pw_wgrad_launch(PwWgradArgs& a, hipStream_t st) {
   a.steps_per_block = spb;
   const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
   const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * 33 * sizeof(float);
+  X3D_DESCRIBE("pw_wgrad_kernel<float, %d, %d, %d, %d>", VEC, TPW, (int)XPRO, (int)STRIDED);
   auto kern = pw_wgrad_kernel<T, VEC, TPW, XPRO, STRIDED>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
@@ -187,7 +188,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(w->stride == 1 || w->stride == 2, "pw_wgrad: stride must be 1 or 2");
   X3D_REQUIRE(w->N > 0 && w->Cin > 0 && w->Cout > 0 && w->T > 0 && w->H > 0 && w->W > 0,
               "pw_wgrad: bad extents");
-  X3D_REQUIRE(w->dtype == X3D_F32 || w->dtype == X3D_BF16, "pw_wgrad: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(w->dtype), "pw_wgrad: bad dtype");
   X3D_REQUIRE(w->Cin <= 32 * 32, "pw_wgrad: Cin too large");
   PwWgradArgs a;
   memset(&a, 0, sizeof(a));
@@ -206,6 +207,10 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (w->dtype == X3D_F32) return pw_wgrad_dispatch<float>(a, vec, xpro, st);
   // bf16 storage: bf16 matrix cores; v2 = aligned fast path, v1 = generic (odd point counts / widths)
-  const int rc = pw_wgrad_v2_dispatch(a, vec, xpro, st);
-  return rc >= 0 ? rc : pw_wgrad_bf16_dispatch(a, vec, xpro, st);
+  if (w->dtype == X3D_F16) {
+    const int rc = pw_wgrad_v2_dispatch<f16>(a, vec, xpro, st);
+    return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<f16>(a, vec, xpro, st);
+  }
+  const int rc = pw_wgrad_v2_dispatch<bf16>(a, vec, xpro, st);
+  return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<bf16>(a, vec, xpro, st);
 }

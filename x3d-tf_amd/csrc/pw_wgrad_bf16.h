@@ -9,14 +9,15 @@
 #pragma once
 #include "common.h"
 
-template <int VEC, int TPW, bool XPRO, bool STRIDED>
+template <typename H, int VEC, int TPW, bool XPRO, bool STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   constexpr int BP = 64, LP = BP + 8;
   const int rowsA = a.mt_per_group * 32, rowsB = a.nt_total * 32;
-  bf16* As = (bf16*)smem_raw;        // [rowsA][LP]  dYraw
-  bf16* Bs = As + rowsA * LP;        // [rowsB][LP]  f(X)
+  H* As = (H*)smem_raw;        // [rowsA][LP]  dYraw
+  H* Bs = As + rowsA * LP;        // [rowsB][LP]  f(X)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int co0 = blockIdx.y * rowsA;
@@ -61,15 +62,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a)
 #pragma unroll
         for (int e = 0; e < VEC; e++) val[e] = 0.f;
       }
-      VecIO<bf16, VEC>::store(&As[row * LP + pv * VEC], val);
+      VecIO<H, VEC>::store(&As[row * LP + pv * VEC], val);
     }
     for (int v = tid; v < rowsB * VPR; v += 256) {
       const int row = v / VPR, pv = v - row * VPR;
       const long long p = p0 + (long long)pv * VEC;
-      bf16* dst = &Bs[row * LP + pv * VEC];
+      H* dst = &Bs[row * LP + pv * VEC];
       if (row < a.Cin && p < a.P) {
         if constexpr (!XPRO && !STRIDED && VEC == 8) {
-          *(bf16x8*)dst = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p);
+          *(hx8*)dst = *(const hx8*)((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p);
         } else {
           float val[VEC];
           if constexpr (STRIDED) {
@@ -89,13 +90,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a)
             for (int e = 0; e < VEC; e++) val[e] = (s * val[e] + t) * g;
             act_vec<VEC>(val, a.xact);
           }
-          VecIO<bf16, VEC>::store(dst, val);
+          VecIO<H, VEC>::store(dst, val);
         }
       } else {
         float z[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e++) z[e] = 0.f;
-        VecIO<bf16, VEC>::store(dst, z);
+        VecIO<H, VEC>::store(dst, z);
       }
     }
     __syncthreads();
@@ -105,12 +106,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a)
       if (nks > 1) { id = wid % ntiles; kpart = wid / ntiles; }
       if (id < ntiles) {
         const int mt = id / a.nt_total, nt = id - mt * a.nt_total;
-        const bf16* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
-        const bf16* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const H* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const H* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
         for (int ks = 0; ks < ksteps; ks++) {
-          const bf16x8 af = *(const bf16x8*)(ap + ks * 16);
-          const bf16x8 bf = *(const bf16x8*)(bp + ks * 16);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[s], 0, 0, 0);
+          const hx8 af = *(const hx8*)(ap + ks * 16);
+          const hx8 bf = *(const hx8*)(bp + ks * 16);
+          acc[s] = mfma16<H>(af, bf, acc[s]);
         }
       }
     }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const PwWgradArgs a)
   }
 }
 
-template <int VEC, int TPW, bool XPRO, bool STRIDED>
+template <typename H, int VEC, int TPW, bool XPRO, bool STRIDED>
 static int pw_wgrad_bf16_launch(PwWgradArgs& a, hipStream_t st) {
   const int mt_total = ceil_div(a.Cout, 32);
   a.nt_total = ceil_div(a.Cin, 32);
@@ -150,7 +151,8 @@ static int pw_wgrad_bf16_launch(PwWgradArgs& a, hipStream_t st) {
   a.steps_per_block = spb;
   const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
   const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * 72 * 2;
-  auto kern = pw_wgrad_bf16_kernel<VEC, TPW, XPRO, STRIDED>;
+  X3D_DESCRIBE("pw_wgrad_bf16_kernel<%s, %d, %d, %d, %d>", HV<H>::name, VEC, TPW, (int)XPRO, (int)STRIDED);
+  auto kern = pw_wgrad_bf16_kernel<H, VEC, TPW, XPRO, STRIDED>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -163,24 +165,25 @@ static int pw_wgrad_bf16_launch(PwWgradArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <int VEC, bool XPRO, bool STRIDED>
+template <typename H, int VEC, bool XPRO, bool STRIDED>
 static int pw_wgrad_bf16_tpw(PwWgradArgs& a, hipStream_t st) {
   const int nt = ceil_div(a.Cin, 32), mt = ceil_div(a.Cout, 32);
   const int tiles = nt * mt;
-  if (tiles <= 4) return pw_wgrad_bf16_launch<VEC, 1, XPRO, STRIDED>(a, st);
-  if (tiles <= 8) return pw_wgrad_bf16_launch<VEC, 2, XPRO, STRIDED>(a, st);
-  if (tiles <= 16) return pw_wgrad_bf16_launch<VEC, 4, XPRO, STRIDED>(a, st);
-  return pw_wgrad_bf16_launch<VEC, 8, XPRO, STRIDED>(a, st);
+  if (tiles <= 4) return pw_wgrad_bf16_launch<H, VEC, 1, XPRO, STRIDED>(a, st);
+  if (tiles <= 8) return pw_wgrad_bf16_launch<H, VEC, 2, XPRO, STRIDED>(a, st);
+  if (tiles <= 16) return pw_wgrad_bf16_launch<H, VEC, 4, XPRO, STRIDED>(a, st);
+  return pw_wgrad_bf16_launch<H, VEC, 8, XPRO, STRIDED>(a, st);
 }
 
+template <typename H>
 static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
   if (a.stride > 1) {
     if (xpro) { x3d_set_error("pw_wgrad: strided input takes no prologue"); return X3D_ERR_INVALID; }
-    return pw_wgrad_bf16_tpw<1, false, true>(a, st);
+    return pw_wgrad_bf16_tpw<H, 1, false, true>(a, st);
   }
   if (vec >= 8)
-    return xpro ? pw_wgrad_bf16_tpw<8, true, false>(a, st) : pw_wgrad_bf16_tpw<8, false, false>(a, st);
-  return xpro ? pw_wgrad_bf16_tpw<1, true, false>(a, st) : pw_wgrad_bf16_tpw<1, false, false>(a, st);
+    return xpro ? pw_wgrad_bf16_tpw<H, 8, true, false>(a, st) : pw_wgrad_bf16_tpw<H, 8, false, false>(a, st);
+  return xpro ? pw_wgrad_bf16_tpw<H, 1, true, false>(a, st) : pw_wgrad_bf16_tpw<H, 1, false, false>(a, st);
 }
 
 // ================================================================================================
@@ -197,16 +200,17 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
 //  * strided shortcut (1x1x1, stride (1,2,2), valid): an output row segment of 8 points is the even
 //    elements of 16 contiguous input elements -> two 16-byte loads, no scalar gather.
 // ================================================================================================
-template <int MG, int NG, bool XPRO, int STRIDED>
+template <typename H, int MG, int NG, bool XPRO, int STRIDED>
 __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
+  typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef bf16 T;
+  typedef H T;
   // U sub-steps of 64 points are staged and multiplied per barrier pair: half the barriers and twice the loads in
   // flight per thread (a 64-point step is ~400 instructions between two barriers: the waves mostly wait)
   constexpr int BP = 64, U = 2, LP = U * BP + 8;
   constexpr int TPW = (MG * NG + 3) / 4;
-  bf16* As = (bf16*)smem_raw;              // [MG*32][LP]  dYraw
-  bf16* Bs = As + MG * 32 * LP;            // [NG*32][LP]  f(X)
+  H* As = (H*)smem_raw;              // [MG*32][LP]  dYraw
+  H* Bs = As + MG * 32 * LP;            // [NG*32][LP]  f(X)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int srow = tid >> 3, sp = (tid & 7) * 8;       // staging row within a 32-row tile, first point
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
 
-  bf16x8 rg[U][MG], ry[U][MG], rx[U][NG], rx2[U][STRIDED ? NG : 1];
+  hx8 rg[U][MG], ry[U][MG], rx[U][NG], rx2[U][STRIDED ? NG : 1];
   // per-row coefficients are loop invariants of this thread (rows co0 + i*32 + srow / ci0 + i*32 + srow): loaded
   // once here instead of from global inside every step's prologue (an exposed L2 round trip per 64-point step);
   // only the SE gate depends on the sample and is re-read when the step crosses into the next sample
@@ -254,17 +258,17 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
   // was ~100 scalar instructions of the 380-860 in the loop
   auto issue = [&](int u, int n, int stp, bool live) {
     const long long p = live ? (long long)stp * BP + sp : a.P;   // a dead sub-step (past s_end) stages zeros
-    bf16x8 z;
+    hx8 z;
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
+    for (int e = 0; e < 8; e++) z[e] = (H)0.f;
 #pragma unroll
     for (int i = 0; i < MG; i++) {
       const int co = co0 + i * 32 + srow;
       rg[u][i] = z; ry[u][i] = z;
       if (co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
-        rg[u][i] = *(const bf16x8*)((const T*)a.g + o);
-        if (a.coef) ry[u][i] = *(const bf16x8*)((const T*)a.yraw + o);
+        rg[u][i] = *(const hx8*)((const T*)a.g + o);
+        if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
       }
     }
 #pragma unroll
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
           // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
           strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
         } else {
-          rx[u][i] = *(const bf16x8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
+          rx[u][i] = *(const hx8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
         }
       }
     }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
 #pragma unroll
     for (int i = 0; i < MG; i++) {
       const int co = co0 + i * 32 + srow;
-      bf16* dst = &As[(i * 32 + srow) * LP + u * BP + sp];
+      H* dst = &As[(i * 32 + srow) * LP + u * BP + sp];
       if (a.coef && co < a.Cout) {
         const float A = cA[i], B = cB[i], C = cC[i];
         float v[8];
@@ -297,20 +301,20 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = 0.f;      // C must not leak into padded points
         }
-        VecIO<bf16, 8>::store(dst, v);
+        VecIO<H, 8>::store(dst, v);
       } else {
-        *(bf16x8*)dst = rg[u][i];
+        *(hx8*)dst = rg[u][i];
       }
     }
 #pragma unroll
     for (int i = 0; i < NG; i++) {
       const int ci = ci0 + i * 32 + srow;
-      bf16* dst = &Bs[(i * 32 + srow) * LP + u * BP + sp];
+      H* dst = &Bs[(i * 32 + srow) * LP + u * BP + sp];
       if constexpr (STRIDED) {
-        bf16x8 o;
+        hx8 o;
 #pragma unroll
         for (int e = 0; e < 4; e++) { o[e] = rx[u][i][2 * e]; o[4 + e] = rx2[u][i][2 * e]; }
-        *(bf16x8*)dst = o;
+        *(hx8*)dst = o;
       } else if constexpr (XPRO) {
         float v[8];
         if (live && n != n_gate) load_gate(n);
@@ -322,9 +326,9 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
         act_vec<8>(v, a.xact);
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = pin ? v[e] : 0.f;
-        VecIO<bf16, 8>::store(dst, v);
+        VecIO<H, 8>::store(dst, v);
       } else {
-        *(bf16x8*)dst = rx[u][i];
+        *(hx8*)dst = rx[u][i];
       }
     }
   };
@@ -369,12 +373,12 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
       if (nks > 1) { id = wid % ntiles; kpart = wid / ntiles; }
       if (id < ntiles) {
         const int mt = id / nt_here, nt = id - mt * nt_here;
-        const bf16* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
-        const bf16* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const H* ap = As + (mt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
+        const H* bp = Bs + (nt * 32 + r) * LP + 8 * half + kpart * ksteps * 16;
         for (int ks = 0; ks < ksteps; ks++) {
-          const bf16x8 af = *(const bf16x8*)(ap + ks * 16);
-          const bf16x8 bf = *(const bf16x8*)(bp + ks * 16);
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[s], 0, 0, 0);
+          const hx8 af = *(const hx8*)(ap + ks * 16);
+          const hx8 bf = *(const hx8*)(bp + ks * 16);
+          acc[s] = mfma16<H>(af, bf, acc[s]);
         }
       }
     }
@@ -418,14 +422,15 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
   }
 }
 
-template <int MG, int NG, bool XPRO, int STRIDED>
+template <typename H, int MG, int NG, bool XPRO, int STRIDED>
 static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
   const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
   const size_t lds = (size_t)(MG + NG) * 32 * (2 * 64 + 8) * 2;
-  auto kern = pw_wgrad_bf16_v2_kernel<MG, NG, XPRO, STRIDED>;
+  X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED);
+  auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -463,7 +468,7 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   return X3D_OK;
 }
 
-template <bool XPRO, int STRIDED>
+template <typename H, bool XPRO, int STRIDED>
 static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   // X rows may carry the swish prologue: prefer few M-groups (each re-stages every X row of its N-group)
@@ -473,7 +478,7 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
     // every dY / X row by the other tile groups, but need 232-252 VGPRs + 64 AGPRs (one workgroup per CU):
     // measured slower (80 -> 100 us), so 128 x 64 stays the default
     static const char* e = getenv("X3D_PW_WG_NG4");
-    if (MG == 4 && nt >= 4 && e && atoi(e) == 1) return pw_wgrad_v2_launch<4, 4, XPRO, STRIDED>(a, st);
+    if (MG == 4 && nt >= 4 && e && atoi(e) == 1) return pw_wgrad_v2_launch<H, 4, 4, XPRO, STRIDED>(a, st);
   }
   if constexpr (STRIDED == 0) {
     // wide layers: every dY (+ yraw) row is staged once per N-group and every X row once per M-group, so the tile shape
@@ -485,26 +490,27 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
       const int dyr = a.coef ? 2 : 1;
       auto rows = [&](int mg, int ng) { return (long long)ceil_div(nt, ng) * dyr * a.Cout + (long long)ceil_div(mt, mg) * a.Cin; };
       const long long r42 = rows(4, 2), r43 = rows(4, 3), r34 = rows(3, 4);
-      if (r43 < r42 && r43 <= r34) return pw_wgrad_v2_launch<4, 3, XPRO, STRIDED>(a, st);
-      if (r34 < r42) return pw_wgrad_v2_launch<3, 4, XPRO, STRIDED>(a, st);
+      if (r43 < r42 && r43 <= r34) return pw_wgrad_v2_launch<H, 4, 3, XPRO, STRIDED>(a, st);
+      if (r34 < r42) return pw_wgrad_v2_launch<H, 3, 4, XPRO, STRIDED>(a, st);
     }
   }
-  if (MG == 1) return NG == 1 ? pw_wgrad_v2_launch<1, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<1, 2, XPRO, STRIDED>(a, st);
-  if (MG == 2) return NG == 1 ? pw_wgrad_v2_launch<2, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<2, 2, XPRO, STRIDED>(a, st);
-  return NG == 1 ? pw_wgrad_v2_launch<4, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<4, 2, XPRO, STRIDED>(a, st);
+  if (MG == 1) return NG == 1 ? pw_wgrad_v2_launch<H, 1, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<H, 1, 2, XPRO, STRIDED>(a, st);
+  if (MG == 2) return NG == 1 ? pw_wgrad_v2_launch<H, 2, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<H, 2, 2, XPRO, STRIDED>(a, st);
+  return NG == 1 ? pw_wgrad_v2_launch<H, 4, 1, XPRO, STRIDED>(a, st) : pw_wgrad_v2_launch<H, 4, 2, XPRO, STRIDED>(a, st);
 }
 
 // returns -1 when the fast path does not apply (caller falls back to the generic kernel)
+template <typename H>
 static int pw_wgrad_v2_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
   if (vec < 8) return -1;
   if (a.stride > 1) {
     if (a.stride != 2 || xpro) return -1;
     switch (strided_gather_gv(a.W, a.Wo, a.P, a.x)) {
-      case 4: return pw_wgrad_v2_pick<false, 4>(a, st);
-      case 2: return pw_wgrad_v2_pick<false, 2>(a, st);
-      case 1: return pw_wgrad_v2_pick<false, 1>(a, st);
+      case 4: return pw_wgrad_v2_pick<H, false, 4>(a, st);
+      case 2: return pw_wgrad_v2_pick<H, false, 2>(a, st);
+      case 1: return pw_wgrad_v2_pick<H, false, 1>(a, st);
       default: return -1;
     }
   }
-  return xpro ? pw_wgrad_v2_pick<true, 0>(a, st) : pw_wgrad_v2_pick<false, 0>(a, st);
+  return xpro ? pw_wgrad_v2_pick<H, true, 0>(a, st) : pw_wgrad_v2_pick<H, false, 0>(a, st);
 }

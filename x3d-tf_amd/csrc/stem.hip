@@ -55,15 +55,16 @@ __global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x
 // is two k-steps of v_mfma_f32_32x32x16_bf16 per 32 points: A = the 32x32 weight tile (bf16, held in registers for
 // the whole kernel), B = the im2col tile read transposed (ds_read_b64_tr_b16).  One wave = one 64-column segment of
 // an output row; its 24x64 result goes through a private LDS slab so that the stores are 16-byte row pieces.
-template <int SEGS>
-__global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
-                                                              bf16* __restrict__ y, int Cin, int Cout, int Tn, int H,
+template <typename HT, int SEGS>
+__global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restrict__ x, const float* __restrict__ w,
+                                                              HT* __restrict__ y, int Cin, int Cout, int Tn, int H,
                                                               int W, int Ho, int Wo, int nws, int total_segs,
                                                               int segs_per_block) {
+  typedef typename HV<HT>::x8 hx8; typedef typename HV<HT>::x4 hx4; typedef typename HV<HT>::x2 hx2;
   static_assert(SEGS == 4, "one wave per segment");
   constexpr int LP = SEGS * 64 + 32;        // 576 B pitch = 64 mod 256: the transposed read is conflict-free
   constexpr int OP = 64 + 4;                // fp32 slab pitch
-  __shared__ __attribute__((aligned(16))) bf16 Bs[32 * LP];        // im2col [tap][point]
+  __shared__ __attribute__((aligned(16))) HT Bs[32 * LP];        // im2col [tap][point]
   __shared__ __attribute__((aligned(16))) float Os[SEGS * 32 * OP]; // per-wave output slab [co][64 points]
   typedef __attribute__((ext_vector_type(4))) short s16x4_s;
   typedef __attribute__((ext_vector_type(8))) short s16x8_s;
@@ -76,34 +77,34 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
   const int seg_begin = blockIdx.x * segs_per_block;
   const int seg_end = min(seg_begin + segs_per_block, total_segs);
   for (int i = tid; i < 32 * LP / 8; i += 256) {
-    bf16x8 z;
+    hx8 z;
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-    ((bf16x8*)Bs)[i] = z;
+    for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
+    ((hx8*)Bs)[i] = z;
   }
   // A operand: row co = lane & 31, taps 8*half + 16*ks .. +7 (zero beyond Cout / ntap)
-  bf16x8 afrag[2];
+  hx8 afrag[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++)
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const int tap = ks * 16 + 8 * half + e;
-      afrag[ks][e] = (bf16)((r < Cout && tap < ntap) ? w[r * ntap + tap] : 0.f);
+      afrag[ks][e] = (HT)((r < Cout && tap < ntap) ? w[r * ntap + tap] : 0.f);
     }
 
   const int xrow = tid >> 4, xv = tid & 15;
   const int xci = xrow / 3, xkh = xrow - xci * 3;
   const bool xrow_ok = xrow < Cin * 3;
-  bf16x8 rx[SEGS];
-  bf16 rl[SEGS];
+  hx8 rx[SEGS];
+  HT rl[SEGS];
   auto issue = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
       const int seg = s0 + q;
-      bf16x8 z;
+      hx8 z;
 #pragma unroll
-      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-      rx[q] = z; rl[q] = (bf16)0.f;
+      for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
+      rx[q] = z; rl[q] = (HT)0.f;
       if (seg >= seg_end) continue;
       const int ws = seg % nws;
       int tmp = seg / nws;
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
       const int wo0 = ws * 64;
       const int hi = 2 * ho + xkh - 1;
       if (xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
-        const bf16* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
-        rx[q] = *(const bf16x8*)src;
+        const HT* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
+        rx[q] = *(const hx8*)src;
         if (xv == 0 && wo0 > 0) rl[q] = src[-1];
       }
     }
@@ -124,12 +125,12 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
     for (int q = 0; q < SEGS; q++) {
       if (xrow_ok) {
         const int tap1 = xci * 9 + xkh * 3 + 1;
-        bf16x4 ev, od;
+        hx4 ev, od;
 #pragma unroll
         for (int e = 0; e < 4; e++) { ev[e] = rx[q][2 * e]; od[e] = rx[q][2 * e + 1]; }
-        *(bf16x4*)&Bs[tap1 * LP + q * 64 + 4 * xv] = ev;          // kw = 1: wi = 2wo
-        *(bf16x4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * xv] = od;    // kw = 2: wi = 2wo + 1
-        bf16* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * xv + 1];    // kw = 0: wi = 2wo - 1  (one point later)
+        *(hx4*)&Bs[tap1 * LP + q * 64 + 4 * xv] = ev;          // kw = 1: wi = 2wo
+        *(hx4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * xv] = od;    // kw = 2: wi = 2wo + 1
+        HT* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * xv + 1];    // kw = 0: wi = 2wo - 1  (one point later)
 #pragma unroll
         for (int e = 0; e < 4; e++)
           if (4 * xv + 1 + e < 64) k0[e] = od[e];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
         const s16x4_s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[(ks * 16 + tr_row) * LP + tr_col + nt * 32]));
         const s16x4_s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[(ks * 16 + tr_row + 4) * LP + tr_col + nt * 32]));
         const s16x8_s bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], __builtin_bit_cast(bf16x8, bs), acc[nt], 0, 0, 0);
+        acc[nt] = mfma16<HT>(afrag[ks], __builtin_bit_cast(hx8, bs), acc[nt]);
       }
 #pragma unroll
       for (int j = 0; j < 16; j++) myOs[((j & 3) + 8 * (j >> 2) + 4 * half) * OP + nt * 32 + r] = acc[nt][j];
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const bf16* __rest
         if (co < Cout && wo0 + 8 * v < Wo) {
           const f32x4 v0 = *(const f32x4*)&myOs[co * OP + 8 * v], v1 = *(const f32x4*)&myOs[co * OP + 8 * v + 4];
           float val[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          VecIO<bf16, 8>::store(y + ((((long long)n * Cout + co) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v, val);
+          VecIO<HT, 8>::store(y + ((((long long)n * Cout + co) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v, val);
         }
       }
     }
@@ -193,11 +194,11 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
   X3D_REQUIRE(x && w && y && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_fwd: bad args");
   X3D_REQUIRE(Cin == 3, "stem_s_fwd: Cin must be 3 (DATA.NUM_INPUT_CHANNELS)");
   X3D_REQUIRE(Cout == 24 || Cout == 32 || Cout == 8 || Cout == 16, "stem_s_fwd: unsupported Cout %d", Cout);
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "stem_s_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "stem_s_fwd: bad dtype");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   dim3 grid(ceil_div(Ho * Wo, 256), T, N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == X3D_BF16 && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
+  if (x3d_is_half(dtype) && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
     // matrix-core path (weights rounded to bf16 like every pointwise conv): rows of x / y 16-byte aligned
     constexpr int SEGS = 4;
     const int nws = ceil_div(Wo, 64);
@@ -207,7 +208,7 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
       int nb = 0, dev = 0, cus = 256;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_fwd_bf16_kernel<SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_fwd_bf16_kernel<bf16, SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
       slots = nb * cus;
     }
     long long spb2 = ceil_div_ll(total_segs, slots);
@@ -215,8 +216,12 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
     spb2 = ceil_div_ll(spb2, SEGS) * SEGS;
     const long long gx2 = ceil_div_ll(total_segs, spb2);
     X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_fwd: too many row segments");
-    hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x, w, (bf16*)y,
-                       Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+    if (dtype == X3D_F16)
+      hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<f16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const f16*)x, w, (f16*)y,
+                         Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+    else
+      hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<bf16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x, w, (bf16*)y,
+                         Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
     X3D_LAUNCH_CHECK("stem_s_fwd");
     return X3D_OK;
   }
@@ -229,7 +234,7 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
     case 24: LAUNCH(TT, 24); break;    \
     default: LAUNCH(TT, 32); break;    \
   }
-  if (dtype == X3D_F32) { BY_CO(float) } else { BY_CO(bf16) }
+  if (dtype == X3D_F32) { BY_CO(float) } else if (dtype == X3D_F16) { BY_CO(f16) } else { BY_CO(bf16) }
 #undef BY_CO
 #undef LAUNCH
   X3D_LAUNCH_CHECK("stem_s_fwd");
@@ -313,26 +318,27 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_kernel(const T* __restrict__
 //     one point) kw=0.  That IS the im2col tile [tap][point], bf16, k-contiguous -- the B operand;
 //   * one v_mfma_f32_32x32x16_bf16 tile D[co][tap] per wave (wave = segment), summed across the four waves in LDS
 //     and added to dW with <= Cout*Cin*9 atomics per workgroup.
-template <int SEGS>
-__global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+template <typename HT, int SEGS>
+__global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __restrict__ x, const HT* __restrict__ dy,
                                                                 float* dw, int Cin, int Cout, int Tn, int H, int W,
                                                                 int Ho, int Wo, int nws, int total_segs,
                                                                 int segs_per_block) {
+  typedef typename HV<HT>::x8 hx8; typedef typename HV<HT>::x4 hx4; typedef typename HV<HT>::x2 hx2;
   static_assert(SEGS == 4, "one wave per segment");
   constexpr int LP = SEGS * 64 + 8;
-  __shared__ __attribute__((aligned(16))) bf16 As[32 * LP];  // dY     [co][point]
-  __shared__ __attribute__((aligned(16))) bf16 Bs[32 * LP];  // im2col [tap][point]
+  __shared__ __attribute__((aligned(16))) HT As[32 * LP];  // dY     [co][point]
+  __shared__ __attribute__((aligned(16))) HT Bs[32 * LP];  // im2col [tap][point]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int ntap = Cin * 9;
   const int seg_begin = blockIdx.x * segs_per_block;      // 32-bit segment arithmetic (host check), as in the forward
   const int seg_end = min(seg_begin + segs_per_block, total_segs);
   for (int i = tid; i < 32 * LP / 8; i += 256) {
-    bf16x8 z;
+    hx8 z;
 #pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-    ((bf16x8*)As)[i] = z;
-    ((bf16x8*)Bs)[i] = z;
+    for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
+    ((hx8*)As)[i] = z;
+    ((hx8*)Bs)[i] = z;
   }
   f32x16 acc;
 #pragma unroll
@@ -342,17 +348,17 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
   const int xrow = tid >> 4, xv = tid & 15;
   const int xci = xrow / 3, xkh = xrow - xci * 3;
   const bool xrow_ok = xrow < Cin * 3;
-  bf16x8 rd[SEGS], rx[SEGS];
-  bf16 rl[SEGS];
+  hx8 rd[SEGS], rx[SEGS];
+  HT rl[SEGS];
   bool okd[SEGS], okx[SEGS];
   auto issue = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
       const int seg = s0 + q;
-      bf16x8 z;
+      hx8 z;
 #pragma unroll
-      for (int e = 0; e < 8; e++) z[e] = (bf16)0.f;
-      rd[q] = z; rx[q] = z; rl[q] = (bf16)0.f;
+      for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
+      rd[q] = z; rx[q] = z; rl[q] = (HT)0.f;
       okd[q] = false; okx[q] = false;
       if (seg >= seg_end) continue;
       const int ws = seg % nws;
@@ -364,14 +370,14 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
       {  // dY: this thread's vector (row, v) of segment q is item tid of the segment's 256
         const int row = tid >> 3, v = tid & 7;
         if (row < Cout && wo0 + 8 * v < Wo) {
-          rd[q] = *(const bf16x8*)(dy + ((((long long)n * Cout + row) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v);
+          rd[q] = *(const hx8*)(dy + ((((long long)n * Cout + row) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v);
           okd[q] = true;
         }
       }
       const int hi = 2 * ho + xkh - 1;
       if (xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
-        const bf16* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
-        rx[q] = *(const bf16x8*)src;
+        const HT* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
+        rx[q] = *(const hx8*)src;
         if (xv == 0 && wo0 > 0) rl[q] = src[-1];
         okx[q] = true;
       }
@@ -382,16 +388,16 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
     for (int q = 0; q < SEGS; q++) {
       {
         const int row = tid >> 3, v = tid & 7;
-        *(bf16x8*)&As[row * LP + q * 64 + 8 * v] = rd[q];   // zeros where invalid
+        *(hx8*)&As[row * LP + q * 64 + 8 * v] = rd[q];   // zeros where invalid
       }
       if (xrow_ok) {
         const int tap1 = xci * 9 + xkh * 3 + 1;
-        bf16x4 ev, od;
+        hx4 ev, od;
 #pragma unroll
         for (int e = 0; e < 4; e++) { ev[e] = rx[q][2 * e]; od[e] = rx[q][2 * e + 1]; }
-        *(bf16x4*)&Bs[tap1 * LP + q * 64 + 4 * xv] = ev;          // kw = 1: wi = 2wo
-        *(bf16x4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * xv] = od;    // kw = 2: wi = 2wo + 1
-        bf16* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * xv + 1];    // kw = 0: wi = 2wo - 1  (one point later)
+        *(hx4*)&Bs[tap1 * LP + q * 64 + 4 * xv] = ev;          // kw = 1: wi = 2wo
+        *(hx4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * xv] = od;    // kw = 2: wi = 2wo + 1
+        HT* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * xv + 1];    // kw = 0: wi = 2wo - 1  (one point later)
 #pragma unroll
         for (int e = 0; e < 4; e++)
           if (4 * xv + 1 + e < 64) k0[e] = od[e];
@@ -406,13 +412,13 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const bf16* __re
     commit();
     __syncthreads();
     if (s0 + SEGS < seg_end) issue(s0 + SEGS);
-    const bf16* ap = As + r * LP + wid * 64 + 8 * half;
-    const bf16* bp = Bs + r * LP + wid * 64 + 8 * half;
+    const HT* ap = As + r * LP + wid * 64 + 8 * half;
+    const HT* bp = Bs + r * LP + wid * 64 + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      const bf16x8 af = *(const bf16x8*)(ap + ks * 16);
-      const bf16x8 bf = *(const bf16x8*)(bp + ks * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      const hx8 af = *(const hx8*)(ap + ks * 16);
+      const hx8 bf = *(const hx8*)(bp + ks * 16);
+      acc = mfma16<HT>(af, bf, acc);
     }
   }
   // sum the four waves' partial tiles in LDS, then one atomic per (co, tap)
@@ -432,7 +438,7 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
                                 int Cout, int dtype, void* stream) {
   X3D_REQUIRE(x && dy && dw && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_wgrad: bad args");
   X3D_REQUIRE(Cin * 9 <= 32 && Cout <= 32, "stem_s_wgrad: needs Cin*9 <= 32 and Cout <= 32");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "stem_s_wgrad: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "stem_s_wgrad: bad dtype");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long P = (long long)T * Ho * Wo;
   const long long steps_per_n = ceil_div_ll(P, 64);
@@ -442,7 +448,7 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
   if (spb > steps_per_n) spb = (int)steps_per_n;
   const long long gx = ceil_div_ll(steps_per_n, spb) * N;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == X3D_BF16 && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+  if (x3d_is_half(dtype) && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
     // fast path: rows of x and dY are 16-byte aligned (W % 16 == 0 -> Wo % 8 == 0)
     constexpr int SEGS = 4;
     const int nws = ceil_div(Wo, 64);
@@ -452,7 +458,7 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
       int nb = 0, dev = 0, cus = 256;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_wgrad_bf16_kernel<SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_wgrad_bf16_kernel<bf16, SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
       slots = nb * cus;
     }
     long long spb2 = ceil_div_ll(total_segs, slots);
@@ -461,14 +467,21 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
     const long long gx2 = ceil_div_ll(total_segs, spb2);
     X3D_REQUIRE(gx2 < (1ll << 31), "stem_s_wgrad: grid too large");
     X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_wgrad: too many row segments");
-    hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x,
-                       (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+    if (dtype == X3D_F16)
+      hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<f16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const f16*)x,
+                         (const f16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+    else
+      hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<bf16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x,
+                         (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
     X3D_LAUNCH_CHECK("stem_s_wgrad");
     return X3D_OK;
   }
   if (dtype == X3D_F32)
     hipLaunchKernelGGL((stem_s_wgrad_kernel<float>), dim3((unsigned)gx), dim3(256), 0, st, (const float*)x,
                        (const float*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, spb);
+  else if (dtype == X3D_F16)
+    hipLaunchKernelGGL((stem_s_wgrad_kernel<f16>), dim3((unsigned)gx), dim3(256), 0, st, (const f16*)x,
+                       (const f16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, spb);
   else
     hipLaunchKernelGGL((stem_s_wgrad_kernel<bf16>), dim3((unsigned)gx), dim3(256), 0, st, (const bf16*)x,
                        (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, spb);
@@ -567,19 +580,20 @@ template <typename T, int VEC> struct BufVec {
   }
   __device__ __forceinline__ float get(int e) const {
     if constexpr (sizeof(T) == 4) return __uint_as_float(w[e]);
-    else return __uint_as_float(((w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
+    else if constexpr (__is_same(T, bf16)) return __uint_as_float(((w[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
+    else return (float)__builtin_bit_cast(T, (unsigned short)(w[e >> 1] >> (16 * (e & 1))));
   }
   __device__ __forceinline__ void set(const float (&v)[VEC]) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int e = 0; e < VEC; e++) w[e] = __float_as_uint(v[e]);
     } else if constexpr (VEC == 1) {
-      w[0] = (unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[0]);
+      w[0] = (unsigned int)__builtin_bit_cast(unsigned short, (T)v[0]);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC / 2; e++)
-        w[e] = (unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[2 * e]) |
-               ((unsigned int)__builtin_bit_cast(unsigned short, (bf16)v[2 * e + 1]) << 16);
+        w[e] = (unsigned int)__builtin_bit_cast(unsigned short, (T)v[2 * e]) |
+               ((unsigned int)__builtin_bit_cast(unsigned short, (T)v[2 * e + 1]) << 16);
     }
   }
 };
@@ -677,13 +691,16 @@ static int dwt_fwd_kt(const void* x, const float* w, void* y, double* stats, int
 extern "C" int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
                            int KT, int dtype, void* stream) {
   X3D_REQUIRE(x && w && y && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_fwd: bad args");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "dwt_fwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "dwt_fwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, HW, x, y);
   if (dtype == X3D_F32)
     return vec >= 4 ? dwt_fwd_kt<float, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
                     : dwt_fwd_kt<float, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
+  if (dtype == X3D_F16)
+    return vec >= 4 ? dwt_fwd_kt<f16, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
+                    : dwt_fwd_kt<f16, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
   return vec >= 4 ? dwt_fwd_kt<bf16, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
                   : dwt_fwd_kt<bf16, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
 }
@@ -708,7 +725,7 @@ static int dwt_bwd_kt(const void* g, const void* yraw, const float* coef, const 
 extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, const void* x, const float* w,
                            void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream) {
   X3D_REQUIRE(g && yraw && coef && x && w && dx && dw && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_bwd: bad args");
-  X3D_REQUIRE(dtype == X3D_F32 || dtype == X3D_BF16, "dwt_bwd: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "dwt_bwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int eb = dtype == X3D_F32 ? 4 : 2;
   X3D_REQUIRE((long long)T * HW * eb < (1ll << 30), "dwt_bwd: one channel slab exceeds the 1 GB buffer window");
@@ -718,6 +735,12 @@ extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, c
   if (dtype == X3D_F32)
     return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
                     : dwt_bwd_kt<float, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  if (dtype == X3D_F16) {
+    if (vec >= 8 && want >= 8) return dwt_bwd_kt<f16, 8>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    if (vec >= 4 && want >= 4) return dwt_bwd_kt<f16, 4>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    return vec >= 2 ? dwt_bwd_kt<f16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                    : dwt_bwd_kt<f16, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  }
   if (vec >= 8 && want >= 8) return dwt_bwd_kt<bf16, 8>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
   if (vec >= 4 && want >= 4) return dwt_bwd_kt<bf16, 4>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
   return vec >= 2 ? dwt_bwd_kt<bf16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)

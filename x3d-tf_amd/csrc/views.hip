@@ -68,7 +68,7 @@ extern "C" int x3d_eval_views(const x3d_eval_views_args* e, void* stream) {
   X3D_REQUIRE(e && e->video && e->out, "eval_views: null pointer");
   X3D_REQUIRE(e->F > 0 && e->H > 0 && e->W > 0 && e->T > 0 && e->views > 0 && e->crops > 0 && e->size > 0,
               "eval_views: bad extents");
-  X3D_REQUIRE(e->dtype == X3D_F32 || e->dtype == X3D_BF16, "eval_views: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(e->dtype), "eval_views: bad dtype");
   EvalViewsArgs a;
   a.video = e->video; a.out = e->out; a.F = e->F; a.H = e->H; a.W = e->W;
   a.T = e->T; a.views = e->views; a.crops = e->crops; a.size = e->size;
@@ -97,6 +97,7 @@ extern "C" int x3d_eval_views(const x3d_eval_views_args* e, void* stream) {
   X3D_REQUIRE(blocks < (1ll << 31), "eval_views: too many pixels");
   hipStream_t st = (hipStream_t)stream;
   if (e->dtype == X3D_F32) hipLaunchKernelGGL((eval_views_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (e->dtype == X3D_F16) hipLaunchKernelGGL((eval_views_kernel<f16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((eval_views_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   X3D_LAUNCH_CHECK("eval_views");
   return X3D_OK;
@@ -120,7 +121,7 @@ extern "C" int x3d_train_clip(const x3d_train_clip_args* e, void* stream) {
   X3D_REQUIRE(e && e->video && e->out, "train_clip: null pointer");
   X3D_REQUIRE(e->F > 0 && e->H > 0 && e->W > 0 && e->T > 0 && e->rate > 0 && e->size > 0, "train_clip: bad extents");
   X3D_REQUIRE(e->start >= 0 && e->start < e->F, "train_clip: start %d outside the %d frames", e->start, e->F);
-  X3D_REQUIRE(e->dtype == X3D_F32 || e->dtype == X3D_BF16, "train_clip: bad dtype");
+  X3D_REQUIRE(x3d_dtype_ok(e->dtype), "train_clip: bad dtype");
   EvalViewsArgs a;
   a.video = e->video; a.out = e->out; a.F = e->F; a.H = e->H; a.W = e->W;
   a.T = e->T; a.views = 1; a.crops = 1; a.size = e->size;
@@ -136,6 +137,7 @@ extern "C" int x3d_train_clip(const x3d_train_clip_args* e, void* stream) {
   X3D_REQUIRE(blocks < (1ll << 31), "train_clip: too many pixels");
   hipStream_t st = (hipStream_t)stream;
   if (e->dtype == X3D_F32) hipLaunchKernelGGL((eval_views_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (e->dtype == X3D_F16) hipLaunchKernelGGL((eval_views_kernel<f16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((eval_views_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   X3D_LAUNCH_CHECK("train_clip");
   return X3D_OK;

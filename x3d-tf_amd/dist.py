@@ -13,8 +13,12 @@ tensors for the multi-process tests.
 import os
 from typing import List, Optional, Sequence, Tuple
 
-import torch
-import torch.distributed as dist
+# the host driver only supports dmabuf IPC; the HSA runtime reads this when HIP initialises, i.e. it has to be in the
+# environment before the first torch.cuda call of the process (launchers export it too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def env_world() -> Tuple[int, int, int]:
@@ -53,7 +57,6 @@ def init_process_group(backend: Optional[str] = None):
             backend = os.environ.get("X3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -82,10 +85,14 @@ class BucketReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = _active(group)
         self._work: List = []
+        self.launched = 0          # all-reduces enqueued so far (bench.py reports them)
+        self.launched_bytes = 0
 
     def launch(self, i: int):
         if not self.active:
             return
+        self.launched += 1
+        self.launched_bytes += self.buckets[i].numel() * self.buckets[i].element_size()
         self._work.append(dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):

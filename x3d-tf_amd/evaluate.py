@@ -12,7 +12,8 @@ from .views import make_eval_views, num_views
 class Metrics:
     """Running means in the Keras sense: per-video loss / hits averaged over the videos seen so far."""
 
-    def __init__(self):
+    def __init__(self, reg_loss: float = 0.0):
+        self.reg_loss = float(reg_loss)   # the model's L2 term: Keras adds it to every reported `loss`
         self.n = 0
         self.loss = 0.0
         self.top1 = 0
@@ -21,8 +22,10 @@ class Metrics:
     def update(self, probs: torch.Tensor, labels: torch.Tensor):
         """probs [videos, classes] fp32 (already view-averaged by the model); labels [videos]."""
         labels = labels.to(probs.device).long()
-        p = probs.gather(1, labels[:, None]).squeeze(1).clamp(1e-7, 1.0 - 1e-7)   # Keras CE from probabilities
-        self.loss += float((-p.log()).sum())
+        # Keras CE from probabilities (the same expression as x3d_softmax_xent and the oracle):
+        # q = clip(p, 1e-7, 1 - 1e-7); loss = -log q_y + log sum_j q_j
+        q = probs.double().clamp(1e-7, 1.0 - 1e-7)
+        self.loss += float((-q.gather(1, labels[:, None]).squeeze(1).log() + q.sum(1).log()).sum())
         top5 = probs.topk(min(5, probs.shape[1]), dim=1).indices
         self.top1 += int((top5[:, 0] == labels).sum())
         self.top5 += int((top5 == labels[:, None]).any(dim=1).sum())
@@ -30,7 +33,7 @@ class Metrics:
 
     def result(self) -> Dict[str, float]:
         n = max(self.n, 1)
-        return {"loss": self.loss / n, "acc": self.top1 / n, "top_5_acc": self.top5 / n, "videos": self.n}
+        return {"loss": self.loss / n + self.reg_loss, "acc": self.top1 / n, "top_5_acc": self.top5 / n, "videos": self.n}
 
 
 def evaluate(model, cfg, videos: Iterable[Tuple[torch.Tensor, int]], batch_videos: int = None) -> Dict[str, float]:
@@ -38,7 +41,8 @@ def evaluate(model, cfg, videos: Iterable[Tuple[torch.Tensor, int]], batch_video
     (default cfg.TEST.BATCH_SIZE) of views x crops clips each through `model(clips, training=False)`."""
     bv = int(batch_videos or cfg.TEST.BATCH_SIZE)
     nv = num_views(cfg)
-    m = Metrics()
+    # `model.evaluate` reports cross-entropy + the model's regularisation losses (weight_decay * sum w^2, model.py:47)
+    m = Metrics(float(model.regularization_loss().item()) if hasattr(model, "regularization_loss") else 0.0)
     clips, labels = [], []
 
     def flush():
@@ -56,4 +60,6 @@ def evaluate(model, cfg, videos: Iterable[Tuple[torch.Tensor, int]], batch_video
         if len(clips) == bv:
             flush()
     flush()
+    if hasattr(model, "release_plans"):
+        model.release_plans(keep=1)     # the partial tail batch allocated a second multi-GB plan
     return m.result()

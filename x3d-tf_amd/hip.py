@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3d_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
 
@@ -111,8 +111,10 @@ _SIGS = {
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
     "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
+    "x3d_pw_kernel_name": ([C.POINTER(PwFwdArgs), C.POINTER(PwDgradArgs), C.POINTER(PwWgradArgs), C.POINTER(PwBwdArgs),
+                            C.c_char_p, _i], _i),
     "x3d_pw_panel_elems": ([_i, _i], _ll),
-    "x3d_pw_pack_weights": ([_vp, _i, _vp], _i),
+    "x3d_pw_pack_weights": ([_vp, _i, _i, _vp], _i),
     "x3d_dw3d_fwd": ([C.POINTER(Dw3dFwdArgs), _vp], _i),
     "x3d_dw3d_bwd": ([C.POINTER(Dw3dBwdArgs), _vp], _i),
     "x3d_dw3d_kernel_name": ([C.POINTER(Dw3dFwdArgs), C.POINTER(Dw3dBwdArgs), C.c_char_p, _i], _i),
@@ -128,6 +130,8 @@ _SIGS = {
     "x3d_softmax_xent": ([_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp], _i),
     "x3d_view_mean": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_sgd_nesterov": ([_vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp], _i),
+    "x3d_adam": ([_vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _ll, _ll, _vp], _i),
+    "x3d_all_finite": ([_vp, _ll, _vp, _vp], _i),
     "x3d_l2_sumsq": ([_vp, _vp, _vp, _ll, _vp], _i),
     "x3d_nthwc_to_ncthw": ([_vp, _i, _vp, _i, _i, _i, _ll, _vp], _i),
     "x3d_eval_views": ([C.POINTER(EvalViewsArgs), _vp], _i),
@@ -175,11 +179,32 @@ def dw3d_kernel_name(args):
     return buf.value.decode()
 
 
+def pw_kernel_name(args):
+    """Instantiation x3d_pw_fwd / x3d_pw_dgrad / x3d_pw_wgrad / x3d_pw_bwd would launch for this argument struct (no
+    launch, no GPU needed)."""
+    buf = C.create_string_buffer(160)
+    slots = [None, None, None, None]
+    for i, kind in enumerate((PwFwdArgs, PwDgradArgs, PwWgradArgs, PwBwdArgs)):
+        if isinstance(args, kind):
+            slots[i] = C.byref(args)
+    rc = load().x3d_pw_kernel_name(*slots, buf, 160)
+    if rc != 0:
+        raise X3DHipError(load().x3d_last_error().decode())
+    return buf.value.decode()
+
+
+def kernel_name(args):
+    """pw_kernel_name / dw3d_kernel_name by struct type."""
+    return dw3d_kernel_name(args) if isinstance(args, (Dw3dFwdArgs, Dw3dBwdArgs)) else pw_kernel_name(args)
+
+
 def dtype_code(dt):
     if dt == torch.float32:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise X3DHipError(f"unsupported activation dtype {dt}")
 
 

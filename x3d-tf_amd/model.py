@@ -100,6 +100,40 @@ class _Sequential(list):
 
 
 # ------------------------------------------------------------------------------------------------
+class _FakeBuf:
+    """Stand-in for a device buffer in a DRY plan (X3D(..., device="dry")): an address range that is never touched.
+    Dry plans exist so that the launch list of a full-size configuration -- and, through x3d_pw_kernel_name /
+    x3d_dw3d_kernel_name, the kernel instantiation behind every launch -- can be enumerated without a GPU
+    (x3d_tf_amd/dispatch.py, tests/test_dispatch_coverage.py).  Addresses are 4 KB aligned like real allocations."""
+    _next = 0x7000_0000_0000
+
+    def __init__(self, shape, dtype, ptr=None):
+        self.shape, self.dtype = tuple(shape), dtype
+        n = 1
+        for d in self.shape:
+            n *= d
+        self._numel = n
+        if ptr is None:
+            ptr = _FakeBuf._next
+            _FakeBuf._next += (n * torch.empty(0, dtype=dtype).element_size() + 4095) // 4096 * 4096 + 4096
+        self._ptr = ptr
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numel(self):
+        return self._numel
+
+    def view(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        return _FakeBuf(shape, self.dtype, self._ptr)
+
+    def __getitem__(self, idx):   # only the `buf[:k]` the plan uses on flat scratch buffers
+        assert isinstance(idx, slice) and idx.start is None and idx.step is None and len(self.shape) == 1
+        return _FakeBuf((min(idx.stop, self._numel),), self.dtype, self._ptr)
+
+
 class _Plan:
     """Buffers + recorded launches for one (N, T, H, W, training) configuration."""
 
@@ -126,9 +160,13 @@ class _Plan:
 
     # -- allocation ------------------------------------------------------------------------------
     def act(self, *shape):
+        if self.model.dry:
+            return _FakeBuf(shape, self.model.dtype)
         return torch.empty(shape, dtype=self.model.dtype, device=self.model.device)
 
     def f32(self, *shape):
+        if self.model.dry:
+            return _FakeBuf(shape, torch.float32)
         return torch.empty(shape, dtype=torch.float32, device=self.model.device)
 
     def acc64(self, *shape):
@@ -156,7 +194,7 @@ class _Plan:
             if st is not None:
                 self.structs[(id(lst), len(lst))] = st
         for a in args:
-            if isinstance(a, torch.Tensor):
+            if isinstance(a, (torch.Tensor, _FakeBuf)):
                 self.keep.append(a)
                 conv.append(a.data_ptr())
             elif isinstance(a, C.Structure):
@@ -209,6 +247,8 @@ class _Plan:
         return launch
 
     def run(self, lst, start=0, stop=None):
+        if self.model.dry:
+            raise hip.X3DHipError("a dry plan records launches; it cannot run (no CPU fallback for the hot path)")
         s = torch.cuda.current_stream().cuda_stream
         for name, fn, args in lst[start:stop]:
             st = fn(*args, s)
@@ -225,10 +265,13 @@ class X3D:
 
     Args:
         cfg: config tree (x3d_tf_amd.config.CfgNode or anything exposing the same attributes).
-        dtype: activation storage type on the GPU: torch.float32 or torch.bfloat16 (weights,
-            statistics and accumulation stay fp32).  The reference's only reduced-precision mode is
-            Keras mixed_float16 (utils.py:176-192); bf16 is this build's equivalent.
-        device: a CUDA/HIP device.  There is no CPU path.
+        dtype: activation storage type on the GPU: torch.float32, torch.bfloat16 or torch.float16 (weights,
+            statistics and accumulation stay fp32).  float16 is the reference's reduced-precision mode (Keras
+            mixed_float16, utils.py:176-192: fp16 compute, fp32 variables, loss scaling in training --
+            train.Trainer's `loss_scale`); bfloat16 needs no loss scaling and is the benchmark's default.
+        device: a CUDA/HIP device.  There is no CPU path.  The one exception is device="dry": the model is built on
+            the host with address-only stand-ins for the activation buffers, plans can be RECORDED (to enumerate
+            launches and their kernel instantiations, x3d_tf_amd/dispatch.py) and every attempt to run one raises.
         seed: seed of the Glorot-uniform initialisation.
     """
 
@@ -241,9 +284,13 @@ class X3D:
         self.dtype = dtype
         self.in_channels = in_channels
         hip.dtype_code(dtype)
-        if not torch.cuda.is_available():
-            raise hip.X3DHipError("X3D needs an MI355X: the HIP path has no CPU fallback")
-        self.device = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self.dry = (device == "dry")
+        if self.dry:
+            self.device = torch.device("cpu")
+        else:
+            if not torch.cuda.is_available():
+                raise hip.X3DHipError("X3D needs an MI355X: the HIP path has no CPU fallback")
+            self.device = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}")
         hip.load()
         self._plans: Dict = {}
         self._build_params(seed)
@@ -305,7 +352,7 @@ class X3D:
         at the start of each forward so the GEMM workgroups copy their weight rows instead of converting them."""
         self._panels: Dict[str, tuple] = {}
         self._panel_table = None
-        if self.dtype != torch.bfloat16:
+        if self.dtype not in (torch.bfloat16, torch.float16):
             return
         lib = hip.load()
         names = [s.name for s in self.specs.values() if s.kind == "pw" and
@@ -315,7 +362,7 @@ class X3D:
             cout, cin = self.specs[nm].shape
             sizes.append((lib.x3d_pw_panel_elems(cout, cin), lib.x3d_pw_panel_elems(cin, cout)))
         total = sum(a + b for a, b in sizes)
-        self._panel_buf = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+        self._panel_buf = torch.zeros(total, dtype=self.dtype, device=self.device)
         items = (hip.PwPackItem * len(names))()
         off = 0
         for i, (nm, (nf, nd)) in enumerate(zip(names, sizes)):   # panel sizes are multiples of 8 elements: 16-B aligned
@@ -329,7 +376,7 @@ class X3D:
 
     def _pack_panels(self):
         if self._panel_table is not None:
-            hip.call("x3d_pw_pack_weights", self._panel_table.data_ptr(), self._n_panels)
+            hip.call("x3d_pw_pack_weights", self._panel_table.data_ptr(), self._n_panels, hip.dtype_code(self.dtype))
 
     def _wp(self, name, dgrad=False):
         pr = self._panels.get(name)
@@ -440,13 +487,26 @@ class X3D:
     # ---------------------------------------------------------------------------------------------
     # plan construction
     # ---------------------------------------------------------------------------------------------
+    MAX_PLANS = 3   # a plan owns every activation / gradient / scratch buffer of its shape (X3D-M, B = 64, bf16: ~16 GB)
+
     def _plan(self, n, t, h, w, training) -> _Plan:
         key = (n, t, h, w, bool(training))
-        pl = self._plans.get(key)
+        pl = self._plans.pop(key, None)
         if pl is None:
+            self.release_plans(keep=self.MAX_PLANS - 1)
             pl = self._make_plan(n, t, h, w, bool(training))
-            self._plans[key] = pl
+        self._plans[key] = pl           # most recently used last
         return pl
+
+    def release_plans(self, keep: int = 0):
+        """Drop all but the `keep` most recently used plans (their buffers return to the allocator once no launch that
+        uses them is pending: the stream is synchronised first)."""
+        if len(self._plans) <= keep:
+            return
+        if not self.dry:
+            torch.cuda.synchronize(self.device)
+        for key in list(self._plans)[:len(self._plans) - keep]:
+            del self._plans[key]
 
     def _make_plan(self, n, t, h, w, training) -> _Plan:
         a, p = self.arch, self.params
@@ -686,7 +746,7 @@ class X3D:
         max_inner_in = max(B.a_raw.numel() for B in pl.blocks)
         max_r = max([1] + [n * B.spec.cin * t * B.ho * B.wo for B in pl.blocks if B.spec.has_shortcut_conv])
         max_nc = max(n * B.spec.inner for B in pl.blocks)
-        flat = lambda numel: torch.empty(numel, dtype=self.dtype, device=self.device)
+        flat = lambda numel: pl.act(numel)
         pl.gbuf = [flat(max_out), flat(max_out)]
         pl.dv = flat(max_inner_out)
         pl.ga = flat(max_inner_in)
@@ -826,12 +886,14 @@ class X3D:
     # execution
     # ---------------------------------------------------------------------------------------------
     def _bind_input(self, pl: _Plan, x):
+        if self.dry:
+            raise hip.X3DHipError("a dry model cannot run (no CPU fallback for the hot path)")
         if x.dim() != 5 or x.shape[-1] != self.in_channels:
             raise ValueError(f"expected a channels-last clip batch [N, T, H, W, {self.in_channels}], got {tuple(x.shape)}")
         if not x.is_cuda:
             x = x.to(self.device, non_blocking=True)
         x = x.contiguous()
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (x.dtype != torch.float32 and x.dtype != self.dtype):
             x = x.float()
         n, t, h, w, c = x.shape
         hip.call("x3d_nthwc_to_ncthw", x.data_ptr(), hip.dtype_code(x.dtype), pl.x.data_ptr(),
@@ -872,12 +934,15 @@ class X3D:
         pl.run(pl.fwd)
         return pl.out
 
-    def forward_backward(self, input, labels, global_batch=None, on_stage_done=None):
+    def forward_backward(self, input, labels, global_batch=None, on_stage_done=None, loss_scale=1.0):
         """One training forward + backward.  Fills ``self.grads`` (data gradients only; the L2 term is
         applied by the optimizer), updates BN moving statistics, returns the plan (loss_rows, probs).
 
         global_batch: divisor of the loss mean (defaults to the local batch; data-parallel callers pass
             world_size * local batch so that summing gradients over ranks gives the global mean).
+        loss_scale: every gradient is multiplied by this factor (Keras LossScaleOptimizer, reference train.py:99-100:
+            keeps fp16 activation gradients out of the denormal range); the optimizer step divides it out again
+            (`apply_sgd(grad_scale=1 / loss_scale)`).  The backward kernels are linear in the upstream gradient.
         on_stage_done(stage): called with "fwd" once the forward pass is on the stream, then as soon as every
             gradient of ``stage`` (4 = head, 3..0 = stages, -1 = stem) is final on the stream -- the hook gradient
             all-reduce buckets attach to.
@@ -885,6 +950,9 @@ class X3D:
         n, t, h, w, _ = input.shape
         pl = self._plan(n, t, h, w, True)
         self._bind_input(pl, input)
+        if not labels.is_cuda:   # host labels are validated for free; device labels by the kernel (NaN loss row, zero gradient)
+            if labels.numel() != n or int(labels.min()) < 0 or int(labels.max()) >= self.num_classes:
+                raise ValueError(f"labels must be {n} class indices in [0, {self.num_classes})")
         pl.labels.copy_(labels.to(self.device, non_blocking=True).to(torch.int32))
         self._pack_panels()
         pl.zero_buf.zero_()
@@ -893,7 +961,7 @@ class X3D:
         gb = float(global_batch or n)
         pl.run(pl.fwd, 0, pl.grad_scale_slot)
         hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
-                 pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), 1.0 / gb, n, self.num_classes)
+                 pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), float(loss_scale) / gb, n, self.num_classes)
         if on_stage_done is None:
             pl.run(pl.bwd)
         else:
@@ -918,6 +986,23 @@ class X3D:
         hip.call("x3d_sgd_nesterov", self.flat_params.data_ptr(), self.flat_velocity.data_ptr(),
                  self.flat_grads.data_ptr(), self.l2_mask.data_ptr(), float(lr), float(momentum),
                  float(self.arch.weight_decay), float(grad_scale), self.n_trainable_flat)
+
+    def apply_adam(self, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Adam + L2 (reference train.py:93-95: tf.optimizers.Adam(learning_rate), Keras defaults), one launch.  The first
+        moment lives in `flat_velocity` (the slot the SGD branch uses for momentum), the second in `flat_second`."""
+        if getattr(self, "flat_second", None) is None:
+            self.flat_second = torch.zeros_like(self.flat_velocity)
+        hip.call("x3d_adam", self.flat_params.data_ptr(), self.flat_velocity.data_ptr(), self.flat_second.data_ptr(),
+                 self.flat_grads.data_ptr(), self.l2_mask.data_ptr(), float(lr), float(beta1), float(beta2), float(eps),
+                 float(self.arch.weight_decay), float(grad_scale), int(step), self.n_trainable_flat)
+
+    def grads_finite(self) -> bool:
+        """True when every entry of the flat gradient buffer is finite (x3d_all_finite; synchronises)."""
+        if getattr(self, "_finite_flag", None) is None:
+            self._finite_flag = torch.ones(1, dtype=torch.int32, device=self.device)
+        self._finite_flag.fill_(1)
+        hip.call("x3d_all_finite", self.flat_grads.data_ptr(), self.n_trainable_flat, self._finite_flag.data_ptr())
+        return bool(self._finite_flag.item())
 
     def grad_bucket(self, stage):
         """Contiguous slice of the flat gradient buffer holding the gradients of one stage

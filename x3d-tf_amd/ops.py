@@ -136,9 +136,9 @@ def bn_bwd_finalize(sums, count, mi, gamma, coef, dgamma, dbeta):
 
 
 # ---- pointwise ----------------------------------------------------------------------------------
-def pw_pack_weights(weights, dgrad=True):
-    """fp32 [Cout, Cin] weights -> list of (fwd_panel, dgrad_panel) bf16 LDS-image panels, one launch
-    (x3d_pw_pack_weights)."""
+def pw_pack_weights(weights, dgrad=True, dtype=torch.bfloat16):
+    """fp32 [Cout, Cin] weights -> list of (fwd_panel, dgrad_panel) LDS-image panels of the 16-bit storage type `dtype`,
+    one launch (x3d_pw_pack_weights)."""
     import ctypes as C
     lib = hip.load()
     items = (hip.PwPackItem * len(weights))()
@@ -146,12 +146,12 @@ def pw_pack_weights(weights, dgrad=True):
     for i, w in enumerate(weights):
         _chk(w)
         cout, cin = w.shape
-        fp = torch.empty(lib.x3d_pw_panel_elems(cout, cin), dtype=torch.bfloat16, device=w.device)
-        dp = torch.empty(lib.x3d_pw_panel_elems(cin, cout), dtype=torch.bfloat16, device=w.device) if dgrad else None
+        fp = torch.empty(lib.x3d_pw_panel_elems(cout, cin), dtype=dtype, device=w.device)
+        dp = torch.empty(lib.x3d_pw_panel_elems(cin, cout), dtype=dtype, device=w.device) if dgrad else None
         items[i] = hip.PwPackItem(ptr(w), ptr(fp), ptr(dp), cout, cin)
         out.append((fp, dp))
     table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(weights[0].device)
-    hip.call("x3d_pw_pack_weights", table.data_ptr(), len(weights))
+    hip.call("x3d_pw_pack_weights", table.data_ptr(), len(weights), hip.dtype_code(dtype))
     torch.cuda.current_stream().synchronize()   # `table` must outlive the launch
     return out
 

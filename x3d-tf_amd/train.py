@@ -27,10 +27,22 @@ class Trainer:
     replica is given rank 0's initial variables, as variables created under MirroredStrategy are.
     """
 
-    def __init__(self, model, cfg, momentum: Optional[float] = None, sync_moving_stats: bool = True, group=None):
-        if cfg.TRAIN.OPTIMIZER.lower() != "sgd":
-            raise NotImplementedError(f"{cfg.TRAIN.OPTIMIZER} not supported")   # reference train.py:97
+    def __init__(self, model, cfg, momentum: Optional[float] = None, sync_moving_stats: bool = True, group=None,
+                 loss_scale="auto"):
+        self.optimizer = cfg.TRAIN.OPTIMIZER.lower()
+        if self.optimizer not in ("sgd", "adam"):   # reference train.py:88-97: SGD(nesterov) / Adam / NotImplementedError
+            raise NotImplementedError(f"{cfg.TRAIN.OPTIMIZER} not supported")
         self.model, self.cfg, self.group = model, cfg, group
+        self.opt_step = 0                     # optimizer steps applied (Adam's bias correction counts them)
+        # Loss scaling = tf.keras.mixed_precision.LossScaleOptimizer(opt) with its defaults (train.py:99-100): dynamic,
+        # initial scale 2^15, doubled after 2000 consecutive finite steps, halved (and the step skipped) when a gradient
+        # is inf / nan.  "auto": on for float16 storage (the reference's mixed_float16), off for float32 / bfloat16;
+        # a number = fixed scale; None = off.
+        if loss_scale == "auto":
+            loss_scale = "dynamic" if model.dtype == torch.float16 else None
+        self.dynamic_scale = loss_scale == "dynamic"
+        self.loss_scale = 2.0 ** 15 if self.dynamic_scale else (float(loss_scale) if loss_scale else 1.0)
+        self.growth_steps, self._good_steps, self.skipped_steps = 2000, 0, 0
         self.momentum = cfg.TRAIN.MOMENTUM if momentum is None else momentum
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
         self.collectives = xdist._active(group)      # world > 1, or the one-rank rehearsal (X3D_DIST_REHEARSE=1)
@@ -56,14 +68,39 @@ class Trainer:
         if lr is None:
             lr = lr_schedule(self.epoch, self.cfg)
         pl = m.forward_backward(clips, labels, global_batch=n * self.world,
-                                on_stage_done=self._on_stage_done if self.collectives else None)
+                                on_stage_done=self._on_stage_done if self.collectives else None,
+                                loss_scale=self.loss_scale)
         self.reducer.finish()
         if self._stats_work is not None:      # mirrored-variable MEAN aggregation of the BN moving statistics [TF-3p]
             self._stats_work.wait()
             self._stats_work = None
             m.moving_stats_flat().div_(self.world)
-        m.apply_sgd(lr, self.momentum)
+        if self.dynamic_scale:                # after the all-reduce: every replica sees the same sums, takes the same branch
+            if not m.grads_finite():
+                self.loss_scale = max(self.loss_scale / 2.0, 1.0)
+                self._good_steps = 0
+                self.skipped_steps += 1
+                return pl                     # LossScaleOptimizer skips the update
+            self._good_steps += 1
+        self.opt_step += 1
+        if self.optimizer == "adam":
+            m.apply_adam(lr, self.opt_step, grad_scale=1.0 / self.loss_scale)
+        else:
+            m.apply_sgd(lr, self.momentum, grad_scale=1.0 / self.loss_scale)
+        if self.dynamic_scale and self._good_steps >= self.growth_steps:
+            self.loss_scale *= 2.0
+            self._good_steps = 0
         return pl
+
+    def collective_stats(self):
+        """What the exchange step of this replica did so far (bench.py's `collectives` block)."""
+        r = self.reducer
+        return {"backend": (torch.distributed.get_backend(self.group) if torch.distributed.is_initialized() else None),
+                "world": self.world, "buckets_per_step": len(r.buckets),
+                "bytes_per_step": sum(b.numel() * b.element_size() for b in r.buckets),
+                "allreduces_launched": r.launched, "allreduce_bytes": r.launched_bytes,
+                "launched_from_backward_hooks": bool(self.collectives and r.launched > 0),
+                "moving_stats_mean": bool(self.sync_moving_stats)}
 
     def _on_stage_done(self, stage):
         """backward hook (model.forward_backward): 'fwd' = forward finished (the moving statistics are final: their
