@@ -130,7 +130,9 @@ def test_evaluate_driver(gpu):
     res = evaluate(model, cfg, vids)
     probs = torch.cat([model(make_eval_views(v, cfg), training=False).clone() for v, _ in vids], 0).cpu()
     labels = torch.tensor([l for _, l in vids])
-    loss = float((-probs.gather(1, labels[:, None]).clamp(1e-7, 1 - 1e-7).log()).mean())
+    # what Keras' model.evaluate reports as `loss`: CE from probabilities (clip, -log q_y + log sum q) + the L2 term
+    q = probs.double().clamp(1e-7, 1 - 1e-7)
+    loss = float((-q.gather(1, labels[:, None]).squeeze(1).log() + q.sum(1).log()).mean()) + float(model.regularization_loss().item())
     acc = float((probs.argmax(1) == labels).float().mean())
     assert res["videos"] == 3 and abs(res["loss"] - loss) < 1e-5 and abs(res["acc"] - acc) < 1e-6
     assert res["top_5_acc"] >= res["acc"]
