@@ -53,8 +53,10 @@ def main():
     dev = torch.device("cuda:0")
     lib = hip.load()
     out = {}
-    for dtype in (torch.bfloat16, torch.float32):
-        for c, t, h, w, s in SHAPES:
+    only = os.environ.get("AB_ONLY")          # e.g. AB_ONLY="216,16,14,14,1": one shape, bf16 only
+    shapes = [tuple(int(v) for v in only.split(","))] if only else SHAPES
+    for dtype in ((torch.bfloat16,) if only else (torch.bfloat16, torch.float32)):
+        for c, t, h, w, s in shapes:
             nn = n if dtype == torch.bfloat16 else max(1, n // 8)
             g = torch.Generator().manual_seed(c * 7 + h)
             ho, wo = -(-h // s), -(-w // s)

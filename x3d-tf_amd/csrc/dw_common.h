@@ -73,6 +73,9 @@ bool dw_fwd_pd_launch(const DwFwdArgs& a, int dtype, int S, int SW, int cv, int 
 bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st);
 
+// packed variant for small stride-1 planes (dw_pk.hip): several samples of one channel per 512-thread workgroup
+bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW, hipStream_t st);
+
 // ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
 // resource's num_records) loads zeros / drops the store WITHOUT touching memory, so the instruction itself can be
 // unconditional.  That matters for more than the branch: vmcnt retires in order and the compiler must assume a
@@ -255,6 +258,8 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
   const int items = g.Ho * g.nstrips;
   if (items <= 64) bd = 64;
   else if (items <= 128) bd = 128;
+  static const char* bd_env = getenv("X3D_DW_BD");   // A/B hook: cap the workgroup size (64 / 128): more, smaller H-tiles
+  if (bd_env && atoi(bd_env) >= 64 && atoi(bd_env) < bd) bd = atoi(bd_env);
   if (g.nstrips > bd) return -1;
   int th = bd / g.nstrips;
   if (th > g.Ho) th = g.Ho;
