@@ -59,9 +59,33 @@ def test_bundle_roundtrip_with_reference_layout(tmp_path):
     hdr, ent = ck.read_index(prefix + ".index")
     assert hdr["num_shards"] == 1
     gold = {e["key"]: e for e in MAN["entries"]}
-    for k, e in ent.items():                      # same keys / shapes / sizes as the released file
-        assert k in gold and list(e.shape) == gold[k]["shape"] and e.size == gold[k]["size"], k
-    assert os.path.getsize(prefix + ".data-00000-of-00001") == 4 * (3795830 + 3764366)
+    assert set(ent) == set(gold)                  # all 789 keys of the released file: variables, momentum slots, optimizer
+    for k, e in ent.items():                      # hyper-parameters, object graph -- with the same shapes / sizes
+        assert list(e.shape) == gold[k]["shape"], k
+        if k != ck.OBJECT_GRAPH_KEY:              # (Keras' own graph carries bookkeeping edges this writer omits)
+            assert e.size == gold[k]["size"], k
+    assert ent[ck.OBJECT_GRAPH_KEY].dtype == ck.DT_STRING and ent["optimizer/iter" + ck.SUFFIX].dtype == ck.DT_INT64
+    # the object graph: following the `children` edges named by a key's segments from the root reaches a variable node
+    # whose VARIABLE_VALUE attribute carries exactly that checkpoint key (how Keras' object-based load_weights finds it);
+    # every momentum slot hangs off the optimizer node and points at its variable
+    nodes = ck.read_object_graph(prefix)
+
+    def walk(path):
+        cur = 0
+        for seg in path.split("/"):
+            cur = nodes[cur]["children"][seg]
+        return cur
+    for name in specs:
+        assert nodes[walk(name)]["attributes"] == {"VARIABLE_VALUE": name + ck.SUFFIX}, name
+    for h in ck.OPTIMIZER_HYPER:
+        assert nodes[walk("optimizer/" + h)]["attributes"]["VARIABLE_VALUE"] == f"optimizer/{h}{ck.SUFFIX}"
+    slots = nodes[walk("optimizer")]["slots"]
+    assert len(slots) == len(mom) == 308
+    for var_node, slot_name, slot_node in slots:
+        vkey = nodes[var_node]["attributes"]["VARIABLE_VALUE"]
+        assert slot_name == "momentum"
+        assert nodes[slot_node]["attributes"]["VARIABLE_VALUE"] == vkey[:-len(ck.SUFFIX)] + "/.OPTIMIZER_SLOT/optimizer/momentum" + ck.SUFFIX
+    assert len(nodes) == len({id(n) for n in nodes}) and all(0 <= c < len(nodes) for n in nodes for c in n["children"].values())
     back, mom_back = ck.read_checkpoint(str(tmp_path), specs, with_momentum=True)   # directory -> `checkpoint` file
     for k in state:
         assert torch.equal(back[k], state[k]), k
@@ -85,10 +109,17 @@ def test_corruption_and_partial_are_detected(tmp_path):
     ck.write_checkpoint(prefix, state, specs)
     data = prefix + ".data-00000-of-00001"
     raw = bytearray(open(data, "rb").read())
-    raw[1000] ^= 0xFF
+    _, ent = ck.read_index(prefix + ".index")
+    raw[ent["fc2/kernel" + ck.SUFFIX].offset + 100] ^= 0xFF          # inside a model variable
     open(data, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="CRC32C"):
         ck.read_checkpoint(prefix, specs)
+    raw[ent["fc2/kernel" + ck.SUFFIX].offset + 100] ^= 0xFF
+    raw[ent[ck.OBJECT_GRAPH_KEY].offset + 1000] ^= 0xFF              # inside the object graph
+    open(data, "wb").write(bytes(raw))
+    ck.read_checkpoint(prefix, specs)                                # the variables are intact ...
+    with pytest.raises(ValueError, match="checksum"):
+        ck.read_object_graph(prefix)                                 # ... the graph's checksum is not
     os.remove(data)
     with pytest.raises(FileNotFoundError, match="data shard"):
         ck.read_checkpoint(prefix, specs)

@@ -390,26 +390,183 @@ def read_checkpoint(path: str, specs: Dict[str, object], expect_partial: bool = 
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# the object graph Keras restores by (tensorflow/core/protobuf/trackable_object_graph.proto) [TF-3p]
+#   TrackableObjectGraph { repeated TrackableObject nodes = 1; }
+#   TrackableObject { repeated ObjectReference children = 1; repeated SerializedTensor attributes = 2;
+#                     repeated SlotVariableReference slot_variables = 3; }
+#   ObjectReference { int32 node_id = 1; string local_name = 2; }
+#   SerializedTensor { string name = 1; string full_name = 2; string checkpoint_key = 3; }
+#   SlotVariableReference { int32 original_variable_node_id = 1; string slot_name = 2; int32 slot_variable_node_id = 3; }
+# `model.load_weights(<TF-format checkpoint>)` (reference train.py:135, eval.py:81) walks the Python object tree from the
+# model and follows the proto's `children` edges by local name; a variable is restored from the `checkpoint_key` of its
+# VARIABLE_VALUE attribute.  The edges a restore walks are exactly the segments of the variable keys
+# ("stages/0/stage/layer_with_weights-0/bottleneck/a/kernel"), so the graph is rebuilt from the keys: one node per key
+# prefix.  Keras' own file holds more edges (layer-N aliases, keras_api bookkeeping): they are not needed to restore and
+# are not emitted.  The reference's file could not be decoded for comparison (its data shard is not in the checkout).
+# ------------------------------------------------------------------------------------------------
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+OPTIMIZER_HYPER = ("decay", "iter", "learning_rate", "momentum")   # optimizer/<name>/.ATTRIBUTES/VARIABLE_VALUE in the released bundles
+
+
+def _pb_len(field: int, payload: bytes) -> bytes:
+    return _put_varint((field << 3) | 2) + _put_varint(len(payload)) + payload
+
+
+def _pb_int(field: int, v: int) -> bytes:
+    return _put_varint((field << 3) | 0) + _put_varint(v)
+
+
+def build_object_graph(var_names: List[str], slot_names: List[str], slot: str = "momentum",
+                       hyper: Tuple[str, ...] = OPTIMIZER_HYPER) -> bytes:
+    """Serialized TrackableObjectGraph for model variables `var_names` (object paths without the VARIABLE_VALUE suffix),
+    an `optimizer` child of the root with its hyper-parameter variables and one `slot` variable per entry of
+    `slot_names`.  Node 0 is the root; nodes are numbered in breadth-first order."""
+    children: List[Dict[str, int]] = [{}]          # node -> {local name: node id}
+    attr_key: Dict[int, str] = {}                  # variable node -> checkpoint key
+    full_name: Dict[int, str] = {}
+
+    def node_of(path: str, create=True) -> int:
+        cur = 0
+        for seg in path.split("/"):
+            nxt = children[cur].get(seg)
+            if nxt is None:
+                if not create:
+                    raise KeyError(path)
+                children.append({})
+                nxt = len(children) - 1
+                children[cur][seg] = nxt
+            cur = nxt
+        return cur
+
+    for name in var_names:
+        nid = node_of(name)
+        attr_key[nid] = name + SUFFIX
+        full_name[nid] = name
+    slots: List[Tuple[int, int]] = []
+    if hyper or slot_names:
+        for h in hyper:
+            nid = node_of("optimizer/" + h)
+            attr_key[nid] = f"optimizer/{h}{SUFFIX}"
+            full_name[nid] = h
+        opt = node_of("optimizer")
+        for name in slot_names:       # slot variables hang off the optimizer node by reference, not by a named edge
+            children.append({})
+            sid = len(children) - 1
+            attr_key[sid] = f"{name}/.OPTIMIZER_SLOT/optimizer/{slot}{SUFFIX}"
+            full_name[sid] = f"{name}/{slot}"
+            slots.append((node_of(name, create=False), sid))
+    else:
+        opt = -1
+    # breadth-first renumbering from the root (the order TF writes; restore does not depend on it)
+    order, seen = [0], {0}
+    i = 0
+    while i < len(order):
+        for _, c in sorted(children[order[i]].items()):
+            if c not in seen:
+                seen.add(c)
+                order.append(c)
+        i += 1
+    order += [sid for _, sid in slots]
+    new_id = {old: new for new, old in enumerate(order)}
+    out = bytearray()
+    for old in order:
+        node = bytearray()
+        for local, c in sorted(children[old].items()):
+            node += _pb_len(1, _pb_int(1, new_id[c]) + _pb_len(2, local.encode()))
+        if old in attr_key:
+            node += _pb_len(2, _pb_len(1, b"VARIABLE_VALUE") + _pb_len(2, full_name[old].encode()) +
+                            _pb_len(3, attr_key[old].encode()))
+        if old == opt:
+            for var, sid in slots:
+                node += _pb_len(3, _pb_int(1, new_id[var]) + _pb_len(2, slot.encode()) + _pb_int(3, new_id[sid]))
+        out += _pb_len(1, bytes(node))
+    return bytes(out)
+
+
+def parse_object_graph(buf: bytes) -> List[dict]:
+    """TrackableObjectGraph bytes -> [{children: {local name: node}, attributes: {name: checkpoint key}, slots: [...]}]"""
+    nodes = []
+    for raw in _parse_proto(buf).get(1, []):
+        f = _parse_proto(raw)
+        ch = {}
+        for c in f.get(1, []):
+            cf = _parse_proto(c)
+            ch[cf[2][0].decode()] = cf.get(1, [0])[0]
+        at = {}
+        for a_ in f.get(2, []):
+            af = _parse_proto(a_)
+            at[af[1][0].decode()] = af[3][0].decode()
+        sl = []
+        for s_ in f.get(3, []):
+            sf = _parse_proto(s_)
+            sl.append((sf.get(1, [0])[0], sf[2][0].decode(), sf.get(3, [0])[0]))
+        nodes.append(dict(children=ch, attributes=at, slots=sl))
+    return nodes
+
+
+def _string_tensor_bytes(value: bytes) -> Tuple[bytes, int]:
+    """Scalar DT_STRING in a tensor bundle (tensor_bundle.cc WriteStringTensor): varint length | masked CRC32C of the
+    length (as uint32) | bytes; the entry checksum runs over length word, length checksum and bytes.  [TF-3p]"""
+    ln = struct.pack("<I", len(value))
+    c = crc32c(ln)
+    cks = struct.pack("<I", mask_crc(c))
+    c = crc32c(cks, c)
+    c = crc32c(value, c)
+    return _put_varint(len(value)) + cks + value, mask_crc(c)
+
+
+def read_object_graph(path: str) -> List[dict]:
+    """Parse the `_CHECKPOINTABLE_OBJECT_GRAPH` entry of a bundle (needs the data shard)."""
+    prefix = resolve_prefix(path)
+    header, entries = read_index(prefix + ".index")
+    e = entries[OBJECT_GRAPH_KEY]
+    fn = f"{prefix}.data-{e.shard_id:05d}-of-{header.get('num_shards', 1):05d}"
+    with open(fn, "rb") as f:
+        f.seek(e.offset)
+        raw = f.read(e.size)
+    ln, pos = _get_varint(raw, 0)
+    body = raw[pos + 4:pos + 4 + ln]
+    want = _string_tensor_bytes(body)
+    if want[0] != raw or want[1] != e.crc32c:
+        raise ValueError(f"{OBJECT_GRAPH_KEY}: string-tensor framing / checksum mismatch")
+    return parse_object_graph(body)
+
+
 def write_checkpoint(prefix: str, state: Dict[str, torch.Tensor], specs: Dict[str, object],
-                     momentum: Optional[Dict[str, torch.Tensor]] = None):
+                     momentum: Optional[Dict[str, torch.Tensor]] = None, optimizer_hyper: Optional[Dict[str, float]] = None):
     """Write ``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` + the ``checkpoint`` state file with the
-    reference's keys and TF layouts.  (The ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry Keras writes is not
-    emitted: name-based readers -- this one, tf.train.load_checkpoint -- do not need it.)"""
+    reference's keys and TF layouts, including the ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry Keras' object-based
+    ``load_weights`` restores by (build_object_graph) and the optimizer's hyper-parameter variables
+    (``optimizer/{iter,learning_rate,momentum,decay}``: `optimizer_hyper`, defaults 0 / 0.0)."""
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     items = []
+    slot_names = []
     for name, spec in specs.items():
         items.append((name + SUFFIX, to_tf(spec, state[name].detach().float().cpu())))
         if momentum and name in momentum:
             items.append((f"{name}/.OPTIMIZER_SLOT/optimizer/momentum{SUFFIX}",
                           to_tf(spec, momentum[name].detach().float().cpu())))
-    items.sort(key=lambda kv: kv[0])
+            slot_names.append(name)
+    hyper = dict(decay=0.0, iter=0, learning_rate=0.0, momentum=0.0)
+    hyper.update(optimizer_hyper or {})
+    raw_items = []     # (key, dtype, shape, raw bytes, masked crc)
+    for key, t in items:
+        raw = t.numpy().astype("<f4").tobytes()
+        raw_items.append((key, DT_FLOAT, tuple(t.shape), raw, mask_crc(crc32c(raw))))
+    for h in OPTIMIZER_HYPER:
+        raw = struct.pack("<q", int(hyper[h])) if h == "iter" else struct.pack("<f", float(hyper[h]))
+        raw_items.append((f"optimizer/{h}{SUFFIX}", DT_INT64 if h == "iter" else DT_FLOAT, (), raw, mask_crc(crc32c(raw))))
+    graph = build_object_graph(list(specs), slot_names)
+    graw, gcrc = _string_tensor_bytes(graph)
+    raw_items.append((OBJECT_GRAPH_KEY, DT_STRING, (), graw, gcrc))
+    raw_items.sort(key=lambda it: it[0])
     entries = {}
     off = 0
     with open(prefix + ".data-00000-of-00001", "wb") as f:
-        for key, t in items:
-            raw = t.numpy().astype("<f4").tobytes()
+        for key, dt, shape, raw, crc in raw_items:
             f.write(raw)
-            entries[key] = BundleEntry(DT_FLOAT, tuple(t.shape), 0, off, len(raw), mask_crc(crc32c(raw)))
+            entries[key] = BundleEntry(dt, shape, 0, off, len(raw), crc)
             off += len(raw)
     write_index(prefix + ".index", entries)
     with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:
@@ -428,9 +585,9 @@ def load_tf_checkpoint(model, path, expect_partial=True):
     return model
 
 
-def save_tf_checkpoint(model, prefix):
+def save_tf_checkpoint(model, prefix, optimizer_hyper=None):
     mom = {}
     for k in model.grads:
         o = model._offsets[k]
         mom[k] = model.flat_velocity[o:o + model.params[k].numel()].view(model.params[k].shape)
-    return write_checkpoint(prefix, model.state_dict(), model.specs, momentum=mom)
+    return write_checkpoint(prefix, model.state_dict(), model.specs, momentum=mom, optimizer_hyper=optimizer_hyper)

@@ -116,12 +116,15 @@ class Trainer:
 
     # -- checkpoints in the reference's layout (utils.py:128-132 ModelCheckpoint 'ckpt-{epoch:d}', train.py:131-136) --
     def save_checkpoint(self, model_dir: str, epoch: int) -> str:
-        """Writes `<model_dir>/ckpt-<epoch>` as a TF tensor bundle (weights + SGD momentum slots) and the
-        `checkpoint` state file, so that the reference's `tf.train.latest_checkpoint(model_dir)` finds it."""
+        """Writes `<model_dir>/ckpt-<epoch>` as a TF tensor bundle -- weights, SGD momentum slots, the optimizer's
+        hyper-parameter variables and the `_CHECKPOINTABLE_OBJECT_GRAPH` Keras' `load_weights` restores by -- and the
+        `checkpoint` state file, so that the reference's `tf.train.latest_checkpoint(model_dir)` finds it.  (Adam's
+        second-moment slots are not written: only the SGD branch round-trips its optimizer state.)"""
         import os
         os.makedirs(model_dir, exist_ok=True)
         prefix = os.path.join(model_dir, f"ckpt-{int(epoch)}")
-        self.model.save_weights(prefix)
+        self.model.save_weights(prefix, optimizer_hyper=dict(iter=self.opt_step, momentum=self.momentum,
+                                                             learning_rate=lr_schedule(self.epoch, self.cfg), decay=0.0))
         return prefix
 
     def resume(self, model_dir: str) -> int:
