@@ -311,11 +311,16 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
 // pairs of elements), at least two planes per workgroup, tensors below 1 GB (32-bit buffer offsets from the tensor base).
 bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW_caller, hipStream_t st) {
   const DwGeom& g = a.g;
-  if (pk_env("X3D_DW_PK", 1) == 0 || S != 1 || SW_caller != 2 || g.ntile_h != 1 || (g.W % 2) != 0 || g.pw != 1 || g.ph != 1)
-    return false;
-  // strips of 4 where the compile-time-geometry instantiation exists and fits 128 VGPRs (16-bit storage, 14x14); the
-  // run-time-geometry / fp32 strips-of-4 instantiations spill (22 / 86 VGPRs): strips of 2 there
-  const int SW = pk_env("X3D_DW_PK_SW", (dtype != X3D_F32 && g.W == 14 && g.H == 14) ? 4 : 2);
+  if (pk_env("X3D_DW_PK", 1) == 0 || S != 1 || g.ntile_h != 1 || (g.W % 2) != 0 || g.pw != 1 || g.ph != 1) return false;
+  // strips of 4 where a compile-time-geometry instantiation exists and fits 128 VGPRs (16-bit storage, 14x14); the
+  // run-time-geometry / fp32 strips-of-4 instantiations spill (22 / 86 VGPRs): strips of 2 there (rows up to 18 wide).
+  // 28x28 planes (whole plane = 196 threads = four waves per workgroup) were measured with this kernel too: 316 us against
+  // 297 us of dw3d_bwd_kernel (108 ch x 64 clips) -- with all global accesses off still 244 us: the fused backward costs
+  // ~2.6 ps of VALU time per output whatever the tiling (54 FMAs + ~30 other instructions per output at ~55 % issue
+  // utilisation), which is what bounds every stride-1 layer, not HBM.
+  const bool fixed4 = dtype != X3D_F32 && g.W == 14 && g.H == 14;
+  if (SW_caller != 2) return false;
+  const int SW = pk_env("X3D_DW_PK_SW", fixed4 ? 4 : 2);
   if (SW != 2 && SW != 4) return false;
   const int items = g.H * ceil_div(g.W, SW);
   if (items > PK_MAX_THREADS) return false;
