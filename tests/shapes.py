@@ -92,7 +92,8 @@ DW = [
     (1, 2, 3, 156, 156, 2), (1, 2, 3, 78, 78, 1), (1, 2, 3, 78, 78, 2), (1, 2, 3, 39, 39, 1),   # X3D-L / XL planes (16 x 312 x 312 clips)
     (1, 2, 3, 20, 20, 2), (1, 2, 3, 10, 10, 1), (1, 2, 3, 80, 80, 2), (1, 2, 3, 40, 40, 1), (1, 2, 3, 40, 40, 2),  # + X3D-S planes
     (1, 2, 3, 10, 10, 2), (1, 2, 3, 5, 5, 1),
-    (6, 3, 5, 14, 14, 1), (11, 2, 4, 10, 10, 1), (3, 2, 7, 12, 12, 1),   # packed backward (dw_pk.hip): 5 + 1, 10 + 1 and 3 planes per workgroup
+    (6, 3, 5, 14, 14, 1), (11, 2, 4, 10, 10, 1), (3, 2, 7, 12, 12, 1),   # packed backward (dw_pk.hip): one plane per wave, strips of 4 / 2
+    (9, 3, 5, 7, 7, 1),                                                   #   7x7: four planes per wave (4 + 4 + 1), strips 4 + 3
 ]
 
 # ---- whole-model cases (tests/test_model_gpu.py): variant, N, T, S --------------------------------------------------------

@@ -40,7 +40,12 @@ struct DwPkArgs {
 // LPC / HC: LDS row pitch and plane height as compile-time constants (0: run-time values from the arguments).  With both
 // known every LDS address of the loop is ONE base register + an immediate offset (tiles, buffers and window rows are
 // constant distances apart); with run-time values the loop carries ~20 address registers and spills at the 128-VGPR cap.
-template <typename T, int SW, int PD, int UN, int LPC, int HC>
+// ODD: rows of an odd number of elements (7x7 planes, strips 4 + 3): strips start at any element, loads are unaligned
+// (2-byte aligned 8-byte buffer loads: the compute queues run in unaligned-access mode), a strip's last half may hold ONE
+// valid element and is then stored as a single element.  The LOAD of a short last strip starts `shift` elements early
+// (columns W-4 .. W-1) so that it never leaves its row: a vector load that straddles the end of the tensor is dropped
+// whole by the bounds check, valid elements included.
+template <typename T, int SW, int PD, int UN, int LPC, int HC, bool ODD>
 __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const DwPkArgs pa) {
   static_assert(UN % 6 == 0 && UN % PD == 0, "roles have periods 2 (LDS buffers) and 3 (planes); slots period PD");
   static_assert(SW == 2 || SW == 4, "strips of 2 or 4 outputs");
@@ -87,9 +92,25 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
   // byte offset of this thread's strip in plane 0 of its (n, c) channel (a strip of 4 at the end of a 14-wide row reads two
   // elements of the next row: loaded, never used)
   const int voff = active ? (int)((((long long)n * g.C + c) * g.T * g.H * g.W + r * g.W + SW * sidx) * EB) : DW_OOB;
-  int voffH[NH];                                 // store offsets of the halves (a half outside the row is dropped)
-#pragma unroll
-  for (int h = 0; h < NH; h++) voffH[h] = (active && 2 * h < ncol) ? voff + 2 * h * EB : DW_OOB;
+  int voffH[NH], voff1[ODD ? NH : 1];            // store offsets of the halves (a half outside the row is dropped; ODD: a half
+#pragma unroll                                   // with one valid element is stored through voff1 as a single element)
+  for (int h = 0; h < NH; h++) {
+    voffH[h] = (active && 2 * h + 1 < ncol + (ODD ? 0 : 1)) ? voff + 2 * h * EB : DW_OOB;
+    if constexpr (ODD) voff1[h] = (active && 2 * h + 1 == ncol) ? voff + 2 * h * EB : DW_OOB;
+  }
+  const int shift = ODD ? SW - ncol : 0;          // elements the load starts early (0, or 1 for the 3-element strip of a 7-wide row)
+  const int voffL = (ODD && active) ? voff - shift * EB : voff;
+  // a loaded vector with output column 0 of the strip in element 0: one 64-bit shift by 16 * shift bits (ODD, 16-bit storage)
+  auto aligned = [&](const Raw& rw) -> Raw {
+    if constexpr (ODD) {
+      static_assert(!ODD || (EB == 2 && SW == 4), "odd rows: 16-bit storage, strips of 4");
+      const unsigned long long v = (((unsigned long long)rw.w[1] << 32) | rw.w[0]) >> (16 * shift);
+      Raw o; o.w[0] = (unsigned)v; o.w[1] = (unsigned)(v >> 32); o.w[2] = o.w[3] = 0u;
+      return o;
+    } else {
+      return rw;
+    }
+  };
   // LDS: plane p, buffer q at lds + (2 p + q) * pplane.  Image pixel (h, w) sits at row h + 1, column w + 1.
   float* myA = lds + (2 * (active ? p : 0)) * pplane;   // (idle threads read plane 0's windows and discard them)
   const int lS = (r + 1) * LP + 1 + SW * sidx;   // where the own strip is staged
@@ -99,12 +120,14 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
   Slot slot[PD];
   auto issue = [&](int t, Slot& s) {
     const int soff = (t < g.T && !pa.noload) ? t * planeB : DW_OOB;      // wave-uniform: planes past T move no data
-    raw_bload<SW * EB>(s.A, rsA, voff, soff);
-    raw_bload<SW * EB>(s.D, rsD, voff, soff);
-    raw_bload<SW * EB>(s.R, rsR, voff, soff);
+    raw_bload<SW * EB>(s.A, rsA, voffL, soff);
+    raw_bload<SW * EB>(s.D, rsD, voffL, soff);
+    raw_bload<SW * EB>(s.R, rsR, voffL, soff);
   };
   // plane in slot s -> LDS buffer q; returns the thread's own dB strip (zeros outside the image)
-  auto stage = [&](const Slot& s, int q, float (&dBown)[SW], bool plane_valid) {   // plane_valid: the plane exists (< T)
+  auto stage = [&](const Slot& s0, int q, float (&dBown)[SW], bool plane_valid) {   // plane_valid: the plane exists (< T)
+    Slot s;
+    s.A = aligned(s0.A); s.D = aligned(s0.D); s.R = aligned(s0.R);
     float* A = myA + q * pplane;
     float* B = A + tile;
 #pragma unroll
@@ -150,12 +173,16 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
       Raw o;
       raw_pack<T, 2>(o, two);
       raw_bstore<2 * EB>(o, rsG, voffH[h], soff);
+      if constexpr (ODD) raw_bstore<EB>(o, rsG, voff1[h], soff);   // element 2h alone (the low half of the packed pair)
     }
   };
   auto dummy_stores = [&]() {   // the store slots of an iteration, dropped: keeps the vmcnt pattern of the prologue = the loop's
     Raw z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
 #pragma unroll
-    for (int h = 0; h < NH; h++) raw_bstore<2 * EB>(z, rsG, voffH[h], DW_OOB);
+    for (int h = 0; h < NH; h++) {
+      raw_bstore<2 * EB>(z, rsG, voffH[h], DW_OOB);
+      if constexpr (ODD) raw_bstore<EB>(z, rsG, voff1[h], DW_OOB);
+    }
   };
 
   // prologue: PD planes in flight
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
   }
   __syncthreads();                       // zero fill done
   stage(slot[0], 0, dBs[0], true);
-  own0 = slot[0].A;
+  own0 = aligned(slot[0].A);
   issue(PD, slot[0]);
   dummy_stores();
   __syncthreads();                       // plane 0 visible in buffer 0
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
       // dB strip replaces plane t-2's
       own2 = own1; own1 = own0;
       stage(slot[sl], prv, dBs[pp1], t + 1 < g.T);
-      own0 = slot[sl].A;
+      own0 = aligned(slot[sl].A);
       issue(t + 1 + PD, slot[sl]);
       // weight gradient: one window of A[t] against the own strips dB[t+1], dB[t], dB[t-1] (temporal taps 0, 1, 2)
 #pragma unroll
@@ -287,15 +314,21 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
   const int threads = ceil_div(pa.NP * pa.items, 64) * 64;
   const size_t lds = ((size_t)pa.NP * 2 * 2 * (g.H + 2) * pa.LP + 8 + 29 * 8 + 8) * sizeof(float);
   if (lds > 64 * 1024 || threads > PK_MAX_THREADS) return false;
-  // compile-time geometry for the planes X3D has: 14x14 (M stage 4; pitch 16) and 10x10 (S / L / XL; pitch 12)
+  // compile-time geometry for the planes X3D has: 14x14 (M stage 4; pitch 16), 10x10 (S / L / XL; pitch 12), 7x7 (M stage 5)
   const bool fixed = (SW == 4 && pa.LP == 16 && g.H == 14) || (SW == 2 && pa.LP == 12 && g.H == 10);
+  const bool odd7 = SW == 4 && g.W == 7 && g.H == 7 && pa.LP == 12;
+  if ((g.W & 1) && !odd7) return false;
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d>", TypeName<T>::v, SW,
-             fixed ? pa.LP : 0, fixed ? g.H : 0);
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d, %d>", TypeName<T>::v, SW,
+             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7);
     return true;
   }
   pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;
-  auto kern = fixed ? dw3d_bwd_pk_kernel<T, SW, 2, 6, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10)> : dw3d_bwd_pk_kernel<T, SW, 2, 6, 0, 0>;
+  auto kern = fixed ? dw3d_bwd_pk_kernel<T, SW, 2, 6, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10), false>
+                    : dw3d_bwd_pk_kernel<T, SW, 2, 6, 0, 0, false>;
+  if constexpr (SW == 4 && sizeof(T) == 2) {
+    if (odd7) kern = dw3d_bwd_pk_kernel<T, 4, 2, 6, 12, 7, true>;
+  }
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,7 +344,9 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
 // pairs of elements), at least two planes per workgroup, tensors below 1 GB (32-bit buffer offsets from the tensor base).
 bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW_caller, hipStream_t st) {
   const DwGeom& g = a.g;
-  if (pk_env("X3D_DW_PK", 1) == 0 || S != 1 || g.ntile_h != 1 || (g.W % 2) != 0 || g.pw != 1 || g.ph != 1) return false;
+  if (pk_env("X3D_DW_PK", 1) == 0 || S != 1 || g.ntile_h != 1 || g.pw != 1 || g.ph != 1) return false;
+  const bool odd7 = dtype != X3D_F32 && g.W == 7 && g.H == 7 && pk_env("X3D_DW_PK7", 1) == 1;   // 7x7: strips 4 + 3, four planes per wave
+  if ((g.W % 2) != 0 && !odd7) return false;
   // strips of 4 where a compile-time-geometry instantiation exists and fits 128 VGPRs (16-bit storage, 14x14); the
   // run-time-geometry / fp32 strips-of-4 instantiations spill (22 / 86 VGPRs): strips of 2 there (rows up to 18 wide).
   // 28x28 planes (whole plane = 196 threads = four waves per workgroup) were measured with this kernel too: 316 us against
@@ -319,8 +354,8 @@ bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW_caller, hipSt
   // ~2.6 ps of VALU time per output whatever the tiling (54 FMAs + ~30 other instructions per output at ~55 % issue
   // utilisation), which is what bounds every stride-1 layer, not HBM.
   const bool fixed4 = dtype != X3D_F32 && g.W == 14 && g.H == 14;
-  if (SW_caller != 2) return false;
-  const int SW = pk_env("X3D_DW_PK_SW", fixed4 ? 4 : 2);
+  if (SW_caller != 2 && !odd7) return false;
+  const int SW = odd7 ? 4 : pk_env("X3D_DW_PK_SW", fixed4 ? 4 : 2);
   if (SW != 2 && SW != 4) return false;
   const int items = g.H * ceil_div(g.W, SW);
   if (items > PK_MAX_THREADS) return false;
