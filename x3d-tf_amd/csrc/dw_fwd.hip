@@ -198,6 +198,11 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   const int cv = strips_ok ? a.g.vec : 0;
   // small planes: deep-prefetch variant (dw_pd.hip) when one staging vector per thread covers the tile
   const int pd = dw_pick_pd(SW);
+  if (cv > 0 && dw_fwd_pk_launch(a, f->dtype, S, SW, st)) {   // 10..18-wide and 7x7 stride-1 planes: packed kernel (dw_pk.hip)
+    if (x3d_describe.out) return X3D_OK;
+    X3D_LAUNCH_CHECK("dw3d_fwd");
+    return X3D_OK;
+  }
   if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
     if (dw_fwd_pd_launch(a, f->dtype, S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;

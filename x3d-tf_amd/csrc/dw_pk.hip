@@ -369,3 +369,253 @@ bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW_caller, hipSt
   return dtype == X3D_BF16 ? PK_GO(bf16) : dtype == X3D_F16 ? PK_GO(f16) : PK_GO(float);
 #undef PK_GO
 }
+
+
+// ================================================================================================
+// FORWARD, same organisation: one wave per workgroup, NP planes of one channel per wave, strips of 4 (2), a thread
+// stages exactly its own strip (ONE load and one store per thread and plane), double-buffered LDS tile, windows read
+// as ds_read_b128 + b64 at a conflict-free pitch.  The tap loop is dw_taps_row / dw_rotate of the other forward
+// kernels (dw_common.h): same products in the same order, bit-identical outputs (tools/ab_dw.py).
+// ================================================================================================
+struct DwPkFwdArgs {
+  DwFwdArgs f;
+  int NP, items, ngroups, LP;
+  unsigned in_bytes;
+  int noload;
+};
+
+template <typename T, int SW, int PD, int UN, int LPC, int HC, bool ODD>
+__global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_fwd_pk_kernel(const DwPkFwdArgs pa) {
+  static_assert(UN % 2 == 0 && UN % PD == 0, "LDS buffers alternate; slots period PD");
+  constexpr int WIN = SW + 2;
+  constexpr int EB = (int)sizeof(T);
+  constexpr int NH = SW / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwFwdArgs& a = pa.f;
+  const DwGeom& g = a.g;
+  const int LP = LPC ? LPC : pa.LP;
+  const int tile = ((HC ? HC : g.H) + 2) * LP;
+  float* scratch = lds + pa.NP * 2 * tile + 8;   // [NP][2] per-plane sums
+
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x % g.C);
+  const int grp = __builtin_amdgcn_readfirstlane(blockIdx.x / g.C);
+  const int nstr = (g.W + SW - 1) / SW;
+  const int p = threadIdx.x / pa.items, rem = threadIdx.x - p * pa.items;
+  const int r = rem / nstr, sidx = rem - r * nstr;
+  const int n = grp * pa.NP + p;
+  const bool active = p < pa.NP && n < g.N;
+  const int ncol = min(SW, g.W - SW * sidx);
+  bool okc[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) okc[i] = active && i < ncol;
+
+  for (int i = threadIdx.x; i < pa.NP * 2 * tile + 8 + pa.NP * 2; i += blockDim.x) lds[i] = 0.f;
+
+  v2f w21[3][3];
+  float w0[3][3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    w21[k / 3][k % 3] = (v2f){a.w[c * 27 + 18 + k], a.w[c * 27 + 9 + k]};
+    w0[k / 3][k % 3] = a.w[c * 27 + k];
+  }
+  float sc = 1.f, sh = 0.f;
+  if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
+  const int act = a.act;
+
+  const int planeB = g.H * g.W * EB;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((T*)a.x, 0, pa.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((T*)a.y, 0, pa.in_bytes, 0x00020000);
+  const int voff = active ? (int)((((long long)n * g.C + c) * g.T * g.H * g.W + r * g.W + SW * sidx) * EB) : DW_OOB;
+  int voffH[NH], voff1[ODD ? NH : 1];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    voffH[h] = (active && 2 * h + 1 < ncol + (ODD ? 0 : 1)) ? voff + 2 * h * EB : DW_OOB;
+    if constexpr (ODD) voff1[h] = (active && 2 * h + 1 == ncol) ? voff + 2 * h * EB : DW_OOB;
+  }
+  const int shift = ODD ? SW - ncol : 0;
+  const int voffL = (ODD && active) ? voff - shift * EB : voff;
+  auto aligned = [&](const Raw& rw) -> Raw {
+    if constexpr (ODD) {
+      static_assert(!ODD || (EB == 2 && SW == 4), "odd rows: 16-bit storage, strips of 4");
+      const unsigned long long v = (((unsigned long long)rw.w[1] << 32) | rw.w[0]) >> (16 * shift);
+      Raw o; o.w[0] = (unsigned)v; o.w[1] = (unsigned)(v >> 32); o.w[2] = o.w[3] = 0u;
+      return o;
+    } else {
+      return rw;
+    }
+  };
+  float* myA = lds + (2 * (active ? p : 0)) * tile;
+  const int lS = (r + 1) * LP + 1 + SW * sidx;
+  const int lW = r * LP + SW * sidx;
+
+  Raw slot[PD];
+  auto issue = [&](int t, Raw& s) {
+    const int soff = (t < g.T && !pa.noload) ? t * planeB : DW_OOB;
+    raw_bload<SW * EB>(s, rsX, voffL, soff);
+  };
+  auto stage = [&](const Raw& s0, int q) {
+    const Raw s = aligned(s0);
+    float* A = myA + q * tile;
+#pragma unroll
+    for (int e = 0; e < SW; e++) {
+      const float u = sc * raw_get<T>(s, e) + sh;
+      if (okc[e]) A[lS + e] = act == X3D_ACT_RELU ? fmaxf(u, 0.f) : u;
+    }
+  };
+
+  float s1 = 0.f, s2 = 0.f;
+  auto store_plane = [&](int t, bool live, const float (&v)[SW]) {   // !live: nothing stored, nothing summed
+    float u[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) {
+      u[i] = (live && okc[i]) ? v[i] : 0.f;
+      s1 += u[i];
+      s2 += u[i] * u[i];
+    }
+    const int soff = (live && !pa.noload) ? t * planeB : DW_OOB;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      const float two[2] = {u[2 * h], u[2 * h + 1]};
+      Raw o;
+      raw_pack<T, 2>(o, two);
+      raw_bstore<2 * EB>(o, rsY, voffH[h], soff);
+      if constexpr (ODD) raw_bstore<EB>(o, rsY, voff1[h], soff);
+    }
+  };
+  auto dummy_stores = [&]() {
+    Raw z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      raw_bstore<2 * EB>(z, rsY, voffH[h], DW_OOB);
+      if constexpr (ODD) raw_bstore<EB>(z, rsY, voff1[h], DW_OOB);
+    }
+  };
+
+  v2f acc01[SW], acc2p[(SW + 1) / 2];   // (out[t-1], out[t]) per output, out[t+1] as pairs over outputs
+  float fin[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) { acc01[i] = (v2f){0.f, 0.f}; fin[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < (SW + 1) / 2; j++) acc2p[j] = (v2f){0.f, 0.f};
+
+#pragma unroll
+  for (int d = 0; d < PD; d++) {
+    issue(d, slot[d]);
+    dummy_stores();
+  }
+  __syncthreads();
+  stage(slot[0], 0);
+  issue(PD, slot[0]);
+  dummy_stores();
+  __syncthreads();
+
+  for (int t0 = 0; t0 < g.T; t0 += UN) {
+#pragma unroll
+    for (int d = 0; d < UN; d++) {
+      const int t = t0 + d;
+      if (t >= g.T) break;
+      const int cur = d & 1, prv = cur ^ 1;
+      const int sl = (d + 1) % PD;
+      float win[3][WIN];
+      {
+        const float* A = myA + cur * tile + lW;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) lds_window<WIN, SW>(A + kh * LP, win[kh]);
+      }
+      store_plane(t - 2, t >= 2, fin);                 // plane t-2 (finished at the end of iteration t-1)
+      stage(slot[sl], prv);
+      issue(t + 1 + PD, slot[sl]);
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) dw_taps_row<1, SW, WIN>(win[kh], w21[kh], w0[kh], acc01, acc2p);
+      dw_rotate<SW>(fin, acc01, acc2p);
+      __syncthreads();
+    }
+  }
+  store_plane(g.T - 2, g.T >= 2, fin);
+  float last[SW];
+#pragma unroll
+  for (int i = 0; i < SW; i++) last[i] = acc01[i].x;
+  store_plane(g.T - 1, true, last);
+
+  if (a.stats || a.pool) {
+    // per-plane sums: the threads of plane p add into scratch[p] (LDS atomics, once per workgroup)
+    if (active) {
+      atomicAdd(&scratch[p * 2], s1);
+      atomicAdd(&scratch[p * 2 + 1], s2);
+    }
+    __syncthreads();
+    if (threadIdx.x < pa.NP) {
+      const int nn = grp * pa.NP + threadIdx.x;
+      if (nn < g.N) {
+        const float q1 = scratch[threadIdx.x * 2], q2 = scratch[threadIdx.x * 2 + 1];
+        if (a.stats) {
+          double* sp = stats_replica(a.stats, g.C, (unsigned)nn);
+          atomic_add_d(&sp[c * 2], (double)q1);
+          atomic_add_d(&sp[c * 2 + 1], (double)q2);
+        }
+        if (a.pool) atomic_add_d(&a.pool[(long long)nn * g.C + c], (double)q1);
+      }
+    }
+  }
+}
+
+template <typename T, int SW>
+static bool fwd_pk_t(const DwFwdArgs& a, hipStream_t st) {
+  const DwGeom& g = a.g;
+  DwPkFwdArgs pa;
+  pa.f = a;
+  const int nstr = ceil_div(g.W, SW);
+  pa.items = g.H * nstr;
+  pa.NP = 64 / pa.items > 0 ? 64 / pa.items : 1;
+  if (pa.NP > g.N) pa.NP = g.N;
+  pa.ngroups = ceil_div(g.N, pa.NP);
+  pa.LP = (nstr * SW + 2 + 3) & ~3;
+  if (SW == 4 && nstr * SW == 16 && g.W + 2 <= 16) pa.LP = 16;
+  pa.in_bytes = (unsigned)((long long)g.N * g.C * g.T * g.H * g.W * (long long)sizeof(T));
+  const int threads = ceil_div(pa.NP * pa.items, 64) * 64;
+  const size_t lds = ((size_t)pa.NP * 2 * (g.H + 2) * pa.LP + 8 + pa.NP * 2 + 8) * sizeof(float);
+  if (lds > 64 * 1024 || threads > PK_MAX_THREADS) return false;
+  const bool fixed = (SW == 4 && pa.LP == 16 && g.H == 14) || (SW == 2 && pa.LP == 12 && g.H == 10);
+  const bool odd7 = SW == 4 && g.W == 7 && g.H == 7 && pa.LP == 12;
+  if ((g.W & 1) && !odd7) return false;
+  if (x3d_describe.out) {
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_pk_kernel<%s, %d, 2, 2, %d, %d, %d>", TypeName<T>::v, SW,
+             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7);
+    return true;
+  }
+  pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;
+  auto kern = fixed ? dw3d_fwd_pk_kernel<T, SW, 2, 2, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10), false>
+                    : dw3d_fwd_pk_kernel<T, SW, 2, 2, 0, 0, false>;
+  if constexpr (SW == 4 && sizeof(T) == 2) {
+    if (odd7) kern = dw3d_fwd_pk_kernel<T, 4, 2, 2, 12, 7, true>;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C * pa.ngroups)), dim3(threads), lds, st, pa);
+  return true;
+}
+
+// forward counterpart of dw_bwd_pk_launch: stride 1, whole plane per tile, rows of 10..18 outputs (strips of 4 at 14x14,
+// else 2) and 7x7 planes (16-bit storage), no folded BatchNorm finalize
+bool dw_fwd_pk_launch(const DwFwdArgs& a, int dtype, int S, int SW_caller, hipStream_t st) {
+  const DwGeom& g = a.g;
+  if (pk_env("X3D_DW_PK", 1) == 0 || pk_env("X3D_DW_PKF", 1) == 0 || S != 1 || g.ntile_h != 1 || g.pw != 1 || g.ph != 1 || a.bn.stats)
+    return false;
+  const bool odd7 = dtype != X3D_F32 && g.W == 7 && g.H == 7;
+  if ((g.W % 2) != 0 && !odd7) return false;
+  const bool fixed4 = dtype != X3D_F32 && g.W == 14 && g.H == 14;
+  if (SW_caller != 2 && !odd7) return false;
+  // measured (64 clips, bf16): 14x14 65.7 -> 63.3 us, 7x7 40.8 -> 38.8 us; strips of 2 (10x10) 54 -> 69 us: the forward
+  // packed kernel is used where strips of 4 apply and nowhere else (X3D_DW_PK_SW=2 forces strips of 2 for A/B runs)
+  const int SW = odd7 ? 4 : pk_env("X3D_DW_PK_SW", fixed4 ? 4 : 0);
+  if (SW != 2 && SW != 4) return false;
+  const int items = g.H * ceil_div(g.W, SW);
+  if (items > PK_MAX_THREADS) return false;
+  const int eb = dtype == X3D_F32 ? 4 : 2;
+  const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * eb;
+  if (bytes >= (1ll << 30)) return false;
+  const uintptr_t al = (uintptr_t)(2 * eb) - 1;
+  if (((uintptr_t)a.x & al) || ((uintptr_t)a.y & al)) return false;
+  if ((long long)g.C * g.N >= (1ll << 31)) return false;
+#define PK_GO(TT) (SW == 4 ? fwd_pk_t<TT, 4>(a, st) : fwd_pk_t<TT, 2>(a, st))
+  return dtype == X3D_BF16 ? PK_GO(bf16) : dtype == X3D_F16 ? PK_GO(f16) : PK_GO(float);
+#undef PK_GO
+}
