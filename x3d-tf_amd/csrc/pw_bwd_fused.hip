@@ -41,9 +41,14 @@ struct PwBwdArgs {
 #define FB_XP 136    // Xh pitch (elements): 272 B = 17 units
 #define FB_OP 132    // fp32 output slab pitch
 
+// waves per SIMD the register allocator must leave room for: the small panels (one or two dW tiles) fit three workgroups
+// per CU in LDS; their kernels are full of barriers and latency (7 per tile), a third workgroup fills them
+#ifndef FB_WAVES
+#define FB_WAVES(MT, KT) (((MT) * (KT) <= 2) ? 3 : 2)
+#endif
 // MT: 32-row tiles of Ci (dX rows / dW columns); KT: 32-row tiles of Co (dY rows / dW rows)
 template <typename H, int MT, int KT, int EPI>
-__global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(const PwBwdArgs a) {
+__global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(const PwBwdArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
