@@ -14,7 +14,8 @@ import re
 import sys
 
 
-_DW = re.compile(r"_Z\d+(dw3d_(?:fwd|bwd)(?:_pd)?(?:_s1)?_kernel)I(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE")
+_DW = re.compile(r"_Z\d+(dw3d_\w+?_kernel)I(DF16b|DF16_|f)((?:L[ib]\d+E)+)E")
+_TYPES = {"DF16b": "bf16", "DF16_": "f16", "f": "float"}
 
 
 def canonical(name):
@@ -23,7 +24,8 @@ def canonical(name):
     m = _DW.match(name)
     if not m:
         return name
-    return "%s<%s, %s, %s, %s, %s>" % (m.group(1), "bf16" if m.group(2) == "DF16b" else "float", *m.groups()[2:])
+    args = re.findall(r"L[ib](\d+)E", m.group(3))
+    return "%s<%s, %s>" % (m.group(1), _TYPES[m.group(2)], ", ".join(args))
 
 
 def collect(d, counter):

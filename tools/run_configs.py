@@ -1,5 +1,6 @@
 """Runs the other BASELINE.json configurations end to end on one MI355X and reports throughput
-(they are parity-test cases, not bench lines): S fp32 B=32 train, L bf16 train, XL 30-view inference."""
+(they are parity-test cases, not bench lines): S fp32 B=32 train, L bf16 train, XL 30-view inference in fp16 (the
+reference's mixed_float16) and bf16."""
 import os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,7 +48,9 @@ if __name__ == "__main__":
     res.append(train_rate("S", 32, 13, 160, torch.float32))          # config 2
     res.append(train_rate("L", 16, 16, 312, torch.bfloat16))         # config 4 (yaml batch 16)
     res.append(train_rate("XL", 8, 16, 312, torch.bfloat16))
-    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.bfloat16))  # config 5 (30 views / video), bf16 instead of fp16
+    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.float16))   # config 5: 30 views / video, fp16 (Keras mixed_float16)
+    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.bfloat16))  #   the same in bf16
+    res.append(train_rate("M", 64, 16, 224, torch.float16))          # the headline workload in fp16 with loss scaling
     res.append(infer_rate("XS", 8, 10, 1, 4, 160, torch.float32))    # config 1 on the GPU
     for r in res:
         print(json.dumps(r))
