@@ -92,6 +92,38 @@ class Trainer:
             self._good_steps = 0
         return pl
 
+    def fit(self, dataset, epochs: Optional[int] = None, steps_per_epoch: Optional[int] = None, model_dir: Optional[str] = None,
+            initial_epoch: Optional[int] = None, on_step=None):
+        """The loop `model.fit(dataset, epochs, steps_per_epoch, initial_epoch, callbacks)` runs in reference train.py:145-152
+        with its LearningRateScheduler (per-epoch `lr_schedule`, train.py:114-125) and ModelCheckpoint (`ckpt-{epoch}`
+        after every epoch, utils.py:128-132) callbacks -- nothing else of the Keras harness (TensorBoard / wandb callbacks
+        are out of scope).  `dataset`: an iterator of (clips, labels) batches, e.g. `dataloader.InputReader(cfg, True,
+        True)(pattern, cfg.TRAIN.BATCH_SIZE)` (infinite in training mode, like `dataset.repeat()`).  Returns the per-epoch
+        mean losses."""
+        tr = self.cfg.TRAIN
+        epochs = int(tr.EPOCHS if epochs is None else epochs)
+        steps = int(steps_per_epoch if steps_per_epoch is not None else tr.DATASET_SIZE // tr.BATCH_SIZE)
+        if steps <= 0:
+            raise ValueError("steps_per_epoch must be positive (cfg.TRAIN.DATASET_SIZE // cfg.TRAIN.BATCH_SIZE)")
+        if initial_epoch is not None:
+            self.epoch = int(initial_epoch)
+        it = iter(dataset)
+        history = []
+        while self.epoch < epochs:
+            lr = lr_schedule(self.epoch, self.cfg)
+            tot = torch.zeros((), dtype=torch.float64, device=self.model.device)
+            for _ in range(steps):
+                clips, labels = next(it)
+                pl = self.step(clips, labels, lr)
+                tot += self.loss(pl).double()
+                if on_step is not None:
+                    on_step(self, pl)
+            self.epoch += 1
+            history.append(float(tot.item()) / steps)
+            if model_dir is not None and xdist.env_world()[0] == 0:
+                self.save_checkpoint(model_dir, self.epoch)
+        return history
+
     def collective_stats(self):
         """What the exchange step of this replica did so far (bench.py's `collectives` block)."""
         r = self.reducer
