@@ -187,6 +187,25 @@ def test_eval_pipeline_matches_oracle(gpu, tmp_path, dtype):
 
 
 @pytest.mark.gpu
+def test_evaluate_dataset_equals_evaluate_on_decoded_videos(gpu, tmp_path):
+    """eval.py:75-89: the metrics over InputReader batches equal the metrics of `evaluate` on the same decoded videos."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.evaluate import evaluate, evaluate_dataset
+    cfg = x.get_config("XS", ["DATA.TEMP_DURATION", 4, "DATA.TEST_CROP_SIZE", 32, "TEST.NUM_TEMPORAL_VIEWS", 2,
+                              "TEST.NUM_SPATIAL_CROPS", 3, "TEST.BATCH_SIZE", 2, "NETWORK.NUM_CLASSES", 10])
+    vids = [(v, i % 10) for i, (v, _) in enumerate(_videos(4, seed=6, h=40, w=52))]
+    pattern, _ = _write_dataset(tmp_path, vids, per_file=2)
+    model = x.X3D(cfg, dtype=torch.float32, device=gpu, seed=3)
+    got = evaluate_dataset(model, cfg, DL.InputReader(cfg, False, True, device=gpu)(pattern, cfg.TEST.BATCH_SIZE))
+    decoded = [(torch.from_numpy(DL.InputReader.parse_and_decode(None, DL.make_sequence_example(v, lab))[0]).to(gpu), lab)
+               for v, lab in vids]
+    want = evaluate(model, cfg, decoded)
+    assert got["videos"] == want["videos"] == 4
+    for k in ("loss", "acc", "top_5_acc"):
+        assert abs(got[k] - want[k]) < 1e-6, k
+
+
+@pytest.mark.gpu
 def test_train_pipeline_matches_oracle(gpu, tmp_path):
     """Training mode: shuffled, repeated, one augmented clip per video; given the draws the reader made, every clip of a
     batch is bit-identical to the oracle's train_clip; one epoch sees every video exactly once."""

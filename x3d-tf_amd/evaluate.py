@@ -63,3 +63,15 @@ def evaluate(model, cfg, videos: Iterable[Tuple[torch.Tensor, int]], batch_video
     if hasattr(model, "release_plans"):
         model.release_plans(keep=1)     # the partial tail batch allocated a second multi-GB plan
     return m.result()
+
+
+def evaluate_dataset(model, cfg, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]]) -> Dict[str, float]:
+    """reference eval.py:83-89 `model.evaluate(InputReader(cfg, False, use_tfrecord)(pattern, cfg.TEST.BATCH_SIZE))`:
+    `batches` yields (clips [B * views * crops, T, S, S, 3], labels [B]) as `dataloader.InputReader` does in evaluation
+    mode (the views were built on the GPU while the batch was assembled)."""
+    m = Metrics(float(model.regularization_loss().item()) if hasattr(model, "regularization_loss") else 0.0)
+    for clips, labels in batches:
+        m.update(model(clips, training=False).float(), labels)
+    if hasattr(model, "release_plans"):
+        model.release_plans(keep=1)
+    return m.result()
