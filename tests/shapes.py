@@ -94,6 +94,10 @@ DW = [
     (1, 2, 3, 10, 10, 2), (1, 2, 3, 5, 5, 1),
     (6, 3, 5, 14, 14, 1), (11, 2, 4, 10, 10, 1), (3, 2, 7, 12, 12, 1),   # packed backward (dw_pk.hip): one plane per wave, strips of 4 / 2
     (9, 3, 5, 7, 7, 1),                                                   #   7x7: four planes per wave (4 + 4 + 1), strips 4 + 3
+    # ragged rows (flat staging, CV < 0): X3D-S 182-pixel test crops (91 / 46 / 23), vectors that cross rows and H-tiles,
+    # rows shorter than a 16-byte vector (13 -> 7: 8-byte vectors), short planes
+    (1, 2, 3, 91, 91, 1), (1, 2, 3, 91, 91, 2), (1, 2, 4, 46, 46, 1), (1, 2, 3, 23, 23, 1), (1, 2, 3, 23, 23, 2),
+    (2, 2, 3, 13, 13, 2), (1, 2, 3, 6, 21, 1), (1, 1, 3, 30, 11, 1), (1, 2, 2, 3, 37, 1),
 ]
 
 # ---- whole-model cases (tests/test_model_gpu.py): variant, N, T, S --------------------------------------------------------

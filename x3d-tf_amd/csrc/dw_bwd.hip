@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
   constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
   constexpr int NS = NSV > 0 ? NSV : 1;
+  constexpr bool RAG = CV < 0;                   // ragged planes: flat staging in vectors of -CV elements (FlatMap)
+  constexpr int RV = RAG ? -CV : 1;
   // deferred emit (see the plane loop): costs NR*NA registers -- the 2x2-quad stride-2 variant would drop a wave
   constexpr bool DEFER = (S == 1);
   const int aplane = g.RIN * g.LP;
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   const T* brp = (const T*)a.braw + ((long long)n * g.C + c) * g.T * opl;
   T* gap = (T*)a.ga + ((long long)n * g.C + c) * g.T * ipl;
   const int rowA0 = h0 * S - g.ph;
-  const int vecA = CV > 0 ? CV : g.vec;
-  const int vecB = CV > 0 ? (S == 1 ? CV : (CV > 1 ? CV / 2 : 1)) : a.vecB;
+  const int vecA = CV > 0 ? CV : (RAG ? RV : g.vec);
+  const int vecB = CV > 0 ? (S == 1 ? CV : (CV > 1 ? CV / 2 : 1)) : (RAG ? RV : a.vecB);
 
-  StageMap<NS> mapA, mapB;
+  typename DwSel<RAG, FlatMap<NS>, StageMap<NS>>::type mapA, mapB;
   Raw rawA[NS], rawD[NS], rawR[NS];
   auto issue = [&](int t) {
     if constexpr (NSV > 0) {
@@ -104,7 +106,9 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
   // top of the iteration so its latency hides behind the plane's arithmetic
   // the NA owned columns of a row are contiguous and NA-aligned when the strips tile the row exactly and the
   // left pad is 0: one vector load / store per row instead of NA two-byte accesses
-  const bool vown = (CV > 0 && NA > 1) || ((NA > 1) && (g.W % NA == 0) && (S == 1 || g.pw == 0) && (g.Wo % SW == 0) &&
+  // (ragged planes: every strip that lies inside the row, at whatever alignment; the strips cut by a row end go
+  // element by element)
+  const bool vown = RAG ? (NA > 1 && wA0 >= 0 && wA0 + NA <= g.W) : (CV > 0 && NA > 1) || ((NA > 1) && (g.W % NA == 0) && (S == 1 || g.pw == 0) && (g.Wo % SW == 0) &&
                     (((uintptr_t)a.araw) % (NA * sizeof(T)) == 0) && (((uintptr_t)a.ga) % (NA * sizeof(T)) == 0));
   float ar[NR][NA];
   auto load_own = [&](int t) {
@@ -163,13 +167,19 @@ __global__ __launch_bounds__(256) void dw3d_bwd_kernel(const DwBwdArgs a) {
       for (int i = 0; i < NS; i++) {
         if (mapA.goff[i] >= 0) {
           float* d = Al + mapA.loff[i];
+          if constexpr (RAG) flat_commit<T, RV>(d, mapA.wrap[i], g.LP - g.W, rawA[i], af);
+          else {
 #pragma unroll
-          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecA) d[e] = af(raw_get<T>(rawA[i], e));
+            for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecA) d[e] = af(raw_get<T>(rawA[i], e));
+          }
         }
         if (mapB.goff[i] >= 0) {
           float* d = Bl + mapB.loff[i];
+          if constexpr (RAG) flat_commit2<T, RV>(d, mapB.wrap[i], a.LPB - g.Wo, rawD[i], rawR[i], bf);
+          else {
 #pragma unroll
-          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecB) d[e] = bf(raw_get<T>(rawD[i], e), raw_get<T>(rawR[i], e));
+            for (int e = 0; e < MaxVec<T>::v; e++) if (e < vecB) d[e] = bf(raw_get<T>(rawD[i], e), raw_get<T>(rawR[i], e));
+          }
         }
       }
     } else {
@@ -305,6 +315,8 @@ static void dw_bwd_launch_cv(const DwBwdArgs& a, int nsv, unsigned grid, int bd,
 template <typename T, int S, int SW>
 static void dw_bwd_launch_nsv(const DwBwdArgs& a, int nsv, int cv, unsigned grid, int bd, size_t lds, hipStream_t st) {
   switch (cv) {
+    case -8: if constexpr (sizeof(T) == 2) { dw_bwd_launch_cv<T, S, SW, -8>(a, nsv, grid, bd, lds, st); break; }
+    case -4: dw_bwd_launch_cv<T, S, SW, -4>(a, nsv, grid, bd, lds, st); break;
     case 8: if constexpr (sizeof(T) == 2) { dw_bwd_launch_cv<T, S, SW, 8>(a, nsv, grid, bd, lds, st); break; }
     case 4: dw_bwd_launch_cv<T, S, SW, 4>(a, nsv, grid, bd, lds, st); break;
     case 2: dw_bwd_launch_cv<T, S, SW, 2>(a, nsv, grid, bd, lds, st); break;
@@ -345,7 +357,18 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     else a.vecB = cvB;
   }
   const int nsvA = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd), nsvB = dw_nsv(a.RB, a.g.Wo, a.vecB, bd);
-  const int nsv = nsvA > nsvB ? nsvA : nsvB;
+  int nsv = nsvA > nsvB ? nsvA : nsvB;
+  // ragged rows (39, 78, 91 ... wide; stride 2 with a left pad; a misaligned tensor): flat staging with unaligned
+  // 16 / 8-byte vectors and per-thread vector / scalar own strips instead of the unprefetched generic path.
+  // X3D_DW_FLAT=0: A/B hook.
+  static const char* flat_env = getenv("X3D_DW_FLAT");
+  if ((cv == 0 || (flat_env && atoi(flat_env) == 2)) && !(flat_env && atoi(flat_env) == 0)) {   // 2: force (experiment)
+    const int rv = dw_flat_vec(sizeof(T), a.g.W < a.g.Wo ? a.g.W : a.g.Wo);
+    if (rv > 0) {
+      const int fa = dw_nsv_flat(a.g.RIN, a.g.W, rv, bd), fb = dw_nsv_flat(a.RB, a.g.Wo, rv, bd);
+      if (fa <= 2 && fb <= 2) { cv = -rv; nsv = fa > fb ? fa : fb; }
+    }
+  }
   // small planes (strips of 1 / 2 outputs, stride 1): deep-prefetch variant (dw_pd.hip) when one staging vector per
   // thread and tensor covers the tile
   // stride 2: depth 2 (144 VGPRs, 3 waves; no vmcnt(0) drain before the stores: 1066 -> 961 us at 112x112); depth 4 is

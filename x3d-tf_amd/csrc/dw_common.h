@@ -135,6 +135,54 @@ struct StageMap {
   }
 };
 
+// Ragged planes (a row is not a whole number of aligned vectors: W = 39, 78, 91 ...).  A tile covers whole rows, so
+// its valid rows are ONE contiguous run of elements in memory: the run is cut into vectors of `vec` elements whatever
+// the row length (the loads are then unaligned, which the compute queues' unaligned access mode allows; the last
+// vector is moved back to end with the run so that nothing past the tensor is touched).  A vector may cross from one
+// row to the next: elements k >= wrap[i] land `skip` = LP - W floats further on in LDS.  Needs W >= vec.
+template <bool B, typename A, typename C> struct DwSel { typedef A type; };
+template <typename A, typename C> struct DwSel<false, A, C> { typedef C type; };
+template <int NSV>
+struct FlatMap {
+  int goff[NSV], loff[NSV], wrap[NSV];
+  __device__ __forceinline__ void build(int RIN, int LP, int row0, int H, int W, int pw, int vec) {
+    const int rlo = row0 > 0 ? row0 : 0, rhi = (row0 + RIN < H) ? row0 + RIN : H;
+    const int span = (rhi - rlo) * W, nvec = (span + vec - 1) / vec;
+#pragma unroll
+    for (int i = 0; i < NSV; i++) {
+      const int v = threadIdx.x + i * blockDim.x;
+      goff[i] = -1; loff[i] = 0; wrap[i] = vec;
+      if (v < nvec) {
+        int e = v * vec;
+        if (e > span - vec) e = span - vec;
+        const int lr = e / W, col = e - lr * W;
+        goff[i] = rlo * W + e; loff[i] = (rlo - row0 + lr) * LP + pw + col; wrap[i] = W - col;
+      }
+    }
+  }
+};
+// LDS commit of one ragged vector: element k of the vector -> d[k] or, past the row end, d[k + skip]
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void flat_commit(float* d, int wrap, int skip, const Raw& r, F f) {
+  float* d2 = d + skip;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) (k >= wrap ? d2 : d)[k] = f(raw_get<T>(r, k));
+}
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void flat_commit2(float* d, int wrap, int skip, const Raw& r0, const Raw& r1, F f) {
+  float* d2 = d + skip;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) (k >= wrap ? d2 : d)[k] = f(raw_get<T>(r0, k), raw_get<T>(r1, k));
+}
+// staging vectors per thread of the ragged map
+static int dw_nsv_flat(int rows, int W, int vec, int bd) { return ceil_div(ceil_div(rows * W, vec), bd); }
+// ragged staging width for rows of at least `wmin` elements: 16 bytes, else 8 bytes (16-bit types), else 0 = not covered
+static int dw_flat_vec(int elem_bytes, int wmin) {
+  if (wmin >= 16 / elem_bytes) return 16 / elem_bytes;
+  if (elem_bytes == 2 && wmin >= 4) return 4;
+  return 0;
+}
+
 // generic (no prefetch) staging for tiles with more vectors per thread than the register budget
 template <typename T, typename F>
 __device__ __forceinline__ void stage_direct(const T* src, float* lds, int RIN, int LP, int row0, int H, int W,

@@ -13,6 +13,8 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   const DwGeom& g = a.g;
   constexpr int WIN = (SW - 1) * S + 3;
   constexpr int NS = NSV > 0 ? NSV : 1;
+  constexpr bool RAG = CV < 0;            // ragged plane: flat staging in vectors of -CV elements (FlatMap, dw_common.h)
+  constexpr int RV = RAG ? -CV : 1;
   const int plane_sz = g.RIN * g.LP;
   float* scratch = lds + plane_sz;
 
@@ -49,9 +51,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   const T* xin = (const T*)a.x + ((long long)n * g.C + c) * g.T * iplane;
   T* yout = (T*)a.y + ((long long)n * g.C + c) * g.T * oplane;
   const int row0 = h0 * S - g.ph;
-  const int vec = CV > 0 ? CV : g.vec;
+  const int vec = CV > 0 ? CV : (RAG ? RV : g.vec);
 
-  StageMap<NS> map;
+  typename DwSel<RAG, FlatMap<NS>, StageMap<NS>>::type map;
   Raw raw[NS];
   if constexpr (NSV > 0) {
     map.build(g.RIN, g.LP, row0, g.H, g.W, g.pw, vec);
@@ -71,7 +73,9 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
 
   // every strip is full and SW-aligned when Wo % SW == 0: one 8/16-byte store per thread and plane instead
   // of SW two-byte stores (the scalar stores, not HBM, were the limiter of the stride-1 layers)
-  const bool vstore = (CV > 0 && SW > 1) || ((SW > 1) && (g.Wo % SW == 0) && (((uintptr_t)a.y) % (SW * sizeof(T)) == 0));
+  // (ragged planes: every strip that is whole, at whatever alignment; the row's last strip stores its elements one by one)
+  const bool vstore = RAG ? (SW > 1 && wo0 + SW <= g.Wo)
+                          : ((CV > 0 && SW > 1) || ((SW > 1) && (g.Wo % SW == 0) && (((uintptr_t)a.y) % (SW * sizeof(T)) == 0)));
   auto store_plane = [&](int t, const float (&v)[SW]) {
     if (!active) return;
     T* dst = yout + t * oplane + (long long)ho * g.Wo + wo0;
@@ -101,8 +105,11 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
       for (int i = 0; i < NS; i++) {
         if (map.goff[i] >= 0) {
           float* d = lds + map.loff[i];
+          if constexpr (RAG) flat_commit<T, RV>(d, map.wrap[i], g.LP - g.W, raw[i], xf);
+          else {
 #pragma unroll
-          for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = xf(raw_get<T>(raw[i], e));
+            for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = xf(raw_get<T>(raw[i], e));
+          }
         }
       }
     } else {
@@ -166,6 +173,8 @@ static void dw_fwd_launch_cv(const DwFwdArgs& a, int nsv, unsigned grid, int bd,
 template <typename T, int S, int SW>
 static void dw_fwd_launch_nsv(const DwFwdArgs& a, int nsv, int cv, unsigned grid, int bd, size_t lds, hipStream_t st) {
   switch (cv) {
+    case -8: if constexpr (sizeof(T) == 2) { dw_fwd_launch_cv<T, S, SW, -8>(a, nsv, grid, bd, lds, st); break; }
+    case -4: dw_fwd_launch_cv<T, S, SW, -4>(a, nsv, grid, bd, lds, st); break;
     case 8: if constexpr (sizeof(T) == 2) { dw_fwd_launch_cv<T, S, SW, 8>(a, nsv, grid, bd, lds, st); break; }
     case 4: dw_fwd_launch_cv<T, S, SW, 4>(a, nsv, grid, bd, lds, st); break;
     case 2: dw_fwd_launch_cv<T, S, SW, 2>(a, nsv, grid, bd, lds, st); break;
@@ -192,10 +201,10 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   X3D_REQUIRE(lds <= 64 * 1024, "dw3d_fwd: tile needs %zu B of LDS", lds);
   const long long grid = (long long)f->N * f->C * a.g.ntile_h;
   X3D_REQUIRE(grid < (1ll << 31), "dw3d_fwd: grid too large");
-  const int nsv = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd);
+  int nsv = dw_nsv(a.g.RIN, a.g.W, a.g.vec, bd);
   // compile-time staging width when every output strip is whole and SW-aligned (always true for SW == 1)
   const bool strips_ok = (a.g.Wo % SW == 0) && (((uintptr_t)f->y) % (SW * sizeof(T)) == 0);
-  const int cv = strips_ok ? a.g.vec : 0;
+  int cv = strips_ok ? a.g.vec : 0;
   // small planes: deep-prefetch variant (dw_pd.hip) when one staging vector per thread covers the tile
   const int pd = dw_pick_pd(SW);
   if (cv > 0 && dw_fwd_pk_launch(a, f->dtype, S, SW, st)) {   // 10..18-wide and 7x7 stride-1 planes: packed kernel (dw_pk.hip)
@@ -209,6 +218,15 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
       X3D_LAUNCH_CHECK("dw3d_fwd");
       return X3D_OK;
     }
+  }
+  // ragged rows (39, 78, 91 ... wide, or a misaligned tensor): flat staging with unaligned 16 / 8-byte vectors instead
+  // of the run-time-width path.  X3D_DW_FLAT=0: A/B hook.
+  static const char* flat_env = getenv("X3D_DW_FLAT");
+  // (also when the strips are whole but the rows only admit 2 / 4-byte vectors: 39 -> 20, 23 -> 12 at stride 2)
+  const bool narrow = cv > 0 && cv * sizeof(T) < 8;
+  if ((cv == 0 || narrow) && !(flat_env && atoi(flat_env) == 0)) {
+    const int rv = dw_flat_vec(sizeof(T), a.g.W);
+    if (rv > 0 && dw_nsv_flat(a.g.RIN, a.g.W, rv, bd) <= 4) { cv = -rv; nsv = dw_nsv_flat(a.g.RIN, a.g.W, rv, bd); }
   }
   switch (SW) {
     case 4: dw_fwd_launch_nsv<T, S, 4>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
