@@ -380,8 +380,18 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     X3D_LAUNCH_CHECK("dw3d_bwd");
     return X3D_OK;
   }
-  if (pd > 1 && cv > 0 && nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
-    if (dw_bwd_pd_launch(a, f->dtype, S, SW, cv, pd, (unsigned)grid, bd, lds, st)) {
+  // stride 2, rows that only admit narrow vectors (28 x 28: 8 bytes, 14 x 14: 4 bytes): the deep-prefetch kernel with FLAT
+  // 16-byte staging vectors when those bring the tile down to one vector per thread.  X3D_DW_PDFLAT=0: A/B hook.
+  static const char* pdflat_env = getenv("X3D_DW_PDFLAT");
+  int pd_cv = cv, pd_nsv = nsv;
+  if (S == 2 && pd > 1 && cv > 0 && nsv > 1 && !(pdflat_env && atoi(pdflat_env) == 0)) {
+    const int va = 16 / (int)sizeof(T), vb = va / 2;
+    if (a.g.W >= va && a.g.Wo >= vb && dw_nsv_flat(a.g.RIN, a.g.W, va, bd) <= 1 && dw_nsv_flat(a.RB, a.g.Wo, vb, bd) <= 1) {
+      pd_cv = -va; pd_nsv = 1;
+    }
+  }
+  if (pd > 1 && cv > 0 && pd_nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
+    if (dw_bwd_pd_launch(a, f->dtype, S, SW, pd_cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;
       X3D_LAUNCH_CHECK("dw3d_bwd");
       return X3D_OK;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
 #define DW_S1_OCC 4
 #endif
 template <int S, int SW, int CV> struct BwdPdWaves {
-  static constexpr int v = (S == 1 && SW == 2 && CV <= 2) ? DW_S1_OCC : ((SW == 1 && CV <= 4) ? 4 : 1);
+  static constexpr int v = CV < 0 ? 1 : ((S == 1 && SW == 2 && CV <= 2) ? DW_S1_OCC : ((SW == 1 && CV <= 4) ? 4 : 1));
 };
 template <typename T, int S, int SW, int CV, int PD>
 __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_kernel(const DwBwdArgs a) {
@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
   constexpr int NA = (S == 1) ? SW : 2 * SW;     // dA columns owned per row
   constexpr int NR = (S == 1) ? 1 : 2;           // dA rows owned
   constexpr bool DEFER = (S == 1);               // emit a finished dA plane one iteration late (register budget, see dw_bwd.hip)
-  constexpr int VA = CV, VB = (S == 1) ? CV : (CV > 1 ? CV / 2 : 1);
+  // CV < 0: FLAT staging (FlatMap, dw_common.h) in vectors of -CV elements cut from the tile's contiguous run of rows --
+  // whole 16-byte loads on planes whose rows are not (28 x 28: 56-byte rows, 14 x 14: 28-byte rows), so that one vector
+  // per thread covers the tile
+  constexpr bool FLAT = CV < 0;
+  constexpr int VA = FLAT ? -CV : CV, VB = (S == 1) ? VA : (VA > 1 ? VA / 2 : 1);
   constexpr int EB = (int)sizeof(T);
   const int aplane = g.RIN * g.LP;
   const int bplane = a.RB * a.LPB;
@@ -215,8 +219,31 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
   const int rowA0 = h0 * S - g.ph;
 
   // staging maps: ONE vector per thread and tensor (host guarantees it)
-  int gA = DW_OOB, lA = 0, gB = DW_OOB, lB = 0;
+  int gA = DW_OOB, lA = 0, gB = DW_OOB, lB = 0, wrA = VA, wrB = VB;
   bool okA = false, okB = false;
+  if constexpr (FLAT) {
+    {
+      const int rlo = rowA0 > 0 ? rowA0 : 0, rhi = (rowA0 + g.RIN < g.H) ? rowA0 + g.RIN : g.H;
+      const int span = (rhi - rlo) * g.W, nvec = (span + VA - 1) / VA, v = threadIdx.x;
+      if (v < nvec) {
+        int e = v * VA;
+        if (e > span - VA) e = span - VA;
+        const int lr = e / g.W, col = e - lr * g.W;
+        okA = true; gA = (rlo * g.W + e) * EB; lA = (rlo - rowA0 + lr) * g.LP + g.pw + col; wrA = g.W - col;
+      }
+    }
+    {
+      const int rb0 = h0 - 1;
+      const int rlo = rb0 > 0 ? rb0 : 0, rhi = (rb0 + a.RB < g.Ho) ? rb0 + a.RB : g.Ho;
+      const int span = (rhi - rlo) * g.Wo, nvec = (span + VB - 1) / VB, v = threadIdx.x;
+      if (v < nvec) {
+        int e = v * VB;
+        if (e > span - VB) e = span - VB;
+        const int lr = e / g.Wo, col = e - lr * g.Wo;
+        okB = true; gB = (rlo * g.Wo + e) * EB; lB = (rlo - rb0 + lr) * a.LPB + 1 + col; wrB = g.Wo - col;
+      }
+    }
+  } else {
   {
     const int nvr = g.W / VA, v = threadIdx.x;
     if (v < g.RIN * nvr) {
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
       const int lr = v / nvr, jv = v - lr * nvr, hi = h0 - 1 + lr;
       if (hi >= 0 && hi < g.Ho) { okB = true; gB = (hi * g.Wo + jv * VB) * EB; lB = lr * a.LPB + 1 + jv * VB; }
     }
+  }
   }
   // image rows / cols owned for dA (NA contiguous, NA-aligned columns per row: host checks W % NA == 0, pw == 0 for S == 2)
   const int hA = (S == 1) ? ho : ho * 2 - g.ph;
@@ -307,13 +335,19 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
       __syncthreads();
       if (okA) {
         float* dst = Al + lA;
+        if constexpr (FLAT) flat_commit<T, VA>(dst, wrA, g.LP - g.W, slot[d].A, af);
+        else {
 #pragma unroll
-        for (int e = 0; e < VA; e++) dst[e] = af(raw_get<T>(slot[d].A, e));
+          for (int e = 0; e < VA; e++) dst[e] = af(raw_get<T>(slot[d].A, e));
+        }
       }
       if (okB) {
         float* dst = Bl + lB;
+        if constexpr (FLAT) flat_commit2<T, VB>(dst, wrB, a.LPB - g.Wo, slot[d].D, slot[d].R, bf);
+        else {
 #pragma unroll
-        for (int e = 0; e < VB; e++) dst[e] = bf(raw_get<T>(slot[d].D, e), raw_get<T>(slot[d].R, e));
+          for (int e = 0; e < VB; e++) dst[e] = bf(raw_get<T>(slot[d].D, e), raw_get<T>(slot[d].R, e));
+        }
       }
       Raw own0[NR];
 #pragma unroll
@@ -734,6 +768,11 @@ static bool bwd_pd_t(const DwBwdArgs& a, int S, int SW, int cv, int pd, unsigned
   } else {
     // stride 2: 2x2 input quads per output put the depth-4 kernel at 160-190 VGPRs (2 waves): measured 0.84x;
     // depth 2 (136-144 VGPRs, 3 waves) is 1.11x the one-plane-ahead kernel on the 112x112 / 56x56 layers
+    // flat staging (cv < 0: 16-byte vectors whatever the row length)
+    if (cv == -(int)(16 / sizeof(T)) && pd == 2) {
+      if (SW == 1) return bwd_go<T, 2, 1, -(int)(16 / sizeof(T)), 2>(a, grid, bd, lds, st);
+      if (SW == 2) return bwd_go<T, 2, 2, -(int)(16 / sizeof(T)), 2>(a, grid, bd, lds, st);
+    }
     if (SW == 1 && pd == 2) { DW_PD_CV(bwd_go, T, 2, 1, 2) }
     if (SW == 2 && pd == 2) { DW_PD_CV(bwd_go, T, 2, 2, 2) }
   }
