@@ -390,7 +390,14 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
       pd_cv = -va; pd_nsv = 1;
     }
   }
-  if (pd > 1 && cv > 0 && pd_nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
+  // ... and with ragged own strips (left pad of an odd row, strips cut by the row end: 39 -> 20, 78 -> 39), 16-bit storage
+  bool pd_ragged = false;
+  if (S == 2 && sizeof(T) == 2 && pd > 1 && cv <= 0 && SW <= 2 && !(pdflat_env && atoi(pdflat_env) == 0)) {
+    if (a.g.W >= 8 && a.g.Wo >= 4 && dw_nsv_flat(a.g.RIN, a.g.W, 8, bd) <= 1 && dw_nsv_flat(a.RB, a.g.Wo, 4, bd) <= 1) {
+      pd_cv = -108; pd_nsv = 1; pd_ragged = true;
+    }
+  }
+  if (pd > 1 && (cv > 0 || pd_ragged) && pd_nsv <= 1 && (long long)f->T * f->H * f->W * (long long)sizeof(T) < (1ll << 30)) {
     if (dw_bwd_pd_launch(a, f->dtype, S, SW, pd_cv, pd, (unsigned)grid, bd, lds, st)) {
       if (x3d_describe.out) return X3D_OK;
       X3D_LAUNCH_CHECK("dw3d_bwd");

@@ -163,8 +163,15 @@ __global__ __launch_bounds__(256) void dw3d_fwd_pd_kernel(const DwFwdArgs a) {
 template <int S, int SW, int CV> struct BwdPdWaves {
   static constexpr int v = CV < 0 ? 1 : ((S == 1 && SW == 2 && CV <= 2) ? DW_S1_OCC : ((SW == 1 && CV <= 4) ? 4 : 1));
 };
-template <typename T, int S, int SW, int CV, int PD>
-__global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_kernel(const DwBwdArgs a) {
+// RO = 1 (16-bit types, flat staging): RAGGED OWN STRIPS -- the NA dA columns a thread owns may start at column -1 (TF-SAME
+// left pad of an odd row, 39 -> 20) or run past the row end (78 -> 39 with strips of 2 outputs).  The araw strip is then
+// loaded from the nearest position inside the row and moved into place with one 32/64-bit shift pair; whole strips are
+// stored as one (unaligned) vector, cut strips element by element -- every instruction unconditional, the offsets of the
+// accesses that must not happen point past the buffer.
+// (flat staging, strips of 2, 16-bit storage: 162-169 VGPRs -- held to the 168 of three waves per SIMD)
+template <typename T, int S, int SW, int CV, int PD, int RO = 0>
+__global__ __launch_bounds__(256, ((CV < 0 && SW == 2 && sizeof(T) == 2) ? 3 : BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_kernel(const DwBwdArgs a) {
+  static_assert(RO == 0 || (CV < 0 && sizeof(T) == 2), "ragged own strips: flat staging, 16-bit storage");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const DwGeom& g = a.g;
   constexpr int WIN = (SW - 1) * S + 3;          // act window columns
@@ -264,12 +271,33 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
   const int wA0 = (S == 1) ? wo0 : wo0 * 2 - g.pw;
   int oOwn[NR];
   bool okOwn[NR];
+  // ragged own strips: ws = first column actually loaded (strip moved inside the row), shr / shl = bit shifts that put
+  // column wA0 + i back at element i, cmask = bit i set when column wA0 + i exists, full = the whole strip exists
+  const int ws = RO ? (wA0 < 0 ? 0 : (wA0 + NA > g.W ? g.W - NA : wA0)) : wA0;
+  const int shr = RO ? (wA0 > ws ? 16 * (wA0 - ws) : 0) : 0, shl = RO ? (ws > wA0 ? 16 * (ws - wA0) : 0) : 0;
+  unsigned cmask = 0;
+#pragma unroll
+  for (int i = 0; i < NA; i++) if (!RO || (wA0 + i >= 0 && wA0 + i < g.W)) cmask |= 1u << i;
+  const bool full = cmask == (1u << NA) - 1;
+  int oSt[NR];   // store offset of column wA0 (element stores add 2 * i)
 #pragma unroll
   for (int q = 0; q < NR; q++) {
     const int h = hA + q;
     okOwn[q] = active && h >= 0 && h < g.H;
-    oOwn[q] = okOwn[q] ? (h * g.W + wA0) * EB : DW_OOB;
+    oOwn[q] = okOwn[q] ? (h * g.W + ws) * EB : DW_OOB;
+    oSt[q] = okOwn[q] ? (h * g.W + wA0) * EB : DW_OOB;
   }
+  auto place = [&](Raw& o) {   // loaded strip -> element i = column wA0 + i (columns that do not exist: zero bits)
+    if constexpr (RO) {
+      if constexpr (NA * EB == 8) {
+        unsigned long long v = ((unsigned long long)o.w[1] << 32) | o.w[0];
+        v = (v >> shr) << shl;
+        o.w[0] = (uint32_t)v; o.w[1] = (uint32_t)(v >> 32);
+      } else {
+        o.w[0] = (o.w[0] >> shr) << shl;
+      }
+    }
+  };
 
   struct Slot { Raw A, D, R, O[NR]; };
   Slot slot[PD];
@@ -308,13 +336,23 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
 #pragma unroll
       for (int i = 0; i < NA; i++) {
         const float av = raw_get<T>(own[q], i);
-        gv[i] = (live && okOwn[q] && sc * av + sh > 0.f) ? v[q][i] : 0.f;
+        gv[i] = (live && okOwn[q] && (!RO || ((cmask >> i) & 1)) && sc * av + sh > 0.f) ? v[q][i] : 0.f;
         s1 += gv[i];
         s2 += gv[i] * av;
       }
       Raw o;
       raw_pack<T, NA>(o, gv);
-      raw_bstore<NA * EB>(o, rsG, live ? oOwn[q] + t * iplB : DW_OOB, 0);
+      if constexpr (RO) {
+        const int base = oSt[q] + t * iplB;
+        raw_bstore<NA * EB>(o, rsG, (live && full) ? base : DW_OOB, 0);
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+          Raw e1; e1.w[0] = (o.w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+          raw_bstore<EB>(e1, rsG, (live && !full && okOwn[q] && ((cmask >> i) & 1)) ? base + EB * i : DW_OOB, 0);
+        }
+      } else {
+        raw_bstore<NA * EB>(o, rsG, live ? oOwn[q] + t * iplB : DW_OOB, 0);
+      }
     }
   };
 
@@ -324,7 +362,13 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
     issue(d, slot[d]);
     Raw z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
 #pragma unroll
-    for (int q = 0; q < NR; q++) raw_bstore<NA * EB>(z, rsG, DW_OOB, 0);
+    for (int q = 0; q < NR; q++) {
+      raw_bstore<NA * EB>(z, rsG, DW_OOB, 0);
+      if constexpr (RO) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) raw_bstore<EB>(z, rsG, DW_OOB, 0);
+      }
+    }
   }
 
   for (int t0 = 0; t0 < g.T; t0 += PD) {
@@ -351,7 +395,7 @@ __global__ __launch_bounds__(256, (BwdPdWaves<S, SW, CV>::v)) void dw3d_bwd_pd_k
       }
       Raw own0[NR];
 #pragma unroll
-      for (int q = 0; q < NR; q++) own0[q] = slot[d].O[q];
+      for (int q = 0; q < NR; q++) { own0[q] = slot[d].O[q]; place(own0[q]); }
       __syncthreads();
       issue(t + PD, slot[d]);
       if constexpr (DEFER) emit(t - 2, t >= 2, fin, own2);   // plane t-2, completed at the end of iteration t-1
@@ -768,6 +812,17 @@ static bool bwd_pd_t(const DwBwdArgs& a, int S, int SW, int cv, int pd, unsigned
   } else {
     // stride 2: 2x2 input quads per output put the depth-4 kernel at 160-190 VGPRs (2 waves): measured 0.84x;
     // depth 2 (136-144 VGPRs, 3 waves) is 1.11x the one-plane-ahead kernel on the 112x112 / 56x56 layers
+    // flat staging + ragged own strips (cv = -100 - vector width; 16-bit storage)
+    if constexpr (sizeof(T) == 2) {
+      if (cv == -108 && pd == 2) {
+        if (x3d_describe.out) {
+          snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_kernel<%s, 2, %d, -8, 2, 1>", TypeName<T>::v, SW);
+          return true;
+        }
+        if (SW == 1) { hipLaunchKernelGGL((dw3d_bwd_pd_kernel<T, 2, 1, -8, 2, 1>), dim3(grid), dim3(bd), lds, st, a); return true; }
+        if (SW == 2) { hipLaunchKernelGGL((dw3d_bwd_pd_kernel<T, 2, 2, -8, 2, 1>), dim3(grid), dim3(bd), lds, st, a); return true; }
+      }
+    }
     // flat staging (cv < 0: 16-byte vectors whatever the row length)
     if (cv == -(int)(16 / sizeof(T)) && pd == 2) {
       if (SW == 1) return bwd_go<T, 2, 1, -(int)(16 / sizeof(T)), 2>(a, grid, bd, lds, st);
