@@ -438,7 +438,8 @@ def test_dw3d_bwd(gpu, dtype, shape):
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 4, 16, 16, 24), (1, 3, 9, 11, 24), (1, 2, 20, 20, 32),
-                                   (1, 2, 18, 160, 24), (2, 3, 13, 224, 24)])   # wgrad fast path: 2 segments / row, odd H
+                                   (1, 2, 18, 160, 24), (2, 3, 13, 224, 24),    # wgrad fast path: 2 segments / row, odd H
+                                   (1, 2, 7, 312, 24), (2, 2, 6, 24, 24)])      # W % 16 == 8 (X3D-L / XL clips): half a vector at the row end
 def test_stem(gpu, dtype, shape):
     ops = _ops()
     n, t, h, w, c1 = shape

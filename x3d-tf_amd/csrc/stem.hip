@@ -182,7 +182,12 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restri
         if (co < Cout && wo0 + 8 * v < Wo) {
           const f32x4 v0 = *(const f32x4*)&myOs[co * OP + 8 * v], v1 = *(const f32x4*)&myOs[co * OP + 8 * v + 4];
           float val[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          VecIO<HT, 8>::store(y + ((((long long)n * Cout + co) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v, val);
+          HT* dst = y + ((((long long)n * Cout + co) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v;
+          if (wo0 + 8 * v + 8 <= Wo) VecIO<HT, 8>::store(dst, val);
+          else {   // Wo % 8 == 4 (W = 312): the row's last vector is half a vector
+            const float lo[4] = {val[0], val[1], val[2], val[3]};
+            VecIO<HT, 4>::store(dst, lo);
+          }
         }
       }
     }
@@ -198,7 +203,8 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   dim3 grid(ceil_div(Ho * Wo, 256), T, N);
   hipStream_t st = (hipStream_t)stream;
-  if (x3d_is_half(dtype) && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
+  // (W % 8 == 0: input rows are whole 16-byte vectors, output rows whole 8-byte ones -- W = 312 has Wo = 156 = 19.5 vectors)
+  if (x3d_is_half(dtype) && (W % 8) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
     // matrix-core path (weights rounded to bf16 like every pointwise conv): rows of x / y 16-byte aligned
     constexpr int SEGS = 4;
     const int nws = ceil_div(Wo, 64);
@@ -370,7 +376,13 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __rest
       {  // dY: this thread's vector (row, v) of segment q is item tid of the segment's 256
         const int row = tid >> 3, v = tid & 7;
         if (row < Cout && wo0 + 8 * v < Wo) {
-          rd[q] = *(const hx8*)(dy + ((((long long)n * Cout + row) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v);
+          const HT* src = dy + ((((long long)n * Cout + row) * Tn + t) * Ho + ho) * Wo + wo0 + 8 * v;
+          if (wo0 + 8 * v + 8 <= Wo) rd[q] = *(const hx8*)src;
+          else {   // Wo % 8 == 4: half a vector, the points past the row stay zero
+            const hx4 h4 = *(const hx4*)src;
+#pragma unroll
+            for (int e = 0; e < 4; e++) rd[q][e] = h4[e];
+          }
           okd[q] = true;
         }
       }
@@ -448,8 +460,8 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
   if (spb > steps_per_n) spb = (int)steps_per_n;
   const long long gx = ceil_div_ll(steps_per_n, spb) * N;
   hipStream_t st = (hipStream_t)stream;
-  if (x3d_is_half(dtype) && (W % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
-    // fast path: rows of x and dY are 16-byte aligned (W % 16 == 0 -> Wo % 8 == 0)
+  if (x3d_is_half(dtype) && (W % 8) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+    // fast path: rows of x are whole 16-byte vectors, rows of dY whole 8-byte ones (W % 8 == 0 -> Wo % 4 == 0)
     constexpr int SEGS = 4;
     const int nws = ceil_div(Wo, 64);
     const long long total_segs = (long long)N * T * Ho * nws;
