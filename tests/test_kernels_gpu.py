@@ -748,6 +748,16 @@ def test_sgd_and_layout(gpu):
         dst = torch.empty((2, 3, 3, 5, 7), dtype=dt, device=gpu)
         ops.nthwc_to_ncthw(x.to(gpu), dst)
         report("layout", dst, x.permute(0, 4, 1, 2, 3).to(dt), 0, 0)
+    # the 8-points-per-thread form (3 channels, P % 8 == 0), every source / destination storage type pair the model uses
+    x8 = torch.randn((3, 2, 6, 12, 3), generator=g_)
+    for sdt in DTYPES:
+        for dt in DTYPES:
+            if sdt != torch.float32 and dt not in (sdt, torch.float32):
+                continue
+            src = x8.to(sdt).to(gpu)
+            dst = torch.empty((3, 3, 2, 6, 12), dtype=dt, device=gpu)
+            ops.nthwc_to_ncthw(src, dst)
+            report(f"layout8 {sdt}->{dt}", dst, x8.to(sdt).permute(0, 4, 1, 2, 3).to(dt), 0, 0)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -416,25 +416,61 @@ __global__ void nthwc_to_ncthw_kernel(const TS* __restrict__ src, TD* __restrict
   for (int c = 0; c < C; c++) dst[((long long)n * C + c) * P + p] = from_f<TD>(to_f<TS>(s[c]));
 }
 
+// C = 3, P % 8 == 0, 16-byte aligned tensors (the clips of every X3D configuration): a thread takes 8 points -- 24
+// contiguous source values as three vector loads -- and writes one 8-point vector per channel plane.  The one-point form
+// above moves 2-byte pieces and is instruction bound (190 us for 64 clips of 16 x 224 x 224 against ~40 us of HBM time).
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void nthwc_to_ncthw_c3_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long P8) {
+  const int n = blockIdx.y;
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // group of 8 points
+  if (q >= P8) return;
+  float v[3][8];
+  const TS* s = src + ((long long)n * P8 + q) * 24;
+#pragma unroll
+  for (int k = 0; k < 3; k++) VecIO<TS, 8>::load(s + 8 * k, v[k]);
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = v[(3 * j + c) >> 3][(3 * j + c) & 7];
+    VecIO<TD, 8>::store(dst + ((long long)n * 3 + c) * (P8 * 8) + q * 8, o);
+  }
+}
+template <typename TS, typename TD>
+static bool nthwc_c3_fast(const void* src, void* dst, int N, int C, long long P, hipStream_t st) {
+  if (C != 3 || (P & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return false;
+  const long long P8 = P >> 3;
+  dim3 grid((unsigned)ceil_div_ll(P8, 256), (unsigned)N);
+  hipLaunchKernelGGL((nthwc_to_ncthw_c3_kernel<TS, TD>), grid, dim3(256), 0, st, (const TS*)src, (TD*)dst, P8);
+  return true;
+}
+
 extern "C" int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C,
                                   long long P, void* stream) {
   X3D_REQUIRE(src && dst && N > 0 && C > 0 && P > 0, "nthwc_to_ncthw: bad args");
   dim3 grid((unsigned)ceil_div_ll(P, 256), (unsigned)N);
   hipStream_t st = (hipStream_t)stream;
   if (src_dtype == X3D_F32 && dst_dtype == X3D_F32)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, C, P);
+    { if (!nthwc_c3_fast<float, float>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, C, P); }
   else if (src_dtype == X3D_F32 && dst_dtype == X3D_BF16)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, bf16>), grid, dim3(256), 0, st, (const float*)src, (bf16*)dst, C, P);
+    { if (!nthwc_c3_fast<float, bf16>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, bf16>), grid, dim3(256), 0, st, (const float*)src, (bf16*)dst, C, P); }
   else if (src_dtype == X3D_BF16 && dst_dtype == X3D_BF16)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)src, (bf16*)dst, C, P);
+    { if (!nthwc_c3_fast<bf16, bf16>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)src, (bf16*)dst, C, P); }
   else if (src_dtype == X3D_BF16 && dst_dtype == X3D_F32)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, st, (const bf16*)src, (float*)dst, C, P);
+    { if (!nthwc_c3_fast<bf16, float>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, st, (const bf16*)src, (float*)dst, C, P); }
   else if (src_dtype == X3D_F32 && dst_dtype == X3D_F16)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, f16>), grid, dim3(256), 0, st, (const float*)src, (f16*)dst, C, P);
+    { if (!nthwc_c3_fast<float, f16>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<float, f16>), grid, dim3(256), 0, st, (const float*)src, (f16*)dst, C, P); }
   else if (src_dtype == X3D_F16 && dst_dtype == X3D_F16)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, f16>), grid, dim3(256), 0, st, (const f16*)src, (f16*)dst, C, P);
+    { if (!nthwc_c3_fast<f16, f16>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, f16>), grid, dim3(256), 0, st, (const f16*)src, (f16*)dst, C, P); }
   else if (src_dtype == X3D_F16 && dst_dtype == X3D_F32)
-    hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, float>), grid, dim3(256), 0, st, (const f16*)src, (float*)dst, C, P);
+    { if (!nthwc_c3_fast<f16, float>(src, dst, N, C, P, st))
+      hipLaunchKernelGGL((nthwc_to_ncthw_kernel<f16, float>), grid, dim3(256), 0, st, (const f16*)src, (float*)dst, C, P); }
   else {
     x3d_set_error("nthwc_to_ncthw: bad dtype");
     return X3D_ERR_INVALID;
