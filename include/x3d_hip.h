@@ -66,11 +66,15 @@ int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, i
  * ------------------------------------------------------------------------------------------ */
 int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
                 int KT, int dtype, void* stream);
-/* backward of K2 through the stem's BN+ReLU: g = grad wrt relu(bn(y)) masked by y's sign is
- * produced by x3d_relu_bn_bwd_reduce; here dY = A*g + B*yraw + C (coef [C][4]).
+/* backward of K2 through the stem's BN+ReLU: dY = A*g + B*yraw + C (coef [C][4]), g = grad wrt relu(bn(y)) masked by
+ * the sign of bn(y).
+ *   relu_scale_shift == NULL : g is already masked (x3d_relu_bn_bwd_reduce wrote it);
+ *   relu_scale_shift [C][2]  : g is the UNMASKED gradient and the mask [s*yraw + t > 0] is applied here, on the yraw values
+ *                              the kernel loads anyway -- x3d_relu_bn_bwd_reduce then runs with g == NULL (sums only) and
+ *                              the masked gradient is never written or re-read (one tensor pass less each way).
  * dx [N][C][T][HW] = conv_t^T dY ; dw [C][KT] += */
-int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, const void* x, const float* w,
-                void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream);
+int x3d_dwt_bwd(const void* g, const void* yraw, const float* relu_scale_shift, const float* coef, const void* x,
+                const float* w, void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3  BatchNormalization(axis=-1, eps, momentum)   reference model.py:89-92,196-199,254-257,
@@ -326,7 +330,7 @@ int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const void* r_raw
 /* generic ReLU+BN backward reduce for stem / conv5: z = s*yraw + t.
  *   dy != NULL : g = dy * [z > 0]                (g may alias dy)
  *   dy == NULL : g = dpool[n][c] / P * [z > 0]   (global-average-pool backward, model.py:94,118)
- * sums [C][2] += (sum g, sum g*yraw) */
+ * sums [C][2] += (sum g, sum g*yraw).  g == NULL: sums only (the consumer applies the mask: x3d_dwt_bwd). */
 int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const void* yraw,
                            const float* scale_shift, void* g, double* sums, int N, int C,
                            long long P, int dtype, void* stream);

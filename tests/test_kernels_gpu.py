@@ -477,6 +477,26 @@ def test_stem(gpu, dtype, shape):
     torch.cuda.synchronize()
     report("dwt_dx", dx, dxs, rs, as_ * dxs.abs().max().item())
     report("dwt_dw", dwt, dwt_ref, 2e-4, 2e-4 * dwt_ref.abs().max().item())
+    # the same launch with the ReLU mask applied inside (relu_scale_shift): bit-identical to masking first, and
+    # x3d_relu_bn_bwd_reduce with g = NULL returns the same sums as the storing form
+    rss = torch.stack([1 + 0.3 * torch.randn(c1, generator=g_), 0.3 * torch.randn(c1, generator=g_)], 1).to(gpu)
+    gg = g.to(gpu)
+    gm = torch.empty_like(gg)
+    s_store = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
+    s_only = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
+    ops.relu_bn_bwd_reduce(gg, None, yt, rss, gm, s_store)
+    ops.relu_bn_bwd_reduce(gg, None, yt, rss, None, s_only)
+    dx_a, dx_b = torch.empty_like(ys), torch.empty_like(ys)
+    dw_a = torch.zeros((c1, 5), dtype=torch.float32, device=gpu)
+    dw_b = torch.zeros((c1, 5), dtype=torch.float32, device=gpu)
+    ops.dwt_bwd(gm, yt, coef.to(gpu), ys, wt.to(gpu), dx_a, dw_a)
+    ops.dwt_bwd(gg, yt, coef.to(gpu), ys, wt.to(gpu), dx_b, dw_b, relu_ss=rss)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b), "mask inside x3d_dwt_bwd differs from masking first"
+    report("dwt_dw masked", dw_b, dw_a, 1e-5, 1e-5 * dw_a.abs().max().item())
+    report("reduce-only sums", s_only, s_store, 1e-9, 1e-9 * max(1.0, s_store.abs().max().item()))
+    zmask = (rss[:, 0].view(1, -1, 1, 1, 1) * yt.float() + rss[:, 1].view(1, -1, 1, 1, 1)) > 0
+    assert torch.equal(gm, torch.where(zmask, gg, torch.zeros_like(gg)))
     dxsd = dx.float().cpu().double()
     wsr = ws.double().requires_grad_(True)
     out_s = F.conv3d(F.pad(xd, (1, 1, 1, 1, 0, 0)), wsr.unsqueeze(2), stride=(1, 2, 2))

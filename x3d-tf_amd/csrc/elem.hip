@@ -236,7 +236,7 @@ __global__ __launch_bounds__(ELEM_BLOCK) void relu_bn_bwd_reduce_kernel(const T*
         red[0] += gr;
         red[1] += gr * yr[e];
       }
-      VecIO<T, VEC>::store(g + base + p, o);
+      if (g) VecIO<T, VEC>::store(g + base + p, o);   // g == NULL: reduce only (the consumer applies the mask itself)
     }
   }
   block_sum<2>(red, scratch);
@@ -357,7 +357,7 @@ extern "C" int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const 
                                       const float* scale_shift, void* g, double* sums, int N, int C,
                                       long long P, int dtype, void* stream) {
   X3D_REQUIRE((dy != nullptr) != (dpool != nullptr), "relu_bn_bwd_reduce: exactly one of dy / dpool");
-  X3D_REQUIRE(yraw && scale_shift && g && sums && N > 0 && C > 0 && P > 0, "relu_bn_bwd_reduce: bad args");
+  X3D_REQUIRE(yraw && scale_shift && sums && N > 0 && C > 0 && P > 0, "relu_bn_bwd_reduce: bad args");
   X3D_REQUIRE(x3d_dtype_ok(dtype), "relu_bn_bwd_reduce: bad dtype");
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = norm_vec(dtype, pick_vec(eb, P, dy, yraw, g));

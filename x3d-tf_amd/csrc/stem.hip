@@ -612,6 +612,7 @@ template <typename T, int VEC> struct BufVec {
 
 template <typename T, int VEC, int KT>
 __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ yraw,
+                                                      const float* __restrict__ rss,
                                                       const float* __restrict__ coef, const T* __restrict__ x,
                                                       const float* __restrict__ w, T* __restrict__ dx, float* dw,
                                                       int C, int Tn, long long HW) {
@@ -624,6 +625,8 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, c
 #pragma unroll
   for (int k = 0; k < KT; k++) { wk[k] = w[c * KT + k]; dwk[k] = 0.f; }
   const float A = coef[c * 4], B = coef[c * 4 + 1], Cc = coef[c * 4 + 2];
+  // rss: g is the unmasked gradient, the ReLU mask [ms*yraw + mt > 0] is applied here (ms = 0, mt = 1: always on)
+  const float ms = rss ? rss[c * 2] : 0.f, mt = rss ? rss[c * 2 + 1] : 1.f;
   // one (n, c) slab of T planes per resource: < 2^30 bytes (host check)
   const long long slab = (long long)nc * Tn * HW;
   const int slab_bytes = (int)(Tn * HW * (long long)sizeof(T)), plane_bytes = (int)(HW * (long long)sizeof(T));
@@ -656,7 +659,9 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, c
     const bool in = live && tau < Tn;   // past T the loads returned zeros: dY must be 0 there, not C
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
-      dwin[KT - 1][e] = in ? A * bg.get(e) + B * by.get(e) + Cc : 0.f;
+      const float yv = by.get(e);
+      const float gv = (ms * yv + mt > 0.f) ? bg.get(e) : 0.f;
+      dwin[KT - 1][e] = in ? A * gv + B * yv + Cc : 0.f;
       xwin[KT - 1][e] = bx.get(e);
     }
     const int noff = qoff + (tau + 1) * plane_bytes;   // tau + 1 >= Tn: past the slab -> zeros, no traffic
@@ -718,10 +723,10 @@ extern "C" int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats
 }
 
 template <typename T, int VEC>
-static int dwt_bwd_kt(const void* g, const void* yraw, const float* coef, const void* x, const float* w, void* dx,
+static int dwt_bwd_kt(const void* g, const void* yraw, const float* rss, const float* coef, const void* x, const float* w, void* dx,
                       float* dw, int NC, int C, int T_, long long HW, int KT, hipStream_t st) {
   dim3 grid((unsigned)ceil_div_ll(HW, 256ll * VEC), (unsigned)NC);
-#define L(K) hipLaunchKernelGGL((dwt_bwd_kernel<T, VEC, K>), grid, dim3(256), 0, st, (const T*)g, (const T*)yraw, coef, (const T*)x, w, (T*)dx, dw, C, T_, HW)
+#define L(K) hipLaunchKernelGGL((dwt_bwd_kernel<T, VEC, K>), grid, dim3(256), 0, st, (const T*)g, (const T*)yraw, rss, coef, (const T*)x, w, (T*)dx, dw, C, T_, HW)
   switch (KT) {
     case 1: L(1); break;
     case 3: L(3); break;
@@ -734,8 +739,9 @@ static int dwt_bwd_kt(const void* g, const void* yraw, const float* coef, const 
   return X3D_OK;
 }
 
-extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, const void* x, const float* w,
-                           void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream) {
+extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* rss, const float* coef, const void* x,
+                           const float* w, void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype,
+                           void* stream) {
   X3D_REQUIRE(g && yraw && coef && x && w && dx && dw && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_bwd: bad args");
   X3D_REQUIRE(x3d_dtype_ok(dtype), "dwt_bwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
@@ -745,16 +751,16 @@ extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* coef, c
   static const char* vec_env = getenv("X3D_DWT_BWD_VEC");   // experiment hook: elements per thread (bf16: 2 or 4)
   const int want = vec_env ? atoi(vec_env) : 4;
   if (dtype == X3D_F32)
-    return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
-                    : dwt_bwd_kt<float, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                    : dwt_bwd_kt<float, 1>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
   if (dtype == X3D_F16) {
-    if (vec >= 8 && want >= 8) return dwt_bwd_kt<f16, 8>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
-    if (vec >= 4 && want >= 4) return dwt_bwd_kt<f16, 4>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
-    return vec >= 2 ? dwt_bwd_kt<f16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
-                    : dwt_bwd_kt<f16, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    if (vec >= 8 && want >= 8) return dwt_bwd_kt<f16, 8>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    if (vec >= 4 && want >= 4) return dwt_bwd_kt<f16, 4>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+    return vec >= 2 ? dwt_bwd_kt<f16, 2>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                    : dwt_bwd_kt<f16, 1>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
   }
-  if (vec >= 8 && want >= 8) return dwt_bwd_kt<bf16, 8>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
-  if (vec >= 4 && want >= 4) return dwt_bwd_kt<bf16, 4>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
-  return vec >= 2 ? dwt_bwd_kt<bf16, 2>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
-                  : dwt_bwd_kt<bf16, 1>(g, yraw, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  if (vec >= 8 && want >= 8) return dwt_bwd_kt<bf16, 8>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  if (vec >= 4 && want >= 4) return dwt_bwd_kt<bf16, 4>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
+  return vec >= 2 ? dwt_bwd_kt<bf16, 2>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
+                  : dwt_bwd_kt<bf16, 1>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
 }

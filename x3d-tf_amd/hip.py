@@ -99,7 +99,7 @@ _SIGS = {
     "x3d_stem_s_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_stem_s_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_dwt_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_stats_replicas": ([], _i),
     "x3d_stats_stride": ([_i], _ll),
     "x3d_bn_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),

@@ -872,10 +872,12 @@ class X3D:
         # ---- stem ------------------------------------------------------------------------------
         b1 = pl.bn1
         P1 = t * pl.y0.shape[3] * pl.y0.shape[4]
-        pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, dy, ("acc", b1.bsums), n, a.c1, P1, dt)
+        # sums only (g = NULL): x3d_dwt_bwd applies the ReLU mask itself on the t_raw values it loads anyway, so the masked
+        # gradient of the widest tensor of the network is neither written nor read back
+        pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
         pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b1.bsums), float(n * P1), b1.mi, p["conv1/bn/gamma"], b1.coef,
                g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
-        pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
+        pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
         pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
                a.c1, dt)

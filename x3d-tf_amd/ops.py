@@ -98,10 +98,11 @@ def dwt_fwd(x, w, y=None, stats=None):
     return y
 
 
-def dwt_bwd(g, yraw, coef, x, w, dx, dw):
-    _chk(g, yraw, coef, x, w, dx, dw)
+def dwt_bwd(g, yraw, coef, x, w, dx, dw, relu_ss=None):
+    """relu_ss [C][2]: g is the unmasked gradient, the ReLU mask of bn(yraw) is applied inside the kernel."""
+    _chk(g, yraw, coef, x, w, dx, dw, relu_ss)
     n, c, t, h, ww = x.shape
-    hip.call("x3d_dwt_bwd", ptr(g), ptr(yraw), ptr(coef), ptr(x), ptr(w), ptr(dx), ptr(dw), n, c, t,
+    hip.call("x3d_dwt_bwd", ptr(g), ptr(yraw), ptr(relu_ss), ptr(coef), ptr(x), ptr(w), ptr(dx), ptr(dw), n, c, t,
              h * ww, w.shape[1], hip.dtype_code(x.dtype))
 
 
