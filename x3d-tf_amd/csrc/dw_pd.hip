@@ -776,7 +776,10 @@ static bool bwd_go(const DwBwdArgs& a, unsigned grid, int bd, size_t lds, hipStr
       return true;
     }
   }
-  DW_PD_DESCRIBE("bwd")
+  if (x3d_describe.out) {   // the name rocprofv3 prints: all six template arguments (RO = 0)
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_kernel<%s, %d, %d, %d, %d, 0>", TypeName<T>::v, S, SW, CV, PD);
+    return true;
+  }
   hipLaunchKernelGGL((dw3d_bwd_pd_kernel<T, S, SW, CV, PD>), dim3(grid), dim3(bd), lds, st, a);
   return true;
 }
