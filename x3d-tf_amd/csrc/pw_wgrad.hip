@@ -14,6 +14,7 @@ struct PwWgradArgs {
   int mt_per_group;     // 32-row tiles of Cout handled by one blockIdx.y
   int nt_total;         // 32-col tiles of Cin
   int steps_per_block;  // 32-point steps per block
+  int noflush;          // X3D_PW_WG_NOFLUSH=1 (timing experiment only: the partial tiles are NOT added to dw)
 };
 
 #include "pw_wgrad_bf16.h"

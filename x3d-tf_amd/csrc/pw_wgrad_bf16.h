@@ -200,20 +200,28 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
 //  * strided shortcut (1x1x1, stride (1,2,2), valid): an output row segment of 8 points is the even
 //    elements of 16 contiguous input elements -> two 16-byte loads, no scalar gather.
 // ================================================================================================
-template <typename H, int MG, int NG, bool XPRO, int STRIDED>
-__global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
+//  * NTHR = 512 (round 2, the stage-5 layers 192 <-> 432): eight waves own up to 7 x 6 tiles, i.e. ALL of the narrower
+//    operand and half of the wider one.  The run time of the 4-wave form follows the number of staged rows (4x2 tiles:
+//    3552 rows, 100 us; 4x3: 2496 rows, 65 us); 7x6 / 6x7 stage 1248 / 1200.  Threads 256..511 stage the odd 32-row tiles.
+template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
   // U sub-steps of 64 points are staged and multiplied per barrier pair: half the barriers and twice the loads in
   // flight per thread (a 64-point step is ~400 instructions between two barriers: the waves mostly wait)
-  constexpr int BP = 64, U = 2, LP = U * BP + 8;
-  constexpr int TPW = (MG * NG + 3) / 4;
+  constexpr int BP = 64, U = NTHR == 512 ? 1 : 2, LP = U * BP + 8;   // (eight waves, 42 tiles: one sub-step's registers)
+  constexpr int NW = NTHR / 64;                      // waves
+  constexpr int NTS = NTHR / 256;                    // 32-row tiles staged side by side (thread group tsel takes tiles tsel, tsel + NTS, ...)
+  constexpr int MGS = (MG + NTS - 1) / NTS, NGS = (NG + NTS - 1) / NTS;
+  constexpr int TPW = (MG * NG + NW - 1) / NW;
+  static_assert(NTHR == 256 || TPW > 1, "the split-K sharing of one or two tiles is written for four waves");
   H* As = (H*)smem_raw;              // [MG*32][LP]  dYraw
   H* Bs = As + MG * 32 * LP;            // [NG*32][LP]  f(X)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int srow = tid >> 3, sp = (tid & 7) * 8;       // staging row within a 32-row tile, first point
+  const int srow = (tid >> 3) & 31, sp = (tid & 7) * 8;       // staging row within a 32-row tile, first point
+  const int tsel = tid >> 8;                                  // which of the NTS side-by-side tiles this thread stages
   const int co0 = blockIdx.y * MG * 32, ci0 = blockIdx.z * NG * 32;
   const int steps_per_n = (int)((a.P + BP - 1) / BP);
   const int total_steps = steps_per_n * a.N;
@@ -230,24 +238,24 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
 
-  hx8 rg[U][MG], ry[U][MG], rx[U][NG], rx2[U][STRIDED ? NG : 1];
+  hx8 rg[U][MGS], ry[U][MGS], rx[U][NGS], rx2[U][STRIDED ? NGS : 1];
   // per-row coefficients are loop invariants of this thread (rows co0 + i*32 + srow / ci0 + i*32 + srow): loaded
   // once here instead of from global inside every step's prologue (an exposed L2 round trip per 64-point step);
   // only the SE gate depends on the sample and is re-read when the step crosses into the next sample
-  float cA[MG], cB[MG], cC[MG], xs_[XPRO ? NG : 1], xt_[XPRO ? NG : 1], xg_[XPRO ? NG : 1];
+  float cA[MGS], cB[MGS], cC[MGS], xs_[XPRO ? NGS : 1], xt_[XPRO ? NGS : 1], xg_[XPRO ? NGS : 1];
 #pragma unroll
-  for (int i = 0; i < MG; i++) {
-    const int co = co0 + i * 32 + srow;
-    const bool ok = a.coef && co < a.Cout;
+  for (int i = 0; i < MGS; i++) {
+    const int co = co0 + (i * NTS + tsel) * 32 + srow;
+    const bool ok = a.coef && co < a.Cout && i * NTS + tsel < MG;
     cA[i] = ok ? a.coef[co * 4] : 1.f; cB[i] = ok ? a.coef[co * 4 + 1] : 0.f; cC[i] = ok ? a.coef[co * 4 + 2] : 0.f;
   }
   int n_gate = -1;
   auto load_gate = [&](int n) {
     if constexpr (XPRO) {
 #pragma unroll
-      for (int i = 0; i < NG; i++) {
-        const int ci = ci0 + i * 32 + srow;
-        const bool inb = ci < a.Cin;
+      for (int i = 0; i < NGS; i++) {
+        const int ci = ci0 + (i * NTS + tsel) * 32 + srow;
+        const bool inb = ci < a.Cin && i * NTS + tsel < NG;
         xs_[i] = inb ? a.xcoef[ci * 2] : 0.f; xt_[i] = inb ? a.xcoef[ci * 2 + 1] : 0.f;
         xg_[i] = (inb && a.xgate) ? a.xgate[(long long)n * a.Cin + ci] : 1.0f;
       }
@@ -262,21 +270,21 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
 #pragma unroll
     for (int e = 0; e < 8; e++) z[e] = (H)0.f;
 #pragma unroll
-    for (int i = 0; i < MG; i++) {
-      const int co = co0 + i * 32 + srow;
+    for (int i = 0; i < MGS; i++) {
+      const int co = co0 + (i * NTS + tsel) * 32 + srow;
       rg[u][i] = z; ry[u][i] = z;
-      if (co < a.Cout && p < a.P) {
+      if (i * NTS + tsel < MG && co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
         rg[u][i] = *(const hx8*)((const T*)a.g + o);
         if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NG; i++) {
-      const int ci = ci0 + i * 32 + srow;
+    for (int i = 0; i < NGS; i++) {
+      const int ci = ci0 + (i * NTS + tsel) * 32 + srow;
       rx[u][i] = z;
       if constexpr (STRIDED) rx2[u][i] = z;
-      if (ci < a.Cin && p < a.P) {
+      if (i * NTS + tsel < NG && ci < a.Cin && p < a.P) {
         if constexpr (STRIDED) {
           // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
           strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
@@ -288,9 +296,11 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
   };
   auto commit = [&](int u, int n, int stp, bool live) {
 #pragma unroll
-    for (int i = 0; i < MG; i++) {
-      const int co = co0 + i * 32 + srow;
-      H* dst = &As[(i * 32 + srow) * LP + u * BP + sp];
+    for (int i = 0; i < MGS; i++) {
+      const int ti = i * NTS + tsel;
+      if (ti >= MG) continue;
+      const int co = co0 + ti * 32 + srow;
+      H* dst = &As[(ti * 32 + srow) * LP + u * BP + sp];
       if (a.coef && co < a.Cout) {
         const float A = cA[i], B = cB[i], C = cC[i];
         float v[8];
@@ -307,9 +317,11 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
       }
     }
 #pragma unroll
-    for (int i = 0; i < NG; i++) {
-      const int ci = ci0 + i * 32 + srow;
-      H* dst = &Bs[(i * 32 + srow) * LP + u * BP + sp];
+    for (int i = 0; i < NGS; i++) {
+      const int ti = i * NTS + tsel;
+      if (ti >= NG) continue;
+      const int ci = ci0 + ti * 32 + srow;
+      H* dst = &Bs[(ti * 32 + srow) * LP + u * BP + sp];
       if constexpr (STRIDED) {
         hx8 o;
 #pragma unroll
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
     for (int u = 0; u < U; u++) { n_c[u] = n_i[u]; stp_c[u] = stp_i[u]; }
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
-      int id = wid + 4 * s, kpart = 0;
+      int id = wid + NW * s, kpart = 0;
       if (nks > 1) { id = wid % ntiles; kpart = wid / ntiles; }
       if (id < ntiles) {
         const int mt = id / nt_here, nt = id - mt * nt_here;
@@ -407,10 +419,10 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
   }
 #pragma unroll
   for (int s = 0; s < TPW; s++) {
-    int id = wid + 4 * s;
+    int id = wid + NW * s;
     bool writer = true;
     if (nks > 1) { id = wid % ntiles; writer = wid < ntiles; }
-    if (id < ntiles && s_begin < s_end && writer) {
+    if (id < ntiles && s_begin < s_end && writer && !a.noflush) {
       const int mt = id / nt_here, nt = id - mt * nt_here;
       const int ci = ci0 + nt * 32 + r;
 #pragma unroll
@@ -422,15 +434,15 @@ __global__ __launch_bounds__(256, (MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void p
   }
 }
 
-template <typename H, int MG, int NG, bool XPRO, int STRIDED>
+template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256>
 static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
   const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
-  const size_t lds = (size_t)(MG + NG) * 32 * (2 * 64 + 8) * 2;
-  X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED);
-  auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED>;
+  const size_t lds = (size_t)(MG + NG) * 32 * ((NTHR == 512 ? 1 : 2) * 64 + 8) * 2;
+  X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED, NTHR);
+  auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED, NTHR>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -445,7 +457,7 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
     int nb = 0, dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NTHR, lds) != hipSuccess || nb < 1) nb = NTHR == 256 ? 2 : 1;
     slots = nb * cus;
   }
   long long gx_target = slots / (gy * gz);
@@ -461,9 +473,11 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
   if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
   a.steps_per_block = (int)spb;
+  static const char* nf_env = getenv("X3D_PW_WG_NOFLUSH");   // timing experiment: how much of the run time is the atomic flush
+  a.noflush = (nf_env && atoi(nf_env) == 1) ? 1 : 0;
   long long gx = ceil_div_ll(total_steps, spb);
   if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(NTHR), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
   return X3D_OK;
 }
@@ -473,6 +487,18 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   // X rows may carry the swish prologue: prefer few M-groups (each re-stages every X row of its N-group)
   const int MG = mt >= 3 ? 4 : mt, NG = nt >= 2 ? 2 : 1;
+  if constexpr (STRIDED == 0) {
+    // experiment hook X3D_PW_WG_WIDE=1, the stage-5 pair (192 <-> 432 channels: 6 x 14 / 14 x 6 tiles): eight-wave
+    // workgroups that hold the whole narrow side and half of the wide one -- half the staged rows of the 12-tile groups.
+    // Measured (tools/ab_wgrad5.sh, X3D_PW_WG_NOFLUSH=1 for the split): the streaming part gets faster (52 -> 38 us,
+    // 37 -> 31 us) but one workgroup per CU means 104 point chunks instead of 56, and the fp32 atomic flush -- 35 MB
+    // instead of 19 MB -- grows from 14 to 25-28 us: 64 vs 66 us and 59 vs 52 us in total, so the 12-tile groups stay.
+    static const char* ew = getenv("X3D_PW_WG_WIDE");
+    if (ew && atoi(ew) == 1) {
+      if (nt >= 4 && nt <= 6 && mt >= 10 && mt <= 14) return pw_wgrad_v2_launch<H, 7, 6, XPRO, STRIDED, 512>(a, st);
+      if (mt >= 4 && mt <= 6 && nt >= 10 && nt <= 14) return pw_wgrad_v2_launch<H, 6, 7, XPRO, STRIDED, 512>(a, st);
+    }
+  }
   if constexpr (STRIDED == 0) {
     // experiment hook X3D_PW_WG_NG4=1: 128 x 128 tiles for the wide layers (stage 5: 192 x 432) halve the re-reads of
     // every dY / X row by the other tile groups, but need 232-252 VGPRs + 64 AGPRs (one workgroup per CU):
