@@ -45,9 +45,10 @@ struct PwGemmArgs {
   int eH, eW;          // EPI_ADD_STRIDED: geometry of dx (H, W); add is at ceil(H/2) x ceil(W/2)
 };
 
+// ck: this row's prologue coefficients from the workgroup's LDS table (PRO_AFFINE: {s*g, t*g}; PRO_BNBWD: {A, B, C})
 template <typename T, int VEC, int PRO, bool STRIDED>
 __device__ __forceinline__ void pw_load_vec(const PwGemmArgs& a, int n, int gk, long long p,
-                                            float (&v)[VEC]) {
+                                            const float* ck, float (&v)[VEC]) {
   const T* x = (const T*)a.x;
   if constexpr (STRIDED) {
     static_assert(VEC == 1, "strided gather is scalar");
@@ -61,15 +62,14 @@ __device__ __forceinline__ void pw_load_vec(const PwGemmArgs& a, int n, int gk, 
     VecIO<T, VEC>::load(x + ((long long)n * a.K + gk) * a.Pin + p, v);
   }
   if constexpr (PRO == PRO_AFFINE) {
-    float s = a.coef[gk * 2], t = a.coef[gk * 2 + 1];
-    float g = a.gate ? a.gate[(long long)n * a.K + gk] : 1.0f;
+    const float s = ck[0], t = ck[1], g = ck[2];
 #pragma unroll
     for (int e = 0; e < VEC; e++) v[e] = (s * v[e] + t) * g;
     act_vec<VEC>(v, a.act);
   } else if constexpr (PRO == PRO_BNBWD) {
     float y2[VEC];
     VecIO<T, VEC>::load((const T*)a.x2 + ((long long)n * a.K + gk) * a.Pin + p, y2);
-    float A = a.coef[gk * 4], B = a.coef[gk * 4 + 1], C = a.coef[gk * 4 + 2];
+    const float A = ck[0], B = ck[1], C = ck[2];
 #pragma unroll
     for (int e = 0; e < VEC; e++) v[e] = A * v[e] + B * y2[e] + C;
   }
@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
   constexpr int BMP = BM + 1;      // odd W pitch: staging along k (stride BMP) is bank-conflict-free
   float* Xs = smem;                // [KC][BN]   (16-B aligned for the vector stores)
   float* Ws = smem + a.KC * BN;    // [KC][BMP]
+  // per-row coefficients as LDS tables, filled once per workgroup (chunk): read from global inside the staging loop
+  // and the epilogue they were 3 dependent L2 round trips per vector / per output element
+  float* Pk = Ws + a.KC * BMP;     // [KC][4]  prologue rows (PRO_AFFINE / PRO_BNBWD)
+  float* Em = Pk + a.KC * 4;       // [BM][4]  epilogue rows (SWISH_BWD: {s_b, t_b, gate})
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
       long long p = p0 + (long long)pv * VEC;
       float val[VEC];
       if (gk < a.K && p < a.P) {
-        pw_load_vec<T, VEC, PRO, STRIDED>(a, n, gk, p, val);
+        pw_load_vec<T, VEC, PRO, STRIDED>(a, n, gk, p, Pk + k * 4, val);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; e++) val[e] = 0.f;
@@ -131,7 +135,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
     }
   };
 
-  if (a.nchunks == 1) stage_w(0);
+  auto fill_pk = [&](int k0) {
+    if constexpr (PRO != PRO_NONE) {
+      for (int k = tid; k < a.KC; k += 256) {
+        const int gk = k0 + k;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (gk < a.K) {
+          if constexpr (PRO == PRO_AFFINE) {
+            c0 = a.coef[gk * 2]; c1 = a.coef[gk * 2 + 1];
+            c2 = a.gate ? a.gate[(long long)n * a.K + gk] : 1.0f;
+          } else {
+            c0 = a.coef[gk * 4]; c1 = a.coef[gk * 4 + 1]; c2 = a.coef[gk * 4 + 2];
+          }
+        }
+        Pk[k * 4] = c0; Pk[k * 4 + 1] = c1; Pk[k * 4 + 2] = c2;
+      }
+    }
+  };
+  if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+    for (int m = tid; m < BM; m += 256) {
+      const int gm = m0 + m;
+      const bool ok = gm < a.M;
+      Em[m * 4] = ok ? a.b_ss[gm * 2] : 0.f;
+      Em[m * 4 + 1] = ok ? a.b_ss[gm * 2 + 1] : 0.f;
+      Em[m * 4 + 2] = (ok && a.egate) ? a.egate[(long long)n * a.M + gm] : 1.0f;
+    }
+  }
+  if (a.nchunks == 1) { stage_w(0); fill_pk(0); __syncthreads(); }
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const long long p0 = (long long)tile * BN;
@@ -143,7 +173,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
     for (int kc = 0; kc < a.nchunks; ++kc) {
       const int k0 = kc * a.KC;
       __syncthreads();  // every wave is done reading the previous tiles
-      if (a.nchunks > 1) stage_w(k0);
+      if (a.nchunks > 1) {
+        stage_w(k0);
+        if constexpr (PRO != PRO_NONE) { fill_pk(k0); __syncthreads(); }
+      }
       stage_x(k0, p0);
       __syncthreads();
 #pragma unroll
@@ -202,8 +235,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
             if (ok) {
               const float b = to_f<T>(((const T*)a.braw)[o]);
-              const float u = a.b_ss[m * 2] * b + a.b_ss[m * 2 + 1];
-              const float g = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+              const float* em = Em + (m - m0) * 4;
+              const float u = em[0] * b + em[1];
+              const float g = em[2];
               const float dv = val * swish_grad_(u * g);
               ((T*)a.y)[o] = from_f<T>(dv);
               const float dvr = round_to<T>(dv);
@@ -253,7 +287,7 @@ template <typename T, int VEC, int MT, int NT, int PRO, int EPI, bool STRIDED>
 static int pw_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, BN = NT * 32;
   const int Kpad = (a.K + 1) & ~1;
-  const size_t resident = (size_t)Kpad * (BM + 1 + BN) * sizeof(float);
+  const size_t resident = (size_t)Kpad * (BM + 1 + BN + 4) * sizeof(float) + (size_t)BM * 16;
   if (resident <= 80 * 1024) {
     a.KC = Kpad;
     a.nchunks = 1;
@@ -261,16 +295,10 @@ static int pw_launch_cfg(PwGemmArgs& a, hipStream_t st) {
     a.KC = 64;
     a.nchunks = ceil_div(a.K, 64);
   }
-  const size_t lds = (size_t)a.KC * (BM + 1 + BN) * sizeof(float);
+  const size_t lds = (size_t)a.KC * (BM + 1 + BN + 4) * sizeof(float) + (size_t)BM * 16;
   const int gy = ceil_div(a.M, BM);
   const long long tiles_per_n = ceil_div_ll(a.P, BN);
   const long long total = tiles_per_n * a.N * gy;
-  int tpb = (int)(total / 2048);
-  if (tpb < 1) tpb = 1;
-  if (tpb > 16) tpb = 16;
-  if (tpb > tiles_per_n) tpb = (int)tiles_per_n;
-  a.tiles_per_block = tpb;
-  const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
   X3D_DESCRIBE("pw_gemm_kernel<float, %d, %d, %d, %d, %d, %d>", VEC, MT, NT, PRO, EPI, (int)STRIDED);
   auto kern = pw_gemm_kernel<T, VEC, MT, NT, PRO, EPI, STRIDED>;
   if (lds > 48 * 1024) {
@@ -280,6 +308,26 @@ static int pw_launch_cfg(PwGemmArgs& a, hipStream_t st) {
       attr_set = true;
     }
   }
+  // one round of workgroups: every workgroup stages the whole weight panel (tens of KB) before its first tile, so a
+  // layer with few points per sample (1344 one-tile workgroups on 512 slots) spent more on weights than on activations
+  static size_t occ_lds[4];
+  static int occ_slots[4], occ_n = 0;
+  int slots = 0;
+  for (int i = 0; i < occ_n; i++) if (occ_lds[i] == lds) slots = occ_slots[i];
+  if (slots == 0) {
+    int nb = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    slots = nb * cus;
+    if (occ_n < 4) { occ_lds[occ_n] = lds; occ_slots[occ_n] = slots; occ_n++; }
+  }
+  long long tpb = ceil_div_ll(total, slots);
+  if (tpb < 1) tpb = 1;
+  if (tpb > 16) tpb = 16;
+  if (tpb > tiles_per_n) tpb = tiles_per_n;
+  a.tiles_per_block = (int)tpb;
+  const long long gx = ceil_div_ll(tiles_per_n, tpb) * a.N;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm");
   return X3D_OK;
