@@ -21,6 +21,31 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 // 16-bit storage types (X3D_BF16 / X3D_F16): vector types, the matrix-core instruction and the name used in kernel
 // descriptions.  Every 16-bit kernel is a template over H; arithmetic around the matrix cores is fp32 either way.
+// 16-bit storage, point counts that are not a multiple of 8 (X3D-S: 13 frames -> 1300 / 325 points per sample in stages
+// 4 / 5; X3D-XS: 100): rows then start at any 2-byte address and end inside their last 8-point vector.  The vector form of
+// the resident-panel kernel (pw_gemm_bf16.h) takes them all the same: unaligned 16-byte accesses for the whole vectors,
+// element accesses for a row's last one, sums masked by element (the scalar form it used to fall back to ran the
+// 216 -> 96 @ 13x10x10 layer in 311 us).  X3D_PW_RAGGED=0: A/B hook.
+static inline bool pw_ragged_rows(long long P, int dtype_bytes) {
+  static const char* e = getenv("X3D_PW_RAGGED");
+  return dtype_bytes == 2 && (P & 7) != 0 && P >= 8 && !(e && atoi(e) == 0);
+}
+
+// 8 elements of a row of which only the first nv exist (the row -- P % 8 != 0 points -- ends inside the vector): element
+// accesses, zero fill.  The whole vectors of such rows start at any 2-byte address; the compute queues run in unaligned
+// access mode, so the 16-byte loads / stores stay (checked on the GPU by the odd-point-count parity cases).
+template <typename H, typename V8> __device__ __forceinline__ V8 load8_ragged(const H* p, int nv) {
+  V8 v;
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (H)0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) if (e < nv) v[e] = p[e];
+  return v;
+}
+template <typename H, typename V8> __device__ __forceinline__ void store8_ragged(H* p, const V8& v, int nv) {
+#pragma unroll
+  for (int e = 0; e < 8; e++) if (e < nv) p[e] = v[e];
+}
 template <typename H> struct HV;
 template <> struct HV<bf16> {
   typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2;

@@ -14,8 +14,8 @@ static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
 }
 
 template <typename H>
-static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int vec, hipStream_t st) {
-  const int ovec = pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
+static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int vec, hipStream_t st, int force_ovec = 0) {
+  const int ovec = force_ovec ? force_ovec : pick_vec(eb, a.P, d->dx, d->epi == X3D_EPI_ADD ? d->add : nullptr, d->braw);
   // stage 5: weights stationary.  The stage-4 shapes stay with the resident-panel kernel here: with two staged tensors
   // the stationary kernel needs 132-146 VGPRs = one workgroup per CU (216 -> 96 dgrad: 58 -> 61 us)
   // (strided shortcut gradient: even image width only -- pairs of points never straddle a row)
@@ -63,7 +63,8 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   a.w = d->w; a.wsk = d->Cin; a.wsm = 1;  // (k = co, m = ci) -> w[co*Cin + ci]
   a.N = d->N; a.K = d->Cout; a.M = d->Cin;
   a.stride = 1;
-  a.P = a.Pin = (long long)d->T * d->H * d->W;
+  a.P = a.Pin = a.Pp = (long long)d->T * d->H * d->W;
+  a.p0 = 0;
   X3D_REQUIRE(a.Pin < (1ll << 31) && a.P < (1ll << 31), "pw_dgrad: more than 2^31 points per sample");   // 32-bit point indices in the kernels
   a.y = d->dx; a.add = d->add; a.braw = d->braw; a.b_ss = d->b_scale_shift; a.egate = d->gate;
   a.nc_sums = d->nc_sums; a.eH = d->H; a.eW = d->W;
@@ -72,6 +73,10 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   const int vec = pick_vec(eb, a.P, d->g, d->yraw);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == X3D_F32) return pw_dgrad_dispatch<float>(a, d->epi, vec, st);
+  const bool al16 = (((uintptr_t)d->g | (uintptr_t)d->yraw | (uintptr_t)d->dx | (uintptr_t)d->braw |
+                      (d->epi == X3D_EPI_ADD ? (uintptr_t)d->add : 0)) % 16) == 0;
+  if (al16 && pw_ragged_rows(a.P, eb))   // P % 8 != 0: the vector form with ragged row ends (pw_gemm.h)
+    return d->dtype == X3D_F16 ? pw_dgrad_h16<f16>(a, d, eb, 8, st, 8) : pw_dgrad_h16<bf16>(a, d, eb, 8, st, 8);
   return d->dtype == X3D_F16 ? pw_dgrad_h16<f16>(a, d, eb, vec, st) : pw_dgrad_h16<bf16>(a, d, eb, vec, st);
 }
 

@@ -29,6 +29,7 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   a.Ho = ceil_div(f->H, f->stride); a.Wo = ceil_div(f->W, f->stride);
   a.Pin = (long long)f->T * f->H * f->W;
   a.P = (long long)f->T * a.Ho * a.Wo;
+  a.Pp = a.P; a.p0 = 0;
   X3D_REQUIRE(a.Pin < (1ll << 31) && a.P < (1ll << 31), "pw_fwd: more than 2^31 points per sample");   // 32-bit point indices in the kernels
   a.y = f->y; a.stats = f->stats;
   a.wp = f->w_panel; a.wp_rows = (f->Cout + 31) & ~31;
@@ -41,7 +42,10 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
   // 16-bit storage: bf16 / f16 matrix cores (fp32 accumulate)
-  const int ovec = pick_vec(eb, a.P, f->y);
+  int ovec = pick_vec(eb, a.P, f->y);
+  int vec16 = vec;
+  if (f->stride == 1 && ((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) vec16 = ovec = 8;
+  if (vec16 != vec) return f->dtype == X3D_F16 ? pw_fwd_h16<f16>(a, vec16, ovec, pro, st) : pw_fwd_h16<bf16>(a, vec16, ovec, pro, st);
   return f->dtype == X3D_F16 ? pw_fwd_h16<f16>(a, vec, ovec, pro, st) : pw_fwd_h16<bf16>(a, vec, ovec, pro, st);
 }
 

@@ -166,8 +166,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           } else {
             // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
             const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
-            xr[i] = *(const hx8*)((const T*)a.x + o);
-            if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
+            const long long left = a.P - p;          // P % 8 != 0: the row may end inside its last vector
+            if (left >= 8) {
+              xr[i] = *(const hx8*)((const T*)a.x + o);
+              if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
+            } else {
+              xr[i] = load8_ragged<T, hx8>((const T*)a.x + o, (int)left);
+              if constexpr (PRO == PRO_BNBWD) yr[i] = load8_ragged<T, hx8>((const T*)a.x2 + o, (int)left);
+            }
           }
         }
       } else {
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     const int oc = (tid & 15) * 8;
     __amdgpu_buffer_rsrc_t yrsrc;
     if constexpr (BSTORE)
-      yrsrc = __builtin_amdgcn_make_buffer_rsrc((T*)a.y + (long long)n * a.M * a.P, 0, (int)((long long)a.M * a.P * 2), 0x00020000);
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc((T*)a.y + (long long)n * a.M * a.Pp, 0, (int)((long long)a.M * a.Pp * 2), 0x00020000);
     // Every global load of the epilogue is issued HERE, before any store of this tile.  vmcnt retires in order
     // (stores included) and the compiler must assume vmcnt(0) around the conditional stores, so a load issued
     // after a store would wait for that store's write latency (once per row), and the first use of the next
@@ -376,8 +382,10 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
           if (m < a.M && p < a.P) {
-            const long long o = ((long long)n * a.M + m) * a.P + p;
-            epl8[i] = *(const hx8*)((const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o);
+            const long long o = ((long long)n * a.M + m) * a.Pp + p;
+            const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o;
+            if (a.P - p >= 8) epl8[i] = *(const hx8*)src;
+            else epl8[i] = load8_ragged<T, hx8>(src, (int)(a.P - p));
           }
         } else {
 #pragma unroll
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           if (epl4_vec && m < a.M && p < a.P) {
             const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-            const int T_ = (int)a.P / hw;
+            const int T_ = (int)a.Pp / hw;
             const T* abase = (const T*)a.add + ((long long)n * a.M + m) * T_ * Hh * Wh;
             if (egv == 8) {
               // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
               for (int gq = 0; gq < 2; gq++) {
                 const int pe = (int)p + 4 * gq;
+                if (pe >= (int)a.P) continue;
                 const int t = pe / hw;
                 const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
               for (int gq = 0; gq < 4; gq++) {
                 const int pe = (int)p + 2 * gq;
+                if (pe >= (int)a.P) continue;
                 const int t = pe / hw;
                 const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
@@ -447,8 +457,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
       }
-      const long long o = ((long long)n * a.M + m) * a.P + p;
-      const int nvalid = (OVEC == 8) ? 8 : (int)min((long long)8, a.P - p);
+      const long long o = ((long long)n * a.M + m) * a.Pp + p;
+      const int nvalid = (int)min((long long)8, a.P - p);   // < 8: the row ends inside this vector (P % 8 != 0)
       if constexpr (EPI == X3D_EPI_ADD) {
         if constexpr (OVEC == 8) {
 #pragma unroll
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
         const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-        const int T_ = (int)a.P / hw;
+        const int T_ = (int)a.Pp / hw;
         if (epl4_vec) {
           if constexpr (EPL4) {   // loaded above (zeros on odd rows)
 #pragma unroll
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           }
         } else
         for (int e = 0; e < nvalid; e++) {
-          const int pe = (int)p + e;
+          const int pe = (int)p + a.p0 + e;
           const int t = pe / hw;
           const int rem = pe - t * hw;
           const int h = rem / a.eW, w = rem - h * a.eW;
@@ -509,10 +519,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) ov[e] = (H)val[e];
         // byte offset inside sample n's [M][P] matrix; 0x80000000 is past num_records -> the store is discarded
-        const unsigned off = rvalid ? (unsigned)(((long long)m * a.P + p) * 2) : 0x80000000u;
+        const unsigned off = (rvalid && nvalid == 8) ? (unsigned)(((long long)m * a.Pp + p) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), yrsrc, off, 0, 0);
+        if (rvalid && nvalid < 8) store8_ragged<T, hx8>((T*)a.y + o, ov, nvalid);
       } else if constexpr (OVEC == 8) {
-        VecIO<T, 8>::store((T*)a.y + o, val);
+        if (nvalid == 8) VecIO<T, 8>::store((T*)a.y + o, val);
+        else {
+          for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
+        }
       } else {
         for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
       }
@@ -565,7 +579,7 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
-  X3D_REQUIRE((long long)a.M * a.P * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
+  X3D_REQUIRE((long long)a.M * a.Pp * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
   X3D_DESCRIBE("pw_gemm_bf16_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, VEC, MT, PRO, EPI, STRIDED, OVEC);
   auto kern = pw_gemm_bf16_kernel<H, VEC, MT, PRO, EPI, STRIDED, OVEC>;
   if (lds > 48 * 1024) {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const int k = v >> 2;
       const long long p = p0 + (v & 3) * 8;
       const bool ok = k < a.K && p < a.P;
-      const long long o = ok ? ((long long)n * a.K + k) * a.P + p : 0;
+      const long long o = ok ? ((long long)n * a.K + k) * a.Pin + p : 0;
       xr[i] = *(const hx8*)((const T*)a.x + o);
       if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
     }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
       // dx [eH x eW] receives `add` [ceil(eH/2) x ceil(eW/2)] on its even pixels.  eW is even (dispatch): the 8 points of
       // a vector are four pairs inside one image row each, the first of a pair on an even column.  32-bit index maths.
-      const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.P / hw;
+      const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.Pp / hw;
 #pragma unroll
       for (int j = 0; j < RB; j++) {
         const int m = (wid + NW * j) * 32 + row;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
-          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.P + p : 0;
+          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.Pp + p : 0;
           eo[j][hv] = *(const hx8*)(src + o);
         }
       }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           if (p >= a.P) continue;                       // P % 8 == 0: a vector of 8 points is inside or outside
-          const long long o = ((long long)n * a.M + m) * a.P + p;
+          const long long o = ((long long)n * a.M + m) * a.Pp + p;
           float val[8];
           {
             const f32x4 v0 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv], v1 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv + 4];

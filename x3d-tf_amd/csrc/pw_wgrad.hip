@@ -15,6 +15,7 @@ struct PwWgradArgs {
   int nt_total;         // 32-col tiles of Cin
   int steps_per_block;  // 32-point steps per block
   int noflush;          // X3D_PW_WG_NOFLUSH=1 (timing experiment only: the partial tiles are NOT added to dw)
+  int ragged;           // 16-bit storage, P % 8 != 0, stride 1: the vector kernel with ragged row ends (pw_gemm.h)
 };
 
 #include "pw_wgrad_bf16.h"
@@ -205,6 +206,8 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(xpro || (!w->in_gate && w->in_act == X3D_ACT_NONE), "pw_wgrad: prologue needs in_scale_shift");
   const int eb = w->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, w->g, w->yraw, w->x);
+  a.ragged = (w->stride == 1 && pw_ragged_rows(a.P, eb) &&
+              (((uintptr_t)w->g | (uintptr_t)w->yraw | (uintptr_t)w->x) % 16) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (w->dtype == X3D_F32) return pw_wgrad_dispatch<float>(a, vec, xpro, st);
   // bf16 storage: bf16 matrix cores; v2 = aligned fast path, v1 = generic (odd point counts / widths)

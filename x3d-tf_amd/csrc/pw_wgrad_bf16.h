@@ -275,8 +275,13 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
       rg[u][i] = z; ry[u][i] = z;
       if (i * NTS + tsel < MG && co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
-        rg[u][i] = *(const hx8*)((const T*)a.g + o);
-        if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
+        if (a.P - p >= 8) {
+          rg[u][i] = *(const hx8*)((const T*)a.g + o);
+          if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
+        } else {   // P % 8 != 0: the row ends inside this vector (zero fill: points are the reduction dimension)
+          rg[u][i] = load8_ragged<T, hx8>((const T*)a.g + o, (int)(a.P - p));
+          if (a.coef) ry[u][i] = load8_ragged<T, hx8>((const T*)a.yraw + o, (int)(a.P - p));
+        }
       }
     }
 #pragma unroll
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
           // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
           strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
         } else {
-          rx[u][i] = *(const hx8*)((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p);
+          const T* xsrc = (const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p;
+          rx[u][i] = (a.P - p >= 8) ? *(const hx8*)xsrc : load8_ragged<T, hx8>(xsrc, (int)(a.P - p));
         }
       }
     }
@@ -310,6 +316,9 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
         if (p >= a.P || !live) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = 0.f;      // C must not leak into padded points
+        } else if (a.P - p < 8) {                      // ... nor into the points past a ragged row end
+#pragma unroll
+          for (int e = 0; e < 8; e++) if (e >= (int)(a.P - p)) v[e] = 0.f;
         }
         VecIO<H, 8>::store(dst, v);
       } else {
@@ -332,12 +341,12 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
         if (live && n != n_gate) load_gate(n);
         const float s = xs_[i], t = xt_[i], g = xg_[i];
         const long long p = (long long)stp * BP + sp;
-        const bool pin = live && p < a.P;
+        const int nin = !live ? 0 : (int)min((long long)8, a.P - p);   // points of this vector inside the row (<= 0: none)
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = (s * (float)rx[u][i][e] + t) * g;
         act_vec<8>(v, a.xact);
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = pin ? v[e] : 0.f;
+        for (int e = 0; e < 8; e++) v[e] = (e < nin) ? v[e] : 0.f;
         VecIO<H, 8>::store(dst, v);
       } else {
         *(hx8*)dst = rx[u][i];
@@ -528,7 +537,7 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
 // returns -1 when the fast path does not apply (caller falls back to the generic kernel)
 template <typename H>
 static int pw_wgrad_v2_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st) {
-  if (vec < 8) return -1;
+  if (vec < 8 && !a.ragged) return -1;   // (ragged: P % 8 != 0 with 16-byte aligned tensors, set by the entry point)
   if (a.stride > 1) {
     if (a.stride != 2 || xpro) return -1;
     switch (strided_gather_gv(a.W, a.Wo, a.P, a.x)) {
