@@ -32,6 +32,10 @@ PW_FWD = [
     (1, 24, 24, 8, 156, 156, 2, None),                                   # Wo = 78: gather group 2
     (1, 24, 54, 1, 32, 32, 1, None), (1, 108, 48, 1, 16, 16, 1, "swish"), (1, 48, 108, 1, 16, 16, 1, None),  # aligned stage-2/3 layers
     (1, 24, 108, 1, 16, 16, 1, None), (1, 48, 216, 1, 16, 16, 1, None),
+    # X3D-S stages 4 / 5 (13 frames: rows of 1300 / 325 points, not multiples of 8): 16-bit storage takes the vector kernels
+    # with ragged row ends (unaligned row starts, a row's last vector element by element)
+    (2, 216, 96, 13, 10, 10, 1, "swish"), (2, 96, 216, 13, 10, 10, 1, None), (1, 432, 192, 13, 5, 5, 1, "swish"),
+    (1, 192, 432, 13, 5, 5, 1, None), (1, 24, 54, 1, 3, 4, 1, None),   # (... and a row shorter than two vectors: P = 12)
 ]
 # X3D-XL widths (configs/kinetics/X3D_XL.yaml: width factor 2.9, bottleneck 2.25): 32/72, 72/162, 136/306, 280/630, conv5 630
 PW_FWD_XL = [
@@ -49,6 +53,7 @@ PW_DGRAD = [
     (1, 54, 24, 4, 14, 14), (1, 48, 108, 2, 28, 28),   # strided add with rows of 2k / 4k points (pair / quad groups)
     (1, 192, 432, 2, 8, 8), (1, 432, 192, 2, 8, 8), (1, 96, 192, 2, 8, 8), (1, 96, 432, 2, 14, 14),   # stage-5 weights-stationary dgrads
     (1, 24, 48, 1, 16, 16), (1, 48, 96, 1, 16, 16), (1, 48, 216, 1, 16, 16),
+    (2, 96, 216, 13, 10, 10), (1, 192, 432, 13, 5, 5), (1, 96, 432, 13, 10, 10), (1, 432, 192, 13, 5, 5),   # X3D-S stages 4 / 5: ragged rows
 ]
 PW_DGRAD_EPI = ["store", "add", "add_strided", "swish_bwd"]
 
@@ -64,6 +69,8 @@ PW_WGRAD = [
     (1, 24, 48, 1, 78, 78, 2, None), (1, 48, 96, 2, 39, 39, 2, None), (1, 96, 192, 2, 20, 20, 2, None),
     (1, 96, 192, 8, 14, 14, 2, None), (1, 24, 48, 8, 78, 78, 2, None), (1, 24, 24, 8, 156, 156, 2, None),
     (1, 48, 108, 1, 16, 16, 1, None), (1, 108, 48, 1, 16, 16, 1, "swish"),
+    (2, 96, 216, 13, 10, 10, 1, None), (2, 216, 96, 13, 10, 10, 1, "swish"), (1, 192, 432, 13, 5, 5, 1, None),   # X3D-S stages 4 / 5: ragged rows
+    (1, 432, 192, 13, 5, 5, 1, "swish"),
 ]
 
 # ---- x3d_pw_bwd (fused dgrad + wgrad): N, Cin, Cout, T, H, W, epilogue ---------------------------------------------------

@@ -52,5 +52,7 @@ if __name__ == "__main__":
     res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.bfloat16))  #   the same in bf16
     res.append(train_rate("M", 64, 16, 224, torch.float16))          # the headline workload in fp16 with loss scaling
     res.append(infer_rate("XS", 8, 10, 1, 4, 160, torch.float32))    # config 1 on the GPU
+    res.append(train_rate("S", 64, 13, 160, torch.bfloat16))         # config 2's model in 16-bit storage: 13 frames -> ragged rows (P % 8 != 0)
+    res.append(train_rate("XS", 64, 4, 160, torch.bfloat16))
     for r in res:
         print(json.dumps(r))
