@@ -42,6 +42,28 @@ template <typename H, typename V8> __device__ __forceinline__ V8 load8_ragged(co
   for (int e = 0; e < 8; e++) if (e < nv) v[e] = p[e];
   return v;
 }
+// v = the 8 elements that END with a row's last element (loaded from row_end - 8, always inside the tensor); returns
+// them moved down by sh places (out[e] = v[e + sh], zero filled): the row's last, partial vector without a load that
+// depends on the data path -- sh = 8 - P % 8 is uniform over the launch, so this is a scalar switch around four v_alignbit
+template <typename V8> __device__ __forceinline__ V8 shift_down8(const V8& v, int sh) {
+  typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
+  const u4_ w = __builtin_bit_cast(u4_, v);
+  unsigned a0, a1, a2, a3;
+  switch (sh >> 1) {
+    case 0: a0 = w[0]; a1 = w[1]; a2 = w[2]; a3 = w[3]; break;
+    case 1: a0 = w[1]; a1 = w[2]; a2 = w[3]; a3 = 0u; break;
+    case 2: a0 = w[2]; a1 = w[3]; a2 = 0u; a3 = 0u; break;
+    default: a0 = w[3]; a1 = 0u; a2 = 0u; a3 = 0u; break;
+  }
+  u4_ o;
+  if (sh & 1) {
+    o[0] = __builtin_amdgcn_alignbit(a1, a0, 16); o[1] = __builtin_amdgcn_alignbit(a2, a1, 16);
+    o[2] = __builtin_amdgcn_alignbit(a3, a2, 16); o[3] = a3 >> 16;
+  } else {
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+  return __builtin_bit_cast(V8, o);
+}
 template <typename H, typename V8> __device__ __forceinline__ void store8_ragged(H* p, const V8& v, int nv) {
 #pragma unroll
   for (int e = 0; e < 8; e++) if (e < nv) p[e] = v[e];

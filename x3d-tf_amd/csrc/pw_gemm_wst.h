@@ -18,7 +18,10 @@
 // the four SIMDs evenly loaded), the first NW of them own row blocks
 #define WST_NWT 8
 
-template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC>
+// RAG (round 2): rows of P % 8 != 0 points (16-bit X3D-S / XS stage 5).  A row's last vector is loaded from
+// row_end - 8 -- always inside the tensor, still one unconditional load per slot -- and moved into place when it is
+// consumed (shift_down8, common.h); its stores go element by element and its sums are masked.
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false>
 __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemmArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int mt = (a.M + 31) >> 5;
+  const int rsh = 8 - (int)(a.P & 7);   // RAG: places a row's last vector (loaded from row_end - 8) moves down by
   const int tiles_per_n = (int)((a.P + BN - 1) / BN);
   const int total_tiles = tiles_per_n * a.N;
   const int tile_begin = blockIdx.x * a.tiles_per_block;
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const int k = v >> 2;
       const long long p = p0 + (v & 3) * 8;
       const bool ok = k < a.K && p < a.P;
-      const long long o = ok ? ((long long)n * a.K + k) * a.Pin + p : 0;
+      const long long pl = (RAG && a.P - p < 8) ? a.P - 8 : p;      // the row's last, partial vector: from row_end - 8
+      const long long o = ok ? ((long long)n * a.K + k) * a.Pin + pl : 0;
       xr[i] = *(const hx8*)((const T*)a.x + o);
       if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
     }
@@ -113,12 +118,19 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       hx8 z;
 #pragma unroll
       for (int e = 0; e < 8; e++) z[e] = (H)0.f;
+      hx8 xv = xr[i], yv = yr[PRO == PRO_BNBWD ? i : 0];
+      if constexpr (RAG) {
+        if (ok && a.P - (p0 + (v & 3) * 8) < 8) {
+          xv = shift_down8(xv, rsh);
+          if constexpr (PRO == PRO_BNBWD) yv = shift_down8(yv, rsh);
+        }
+      }
       if constexpr (PRO == PRO_NONE) {
-        *(hx8*)dst = ok ? xr[i] : z;
+        *(hx8*)dst = ok ? xv : z;
       } else {
         float val[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) val[e] = (float)xr[i][e];
+        for (int e = 0; e < 8; e++) val[e] = (float)xv[e];
         if constexpr (PRO == PRO_AFFINE) {
           const float2 cf = *(const float2*)&Cs[k * 2];
 #pragma unroll
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         } else {
           const f32x4 cf = *(const f32x4*)&Cs[k * 4];
 #pragma unroll
-          for (int e = 0; e < 8; e++) val[e] = cf[0] * val[e] + cf[1] * (float)yr[i][e] + cf[2];
+          for (int e = 0; e < 8; e++) val[e] = cf[0] * val[e] + cf[1] * (float)yv[e] + cf[2];
         }
         if (!ok) {
 #pragma unroll
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
-          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.Pp + p : 0;
+          const long long pl = (RAG && a.P - p < 8) ? a.P - 8 : p;
+          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.Pp + pl : 0;
           eo[j][hv] = *(const hx8*)(src + o);
         }
       }
@@ -285,6 +298,10 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
           const long long p = p0 + c0 + 8 * hv;
           if (p >= a.P) continue;                       // P % 8 == 0: a vector of 8 points is inside or outside
           const long long o = ((long long)n * a.M + m) * a.Pp + p;
+          const int left = RAG ? (int)min((long long)8, a.P - p) : 8;   // RAG: the row may end inside this vector
+          if constexpr (RAG && EPI_LOADS) {
+            if (left < 8) eo[j][hv] = shift_down8(eo[j][hv], rsh);
+          }
           float val[8];
           {
             const f32x4 v0 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv], v1 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv + 4];
@@ -303,15 +320,20 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
               const float b = (float)eo[j][hv][e];
               const float dv = val[e] * swish_grad_((sb * b + tb) * gt);
               val[e] = dv;
-              st1[j] += dv;
-              st2[j] += dv * b;
+              if (!RAG || e < left) {
+                st1[j] += dv;
+                st2[j] += dv * b;
+              }
             }
           }
           if constexpr (EPI == EPI_STATS) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) { st1[j] += val[e]; st2[j] += val[e] * val[e]; }
+            for (int e = 0; e < 8; e++) if (!RAG || e < left) { st1[j] += val[e]; st2[j] += val[e] * val[e]; }
           }
-          VecIO<T, 8>::store((T*)a.y + o, val);
+          if (!RAG || left == 8) VecIO<T, 8>::store((T*)a.y + o, val);
+          else {
+            for (int e = 0; e < left; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
+          }
         }
       }
     }
@@ -339,7 +361,7 @@ static inline size_t pw_wst_lds_bytes() {
 static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never, 1 = stage 5 only
   if (e && atoi(e) == 0) return 0;
-  if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || (a.P % 8) != 0) return 0;
+  if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || a.P < 8) return 0;   // (P % 8 != 0: the RAG instantiations)
   const int ks = (a.K + 15) >> 4;
   if (ks == 27 && a.M <= 192) return 1;
   if (ks == 12 && a.M <= 448) return 2;
@@ -350,12 +372,15 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   return 0;
 }
 
-template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC>
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false>
 static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
+  if constexpr (!RAG) {
+    if (a.P % 8 != 0) return pw_wst_launch_t<H, PRO, EPI, NW, RB, KS, OCC, true>(a, st);
+  }
   a.KC = KS * 16;
   const size_t lds = pw_wst_lds_bytes<NW, KS>();
-  X3D_DESCRIBE("pw_gemm_wst_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, PRO, EPI, NW, RB, KS, OCC);
-  auto kern = pw_gemm_wst_kernel<H, PRO, EPI, NW, RB, KS, OCC>;
+  X3D_DESCRIBE("pw_gemm_wst_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", HV<H>::name, PRO, EPI, NW, RB, KS, OCC, (int)RAG);
+  auto kern = pw_gemm_wst_kernel<H, PRO, EPI, NW, RB, KS, OCC, RAG>;
   static bool attr_set = false;
   static int cus = 256;
   if (!attr_set) {
