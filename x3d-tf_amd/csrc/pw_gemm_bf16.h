@@ -30,7 +30,10 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define PWB_XP (PWB_BN + 32)   // X pitch (elements)
 #define PWB_OP (PWB_BN + 4)    // output-tile pitch (floats)
 
-template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
+// RAG: rows of P % 8 != 0 points (common.h, pw_ragged_rows).  A separate instantiation: the element accesses of a row's
+// last vector sit in branches, and with them in the loop the compiler's vmcnt counts of the ALIGNED layers turned
+// conservative (216 -> 96 @ 14x14 forward 54 -> 87 us) -- so the aligned instantiations do not contain them.
+template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC, bool RAG = false>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           } else {
             // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
             const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
-            const long long left = a.P - p;          // P % 8 != 0: the row may end inside its last vector
+            const long long left = RAG ? a.P - p : 8;          // RAG: the row may end inside its last vector
             if (left >= 8) {
               xr[i] = *(const hx8*)((const T*)a.x + o);
               if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           if (m < a.M && p < a.P) {
             const long long o = ((long long)n * a.M + m) * a.Pp + p;
             const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o;
-            if (a.P - p >= 8) epl8[i] = *(const hx8*)src;
+            if (!RAG || a.P - p >= 8) epl8[i] = *(const hx8*)src;
             else epl8[i] = load8_ragged<T, hx8>(src, (int)(a.P - p));
           }
         } else {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
               for (int gq = 0; gq < 2; gq++) {
                 const int pe = (int)p + 4 * gq;
-                if (pe >= (int)a.P) continue;
+                if (RAG && pe >= (int)a.P) continue;
                 const int t = pe / hw;
                 const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
               for (int gq = 0; gq < 4; gq++) {
                 const int pe = (int)p + 2 * gq;
-                if (pe >= (int)a.P) continue;
+                if (RAG && pe >= (int)a.P) continue;
                 const int t = pe / hw;
                 const int rem = pe - t * hw;
                 const int h = rem / a.eW, w = rem - h * a.eW;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
       }
       const long long o = ((long long)n * a.M + m) * a.Pp + p;
-      const int nvalid = (int)min((long long)8, a.P - p);   // < 8: the row ends inside this vector (P % 8 != 0)
+      const int nvalid = (OVEC == 8 && !RAG) ? 8 : (int)min((long long)8, a.P - p);   // < 8: the row ends inside this vector
       if constexpr (EPI == X3D_EPI_ADD) {
         if constexpr (OVEC == 8) {
 #pragma unroll
@@ -519,11 +522,13 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) ov[e] = (H)val[e];
         // byte offset inside sample n's [M][P] matrix; 0x80000000 is past num_records -> the store is discarded
-        const unsigned off = (rvalid && nvalid == 8) ? (unsigned)(((long long)m * a.Pp + p) * 2) : 0x80000000u;
+        const unsigned off = (rvalid && (!RAG || nvalid == 8)) ? (unsigned)(((long long)m * a.Pp + p) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), yrsrc, off, 0, 0);
-        if (rvalid && nvalid < 8) store8_ragged<T, hx8>((T*)a.y + o, ov, nvalid);
+        if constexpr (RAG) {
+          if (rvalid && nvalid < 8) store8_ragged<T, hx8>((T*)a.y + o, ov, nvalid);
+        }
       } else if constexpr (OVEC == 8) {
-        if (nvalid == 8) VecIO<T, 8>::store((T*)a.y + o, val);
+        if (!RAG || nvalid == 8) VecIO<T, 8>::store((T*)a.y + o, val);
         else {
           for (int e = 0; e < nvalid; e++) ((T*)a.y)[o + e] = from_f<T>(val[e]);
         }
@@ -570,8 +575,11 @@ static inline int pw_bf16_pick_mt(int M, int K) {
   return 2;
 }
 
-template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC>
+template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC, bool RAG = false>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
+  if constexpr (!RAG && VEC == 8 && OVEC == 8 && STRIDED == 0) {
+    if (a.P % 8 != 0) return pw_bf16_launch_cfg<H, VEC, MT, PRO, EPI, STRIDED, OVEC, true>(a, st);   // ragged rows
+  }
   constexpr int BM = MT * 32, BN = PWB_BN;
   a.KC = (a.K + 15) & ~15;
   const size_t lds = pw_bf16_lds_bytes(MT, a.K);
@@ -580,8 +588,8 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
   X3D_REQUIRE((long long)a.M * a.Pp * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
-  X3D_DESCRIBE("pw_gemm_bf16_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, VEC, MT, PRO, EPI, STRIDED, OVEC);
-  auto kern = pw_gemm_bf16_kernel<H, VEC, MT, PRO, EPI, STRIDED, OVEC>;
+  X3D_DESCRIBE("pw_gemm_bf16_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", HV<H>::name, VEC, MT, PRO, EPI, STRIDED, OVEC, (int)RAG);
+  auto kern = pw_gemm_bf16_kernel<H, VEC, MT, PRO, EPI, STRIDED, OVEC, RAG>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -203,7 +203,9 @@ static int pw_wgrad_bf16_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_
 //  * NTHR = 512 (round 2, the stage-5 layers 192 <-> 432): eight waves own up to 7 x 6 tiles, i.e. ALL of the narrower
 //    operand and half of the wider one.  The run time of the 4-wave form follows the number of staged rows (4x2 tiles:
 //    3552 rows, 100 us; 4x3: 2496 rows, 65 us); 7x6 / 6x7 stage 1248 / 1200.  Threads 256..511 stage the odd 32-row tiles.
-template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256>
+//  * RAG: rows of P % 8 != 0 points (common.h, pw_ragged_rows) -- a separate instantiation, so that the element loads of a
+//    row's last vector do not sit (as branches) in the loop of the aligned layers
+template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256, bool RAG = false>
 __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12) ? 2 : 1) void pw_wgrad_bf16_v2_kernel(const PwWgradArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
       rg[u][i] = z; ry[u][i] = z;
       if (i * NTS + tsel < MG && co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
-        if (a.P - p >= 8) {
+        if (!RAG || a.P - p >= 8) {
           rg[u][i] = *(const hx8*)((const T*)a.g + o);
           if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
         } else {   // P % 8 != 0: the row ends inside this vector (zero fill: points are the reduction dimension)
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
           strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
         } else {
           const T* xsrc = (const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p;
-          rx[u][i] = (a.P - p >= 8) ? *(const hx8*)xsrc : load8_ragged<T, hx8>(xsrc, (int)(a.P - p));
+          if (!RAG || a.P - p >= 8) rx[u][i] = *(const hx8*)xsrc;
+          else rx[u][i] = load8_ragged<T, hx8>(xsrc, (int)(a.P - p));
         }
       }
     }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
         if (p >= a.P || !live) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = 0.f;      // C must not leak into padded points
-        } else if (a.P - p < 8) {                      // ... nor into the points past a ragged row end
+        } else if (RAG && a.P - p < 8) {               // ... nor into the points past a ragged row end
 #pragma unroll
           for (int e = 0; e < 8; e++) if (e >= (int)(a.P - p)) v[e] = 0.f;
         }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
         if (live && n != n_gate) load_gate(n);
         const float s = xs_[i], t = xt_[i], g = xg_[i];
         const long long p = (long long)stp * BP + sp;
-        const int nin = !live ? 0 : (int)min((long long)8, a.P - p);   // points of this vector inside the row (<= 0: none)
+        const int nin = !live ? 0 : (RAG ? (int)min((long long)8, a.P - p) : (p < a.P ? 8 : 0));   // points of this vector inside the row
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = (s * (float)rx[u][i][e] + t) * g;
         act_vec<8>(v, a.xact);
@@ -443,15 +446,18 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
   }
 }
 
-template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256>
+template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256, bool RAG = false>
 static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
+  if constexpr (!RAG && STRIDED == 0) {
+    if (a.ragged) return pw_wgrad_v2_launch<H, MG, NG, XPRO, STRIDED, NTHR, true>(a, st);
+  }
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
   const int gy = ceil_div(mt, MG), gz = ceil_div(nt, NG);
   const long long total_steps = ceil_div_ll(a.P, 64) * a.N;
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
   const size_t lds = (size_t)(MG + NG) * 32 * ((NTHR == 512 ? 1 : 2) * 64 + 8) * 2;
-  X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED, NTHR);
-  auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED, NTHR>;
+  X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED, NTHR, (int)RAG);
+  auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED, NTHR, RAG>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
