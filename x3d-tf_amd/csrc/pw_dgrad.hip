@@ -63,8 +63,7 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   a.w = d->w; a.wsk = d->Cin; a.wsm = 1;  // (k = co, m = ci) -> w[co*Cin + ci]
   a.N = d->N; a.K = d->Cout; a.M = d->Cin;
   a.stride = 1;
-  a.P = a.Pin = a.Pp = (long long)d->T * d->H * d->W;
-  a.p0 = 0;
+  a.P = a.Pin = (long long)d->T * d->H * d->W;
   X3D_REQUIRE(a.Pin < (1ll << 31) && a.P < (1ll << 31), "pw_dgrad: more than 2^31 points per sample");   // 32-bit point indices in the kernels
   a.y = d->dx; a.add = d->add; a.braw = d->braw; a.b_ss = d->b_scale_shift; a.egate = d->gate;
   a.nc_sums = d->nc_sums; a.eH = d->H; a.eW = d->W;

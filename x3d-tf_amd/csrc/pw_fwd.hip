@@ -29,7 +29,6 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   a.Ho = ceil_div(f->H, f->stride); a.Wo = ceil_div(f->W, f->stride);
   a.Pin = (long long)f->T * f->H * f->W;
   a.P = (long long)f->T * a.Ho * a.Wo;
-  a.Pp = a.P; a.p0 = 0;
   X3D_REQUIRE(a.Pin < (1ll << 31) && a.P < (1ll << 31), "pw_fwd: more than 2^31 points per sample");   // 32-bit point indices in the kernels
   a.y = f->y; a.stats = f->stats;
   a.wp = f->w_panel; a.wp_rows = (f->Cout + 31) & ~31;

@@ -29,10 +29,7 @@ struct PwGemmArgs {
   const float* w;
   int wsk, wsm;
   int N, K, M;
-  long long P, Pin;    // points per sample handled by this launch; row pitch (elements) of the streamed operand x / x2
-  long long Pp;        // row pitch of the output-side tensors (y, add, braw).  Pp = Pin = P unless the launch covers a
-                       // sub-range of the points of every row (16-bit storage, P % 8 != 0: main part + tail, pw_split.h)
-  int p0;              // first point of that sub-range (only the strided-add epilogue needs absolute point indices)
+  long long P, Pin;    // points per sample of the output side (y, add, braw) / of the streamed operand x, x2
   int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
   int KC, nchunks, tiles_per_block;
   int wvec;            // bf16 kernel: fp32 vector width for the weight-panel staging
@@ -209,7 +206,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
           const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
           const bool ok = (m < a.M) && (p < a.P);
           float val = acc[s][j];
-          const long long o = ((long long)n * a.M + m) * a.Pp + p;
+          const long long o = ((long long)n * a.M + m) * a.P + p;
           if constexpr (EPI == EPI_STATS) {
             if (ok) {
               ((T*)a.y)[o] = from_f<T>(val);
@@ -224,12 +221,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
           } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
             if (ok) {
               const long long hw = (long long)a.eH * a.eW;
-              const long long t = (p + a.p0) / hw;
-              const int rem = (int)(p + a.p0 - t * hw);
+              const long long t = p / hw;
+              const int rem = (int)(p - t * hw);
               const int h = rem / a.eW, w = rem - h * a.eW;
               if (((h | w) & 1) == 0) {
                 const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-                const long long T_ = a.Pp / hw;
+                const long long T_ = a.P / hw;
                 const long long oa =
                     ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
                 val += to_f<T>(((const T*)a.add)[oa]);

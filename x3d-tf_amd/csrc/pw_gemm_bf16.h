@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     const int oc = (tid & 15) * 8;
     __amdgpu_buffer_rsrc_t yrsrc;
     if constexpr (BSTORE)
-      yrsrc = __builtin_amdgcn_make_buffer_rsrc((T*)a.y + (long long)n * a.M * a.Pp, 0, (int)((long long)a.M * a.Pp * 2), 0x00020000);
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc((T*)a.y + (long long)n * a.M * a.P, 0, (int)((long long)a.M * a.P * 2), 0x00020000);
     // Every global load of the epilogue is issued HERE, before any store of this tile.  vmcnt retires in order
     // (stores included) and the compiler must assume vmcnt(0) around the conditional stores, so a load issued
     // after a store would wait for that store's write latency (once per row), and the first use of the next
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
           if (m < a.M && p < a.P) {
-            const long long o = ((long long)n * a.M + m) * a.Pp + p;
+            const long long o = ((long long)n * a.M + m) * a.P + p;
             const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o;
             if (!RAG || a.P - p >= 8) epl8[i] = *(const hx8*)src;
             else epl8[i] = load8_ragged<T, hx8>(src, (int)(a.P - p));
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           if (epl4_vec && m < a.M && p < a.P) {
             const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-            const int T_ = (int)a.Pp / hw;
+            const int T_ = (int)a.P / hw;
             const T* abase = (const T*)a.add + ((long long)n * a.M + m) * T_ * Hh * Wh;
             if (egv == 8) {
               // the 8 points lie in one image row; on even rows the even ones receive 4 contiguous half-resolution values
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
       }
-      const long long o = ((long long)n * a.M + m) * a.Pp + p;
+      const long long o = ((long long)n * a.M + m) * a.P + p;
       const int nvalid = (OVEC == 8 && !RAG) ? 8 : (int)min((long long)8, a.P - p);   // < 8: the row ends inside this vector
       if constexpr (EPI == X3D_EPI_ADD) {
         if constexpr (OVEC == 8) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
       } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
         const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-        const int T_ = (int)a.Pp / hw;
+        const int T_ = (int)a.P / hw;
         if (epl4_vec) {
           if constexpr (EPL4) {   // loaded above (zeros on odd rows)
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           }
         } else
         for (int e = 0; e < nvalid; e++) {
-          const int pe = (int)p + a.p0 + e;
+          const int pe = (int)p + e;
           const int t = pe / hw;
           const int rem = pe - t * hw;
           const int h = rem / a.eW, w = rem - h * a.eW;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) ov[e] = (H)val[e];
         // byte offset inside sample n's [M][P] matrix; 0x80000000 is past num_records -> the store is discarded
-        const unsigned off = (rvalid && (!RAG || nvalid == 8)) ? (unsigned)(((long long)m * a.Pp + p) * 2) : 0x80000000u;
+        const unsigned off = (rvalid && (!RAG || nvalid == 8)) ? (unsigned)(((long long)m * a.P + p) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), yrsrc, off, 0, 0);
         if constexpr (RAG) {
           if (rvalid && nvalid < 8) store8_ragged<T, hx8>((T*)a.y + o, ov, nvalid);
@@ -587,7 +587,7 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   const int gy = ceil_div(a.M, BM);
   const long long total_tiles = ceil_div_ll(a.P, BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_bf16: too many tiles");
-  X3D_REQUIRE((long long)a.M * a.Pp * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
+  X3D_REQUIRE((long long)a.M * a.P * 2 < (1ll << 31), "pw_gemm_bf16: one sample's output exceeds the 2 GB buffer-store window");
   X3D_DESCRIBE("pw_gemm_bf16_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", HV<H>::name, VEC, MT, PRO, EPI, STRIDED, OVEC, (int)RAG);
   auto kern = pw_gemm_bf16_kernel<H, VEC, MT, PRO, EPI, STRIDED, OVEC, RAG>;
   if (lds > 48 * 1024) {

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           if (p >= a.P) continue;                       // P % 8 == 0: a vector of 8 points is inside or outside
-          const long long o = ((long long)n * a.M + m) * a.Pp + p;
+          const long long o = ((long long)n * a.M + m) * a.P + p;
           float val[8];
           {
             const f32x4 v0 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv], v1 = *(const f32x4*)&myOs[row * OP + c0 + 8 * hv + 4];

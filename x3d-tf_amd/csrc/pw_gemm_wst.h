@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
       // dx [eH x eW] receives `add` [ceil(eH/2) x ceil(eW/2)] on its even pixels.  eW is even (dispatch): the 8 points of
       // a vector are four pairs inside one image row each, the first of a pair on an even column.  32-bit index maths.
-      const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.Pp / hw;
+      const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.P / hw;
 #pragma unroll
       for (int j = 0; j < RB; j++) {
         const int m = (wid + NW * j) * 32 + row;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           const long long pl = (RAG && a.P - p < 8) ? a.P - 8 : p;
-          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.Pp + pl : 0;
+          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.P + pl : 0;
           eo[j][hv] = *(const hx8*)(src + o);
         }
       }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           if (p >= a.P) continue;                       // P % 8 == 0: a vector of 8 points is inside or outside
-          const long long o = ((long long)n * a.M + m) * a.Pp + p;
+          const long long o = ((long long)n * a.M + m) * a.P + p;
           const int left = RAG ? (int)min((long long)8, a.P - p) : 8;   // RAG: the row may end inside this vector
           if constexpr (RAG && EPI_LOADS) {
             if (left < 8) eo[j][hv] = shift_down8(eo[j][hv], rsh);
