@@ -110,13 +110,31 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
   }
 
   auto stage_w = [&](int k0) {
-    // walk the weight matrix along its contiguous axis so the global reads coalesce
-    for (int i = tid; i < a.KC * BM; i += 256) {
-      int k, m;
-      if (a.wsk == 1) { m = i / a.KC; k = i - m * a.KC; }
-      else { k = i / BM; m = i - k * BM; }
-      int gk = k0 + k, gm = m0 + m;
-      Ws[k * BMP + m] = (gk < a.K && gm < a.M) ? a.w[(long long)gk * a.wsk + (long long)gm * a.wsm] : 0.f;
+    // walk the weight matrix along its contiguous axis so the global reads coalesce.  EIGHT elements per thread and round,
+    // all eight loads issued before the first LDS write: the rolled loop (run-time trip count, an integer division per
+    // element) waited for every load in turn -- 24-48 exposed L2 latencies per panel, which was most of the run time of the
+    // small layers (216 -> 96 on 8000 points: 69 us)
+    constexpr int UW = 8;
+    const int total = a.KC * BM;
+    const int kshift = 32 - __builtin_clz((unsigned)(a.KC - 1) | 1u);   // KC rounded up to a power of two: k = i & mask
+    const int kmask = (1 << kshift) - 1;
+    const int span = (a.wsk == 1) ? (BM << kshift) : total;
+    for (int base = 0; base < span; base += 256 * UW) {
+      float wv[UW];
+      int dst[UW];
+#pragma unroll
+      for (int u = 0; u < UW; u++) {
+        const int i = base + u * 256 + tid;
+        int k, m;
+        if (a.wsk == 1) { m = i >> kshift; k = i & kmask; }
+        else { k = i / BM; m = i - k * BM; }
+        const bool in = i < span && k < a.KC && m < BM;
+        const int gk = k0 + k, gm = m0 + m;
+        dst[u] = in ? k * BMP + m : -1;
+        wv[u] = (in && gk < a.K && gm < a.M) ? a.w[(long long)gk * a.wsk + (long long)gm * a.wsm] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UW; u++) if (dst[u] >= 0) Ws[dst[u]] = wv[u];
     }
   };
   auto stage_x = [&](int k0, long long p0) {
