@@ -46,6 +46,38 @@ struct PwGemmArgs {
   int eH, eW;          // EPI_ADD_STRIDED: geometry of dx (H, W); add is at ceil(H/2) x ceil(W/2)
 };
 
+// the same in two halves -- raw loads, then the arithmetic -- so that a thread can put ALL its staging loads of a tile in
+// flight before it touches the first value (stage_x below)
+template <typename T, int VEC, int PRO, bool STRIDED>
+__device__ __forceinline__ void pw_load_raw(const PwGemmArgs& a, int n, int gk, long long p, float (&v)[VEC], float (&y2)[VEC]) {
+  const T* x = (const T*)a.x;
+  if constexpr (STRIDED) {
+    static_assert(VEC == 1, "strided gather is scalar");
+    long long hw = (long long)a.Ho * a.Wo;
+    long long t = p / hw;
+    int rem = (int)(p - t * hw);
+    int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+    v[0] = to_f<T>(x[((long long)n * a.K + gk) * a.Pin + src]);
+  } else {
+    VecIO<T, VEC>::load(x + ((long long)n * a.K + gk) * a.Pin + p, v);
+  }
+  if constexpr (PRO == PRO_BNBWD) VecIO<T, VEC>::load((const T*)a.x2 + ((long long)n * a.K + gk) * a.Pin + p, y2);
+}
+template <int VEC, int PRO>
+__device__ __forceinline__ void pw_prologue(const PwGemmArgs& a, const float* ck, float (&v)[VEC], const float (&y2)[VEC]) {
+  if constexpr (PRO == PRO_AFFINE) {
+    const float s = ck[0], t = ck[1], g = ck[2];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) v[e] = (s * v[e] + t) * g;
+    act_vec<VEC>(v, a.act);
+  } else if constexpr (PRO == PRO_BNBWD) {
+    const float A = ck[0], B = ck[1], C = ck[2];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) v[e] = A * v[e] + B * y2[e] + C;
+  }
+}
+
 // ck: this row's prologue coefficients from the workgroup's LDS table (PRO_AFFINE: {s*g, t*g}; PRO_BNBWD: {A, B, C})
 template <typename T, int VEC, int PRO, bool STRIDED>
 __device__ __forceinline__ void pw_load_vec(const PwGemmArgs& a, int n, int gk, long long p,
@@ -139,6 +171,39 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
   };
   auto stage_x = [&](int k0, long long p0) {
     constexpr int VPR = BN / VEC;  // vectors per row
+    // four vectors per thread and round, their loads issued together (the rolled loop waited for each in turn)
+    constexpr int UX = 4;
+    const int nvec = a.KC * VPR;
+    for (int base = 0; base < nvec; base += 256 * UX) {
+      float xr[UX][VEC], yr[PRO == PRO_BNBWD ? UX : 1][VEC];
+#pragma unroll
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        const int k = v / VPR, pv = v - k * VPR;
+        const long long p = p0 + (long long)pv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { xr[u][e] = 0.f; if constexpr (PRO == PRO_BNBWD) yr[u][e] = 0.f; }
+        if (v < nvec && k0 + k < a.K && p < a.P) pw_load_raw<T, VEC, PRO, STRIDED>(a, n, k0 + k, p, xr[u], yr[PRO == PRO_BNBWD ? u : 0]);
+      }
+#pragma unroll
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        if (v >= nvec) continue;
+        const int k = v / VPR, pv = v - k * VPR;
+        const long long p = p0 + (long long)pv * VEC;
+        float val[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = xr[u][e];
+        if (k0 + k < a.K && p < a.P) {
+          pw_prologue<VEC, PRO>(a, Pk + k * 4, val, yr[PRO == PRO_BNBWD ? u : 0]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) val[e] = 0.f;   // the prologue constants must not leak into the padding
+        }
+        VecIO<float, VEC>::store(&Xs[k * BN + pv * VEC], val);
+      }
+    }
+    return;
     for (int v = tid; v < a.KC * VPR; v += 256) {
       int k = v / VPR, pv = v - k * VPR;
       int gk = k0 + k;
@@ -219,6 +284,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
       if (id < MT * NT) {
         const int mt = id / NT, nt = id - mt * NT;
         const long long p = p0 + nt * 32 + r;
+        // the epilogue operand (residual / raw depthwise output) of all 16 rows first: inside the loop below every load
+        // sat behind the previous row's store (the compiler must assume they alias) and exposed its latency 16 times
+        constexpr bool EPL = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
+        float eop[EPL ? 16 : 1];
+        if constexpr (EPL) {
+          const T* esrc = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+            eop[j] = ((m < a.M) && (p < a.P)) ? to_f<T>(esrc[((long long)n * a.M + m) * a.P + p]) : 0.f;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
@@ -235,7 +312,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
           } else if constexpr (EPI == X3D_EPI_STORE) {
             if (ok) ((T*)a.y)[o] = from_f<T>(val);
           } else if constexpr (EPI == X3D_EPI_ADD) {
-            if (ok) ((T*)a.y)[o] = from_f<T>(val + to_f<T>(((const T*)a.add)[o]));
+            if (ok) ((T*)a.y)[o] = from_f<T>(val + eop[j]);
           } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
             if (ok) {
               const long long hw = (long long)a.eH * a.eW;
@@ -253,7 +330,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
             }
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
             if (ok) {
-              const float b = to_f<T>(((const T*)a.braw)[o]);
+              const float b = eop[j];
               const float* em = Em + (m - m0) * 4;
               const float u = em[0] * b + em[1];
               const float g = em[2];
