@@ -60,6 +60,20 @@ def main():
             fails += 1
             print("FAIL pw_wgrad", dt, (n, cin, cout, t, h, w))
             traceback.print_exc(limit=2)
+        # strided shortcut (stride 2, no prologue): odd and even input widths, P a multiple of 8 or not
+        ts, hs, ws = rng.choice([1, 2, 4, 8]), rng.choice([5, 8, 9, 13, 16, 20, 39]), rng.choice([7, 8, 11, 13, 16, 23, 27, 39, 40, 46])
+        try:
+            K.test_pw_fwd(gpu, dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None), False)
+        except Exception:
+            fails += 1
+            print("FAIL pw_fwd strided", dt, (n, ts, hs, ws))
+            traceback.print_exc(limit=2)
+        try:
+            K.test_pw_wgrad(gpu, dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None))
+        except Exception:
+            fails += 1
+            print("FAIL pw_wgrad strided", dt, (n, ts, hs, ws))
+            traceback.print_exc(limit=2)
         if (i + 1) % 10 == 0:
             print(f"{i + 1} cases, {fails} failures", flush=True)
     print(f"done: {cases} cases, {fails} failures")

@@ -231,7 +231,10 @@ static inline int pick_vec(int elem_bytes, long long extent, const void* p0, con
 // their input rows.  The outputs are taken in groups of GV (GV | Wo, so a group never crosses an output row):
 // one aligned load of 2*GV input elements per group (16 / 8 / 4 bytes for GV = 4 / 2 / 1).  lo | hi hold the 16
 // gathered elements in order, so output j of the vector is element 2*j whatever GV is.
-// Caller guarantees: W % (2*GV) == 0, Wo % GV == 0, base 4*GV-byte aligned, all 8 outputs inside the tensor.
+// Caller guarantees: Wo % GV == 0, base 4*GV-byte aligned, all 8 outputs inside the tensor, and either W % (2*GV) == 0
+// (aligned loads) or W odd (round 2: 39 -> 20, the X3D-L / XL shortcuts).  With W odd the loads are unaligned -- which the
+// compute queues allow -- and the last group of a row would read one element past the row end (W = 2*Wo - 1): that group is
+// loaded one element EARLY and moved down by 16 bits, so nothing past the tensor is touched.
 // ---------------------------------------------------------------------------------------------
 template <int GV, typename HT>
 __device__ __forceinline__ void strided_gather16(const HT* base, long long p, int H, int W, int Ho, int Wo,
@@ -245,15 +248,22 @@ __device__ __forceinline__ void strided_gather16(const HT* base, long long p, in
   unsigned int w[8];
 #pragma unroll
   for (int gi = 0; gi < 8 / GV; gi++) {
-    const HT* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2;
+    const bool early = (W & 1) && wo + GV == Wo;    // odd W: the row's last group, loaded from one element earlier
+    const HT* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2 - (early ? 1 : 0);
     if constexpr (GV == 4) {
-      const u32x4 v = *(const u32x4*)src;
+      u32x4 v = *(const u32x4*)src;
+      if (early) {
+        v[0] = __builtin_amdgcn_alignbit(v[1], v[0], 16); v[1] = __builtin_amdgcn_alignbit(v[2], v[1], 16);
+        v[2] = __builtin_amdgcn_alignbit(v[3], v[2], 16); v[3] = v[3] >> 16;
+      }
       w[gi * 4] = v[0]; w[gi * 4 + 1] = v[1]; w[gi * 4 + 2] = v[2]; w[gi * 4 + 3] = v[3];
     } else if constexpr (GV == 2) {
-      const u32x2 v = *(const u32x2*)src;
+      u32x2 v = *(const u32x2*)src;
+      if (early) { v[0] = __builtin_amdgcn_alignbit(v[1], v[0], 16); v[1] = v[1] >> 16; }
       w[gi * 2] = v[0]; w[gi * 2 + 1] = v[1];
     } else {
-      w[gi] = *(const unsigned int*)src;
+      const unsigned int v = *(const unsigned int*)src;
+      w[gi] = early ? v >> 16 : v;
     }
     wo += GV;
     if (wo >= Wo) { wo = 0; if (++ho >= Ho) { ho = 0; ++t; } }
@@ -263,10 +273,14 @@ __device__ __forceinline__ void strided_gather16(const HT* base, long long p, in
   hi = __builtin_bit_cast(typename HV<HT>::x8, h);
 }
 // largest group size the gather supports for a stride-2 source of row length W sampled to Wo (0: use the scalar path)
+static inline bool strided_odd_enabled() {
+  static const char* e = getenv("X3D_PW_STRIDED_ODD");   // A/B hook: 0 = odd input widths on the scalar gather
+  return !(e && atoi(e) == 0);
+}
 static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
   if ((P % 8) != 0) return 0;
   for (int gv = 4; gv >= 1; gv >>= 1)
-    if ((Wo % gv) == 0 && (W % (2 * gv)) == 0 && ((uintptr_t)x % (4 * gv)) == 0) return gv;
+    if ((Wo % gv) == 0 && ((W % (2 * gv)) == 0 || ((W & 1) && strided_odd_enabled())) && ((uintptr_t)x % (4 * gv)) == 0) return gv;
   return 0;
 }
 
