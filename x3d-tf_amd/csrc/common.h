@@ -236,9 +236,11 @@ static inline int pick_vec(int elem_bytes, long long extent, const void* p0, con
 // compute queues allow -- and the last group of a row would read one element past the row end (W = 2*Wo - 1): that group is
 // loaded one element EARLY and moved down by 16 bits, so nothing past the tensor is touched.
 // ---------------------------------------------------------------------------------------------
+// nout: how many of the 8 outputs exist (a multiple of GV; < 8 only where a row of P % 8 != 0 points ends inside the
+// vector): the groups past it are not loaded (zeros).
 template <int GV, typename HT>
 __device__ __forceinline__ void strided_gather16(const HT* base, long long p, int H, int W, int Ho, int Wo,
-                                                 typename HV<HT>::x8& lo, typename HV<HT>::x8& hi) {
+                                                 typename HV<HT>::x8& lo, typename HV<HT>::x8& hi, int nout = 8) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   const int hw = Ho * Wo;                  // p < 2^31 (per-sample point index): 32-bit divisions
@@ -248,6 +250,11 @@ __device__ __forceinline__ void strided_gather16(const HT* base, long long p, in
   unsigned int w[8];
 #pragma unroll
   for (int gi = 0; gi < 8 / GV; gi++) {
+    if (gi * GV >= nout) {
+#pragma unroll
+      for (int j = 0; j < GV; j++) w[gi * GV + j] = 0u;
+      continue;
+    }
     const bool early = (W & 1) && wo + GV == Wo;    // odd W: the row's last group, loaded from one element earlier
     const HT* src = base + (t * H + (long long)ho * 2) * W + (long long)wo * 2 - (early ? 1 : 0);
     if constexpr (GV == 4) {
@@ -278,7 +285,7 @@ static inline bool strided_odd_enabled() {
   return !(e && atoi(e) == 0);
 }
 static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
-  if ((P % 8) != 0) return 0;
+  if ((P % 8) != 0 && !pw_ragged_rows(P, 2)) return 0;   // (P % 8 != 0: the RAG instantiations; P % GV == 0 since GV | Wo)
   for (int gv = 4; gv >= 1; gv >>= 1)
     if ((Wo % gv) == 0 && ((W % (2 * gv)) == 0 || ((W & 1) && strided_odd_enabled())) && ((uintptr_t)x % (4 * gv)) == 0) return gv;
   return 0;

@@ -43,7 +43,7 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   // 16-bit storage: bf16 / f16 matrix cores (fp32 accumulate)
   int ovec = pick_vec(eb, a.P, f->y);
   int vec16 = vec;
-  if (f->stride == 1 && ((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) vec16 = ovec = 8;
+  if (((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) vec16 = ovec = 8;   // (stride 2: the gather groups)
   if (vec16 != vec) return f->dtype == X3D_F16 ? pw_fwd_h16<f16>(a, vec16, ovec, pro, st) : pw_fwd_h16<bf16>(a, vec16, ovec, pro, st);
   return f->dtype == X3D_F16 ? pw_fwd_h16<f16>(a, vec, ovec, pro, st) : pw_fwd_h16<bf16>(a, vec, ovec, pro, st);
 }

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         if (ok) {
           if constexpr (STRIDED) {
             // strided shortcut: gather the even input elements, STRIDED = outputs per aligned load (common.h)
-            strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.K + gk) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, xr[i], yr[i]);
+            strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.K + gk) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, xr[i], yr[i],
+                                      RAG ? (int)min((long long)8, a.P - p) : 8);
           } else {
             // row (tid>>4) + 16*i of the chunk, 8 points at column 8*(tid&15): one base, stride 16 rows
             const long long o = ((long long)n * a.K + k0 + (tid >> 4)) * a.Pin + p0 + (tid & 15) * 8 + (long long)i * 16 * a.Pin;
@@ -577,7 +578,7 @@ static inline int pw_bf16_pick_mt(int M, int K) {
 
 template <typename H, int VEC, int MT, int PRO, int EPI, int STRIDED, int OVEC, bool RAG = false>
 static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
-  if constexpr (!RAG && VEC == 8 && OVEC == 8 && STRIDED == 0) {
+  if constexpr (!RAG && VEC == 8 && OVEC == 8) {
     if (a.P % 8 != 0) return pw_bf16_launch_cfg<H, VEC, MT, PRO, EPI, STRIDED, OVEC, true>(a, st);   // ragged rows
   }
   constexpr int BM = MT * 32, BN = PWB_BN;
@@ -658,7 +659,7 @@ static int pw_bf16_launch_vec(PwGemmArgs& a, int vec, int ovec, hipStream_t st) 
       if (gv == 4) return pw_bf16_launch_tile<H, 8, PRO, EPI, 4, 8>(a, st);
       if (gv == 2) return pw_bf16_launch_tile<H, 8, PRO, EPI, 2, 8>(a, st);
       if (gv == 1) return pw_bf16_launch_tile<H, 8, PRO, EPI, 1, 8>(a, st);
-      if (ovec >= 8) return pw_bf16_launch_tile<H, 1, PRO, EPI, 1, 8>(a, st);
+      if (ovec >= 8 && a.P % 8 == 0) return pw_bf16_launch_tile<H, 1, PRO, EPI, 1, 8>(a, st);   // (whole output vectors only)
       return pw_bf16_launch_tile<H, 1, PRO, EPI, 1, 1>(a, st);
     } else {
       x3d_set_error("pw: strided gather only in forward");

@@ -206,7 +206,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(xpro || (!w->in_gate && w->in_act == X3D_ACT_NONE), "pw_wgrad: prologue needs in_scale_shift");
   const int eb = w->dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, a.P, w->g, w->yraw, w->x);
-  a.ragged = (w->stride == 1 && pw_ragged_rows(a.P, eb) &&
+  a.ragged = (pw_ragged_rows(a.P, eb) &&
               (((uintptr_t)w->g | (uintptr_t)w->yraw | (uintptr_t)w->x) % 16) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (w->dtype == X3D_F32) return pw_wgrad_dispatch<float>(a, vec, xpro, st);

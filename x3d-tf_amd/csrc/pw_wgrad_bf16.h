@@ -294,7 +294,8 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
       if (i * NTS + tsel < NG && ci < a.Cin && p < a.P) {
         if constexpr (STRIDED) {
           // strided shortcut: even input elements, STRIDED outputs per aligned load (common.h)
-          strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i]);
+          strided_gather16<STRIDED>((const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin, p, a.H, a.W, a.Ho, a.Wo, rx[u][i], rx2[u][i],
+                                    RAG ? (int)min((long long)8, a.P - p) : 8);
         } else {
           const T* xsrc = (const T*)a.x + ((long long)n * a.Cin + ci) * a.Pin + p;
           if (!RAG || a.P - p >= 8) rx[u][i] = *(const hx8*)xsrc;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
 
 template <typename H, int MG, int NG, bool XPRO, int STRIDED, int NTHR = 256, bool RAG = false>
 static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
-  if constexpr (!RAG && STRIDED == 0) {
+  if constexpr (!RAG) {
     if (a.ragged) return pw_wgrad_v2_launch<H, MG, NG, XPRO, STRIDED, NTHR, true>(a, st);
   }
   const int mt = ceil_div(a.Cout, 32), nt = ceil_div(a.Cin, 32);
