@@ -164,10 +164,12 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # Invoked directly with --gpus N: start the N ranks as CHILD processes (torchrun, one rank per GPU) and exit with
-        # their status.  Nothing in this process has touched the GPU yet (torch.cuda.device_count() does not initialise
-        # HIP), and the parent never does: a process that initialised the GPU must not be replaced or forked.
-        have = torch.cuda.device_count()
-        if have < args.gpus and os.environ.get("X3D_DIST_BACKEND") != "gloo":
+        # their status.  This process never loads the HIP runtime: a process that initialised the GPU must not be replaced
+        # or forked, and torch.cuda.device_count() is NOT safe here (without amdsmi it falls through to hipGetDeviceCount,
+        # which opens /dev/kfd) -- the GPUs are counted from sysfs instead.  When the topology cannot be read (None) the
+        # ranks make the check themselves (xdist.local_device raises for a LOCAL_RANK without a GPU).
+        have = xdist.visible_gpu_count()
+        if have is not None and have < args.gpus and os.environ.get("X3D_DIST_BACKEND") != "gloo":
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node (one process per GPU); "
                              "refusing to time fewer GPUs than asked for")
         import socket
@@ -183,7 +185,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
                          "(or run `python bench.py --gpus N` directly, which starts the ranks itself)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+        raise SystemExit("bench.py needs one MI355X GPU per rank and none is visible (no CPU fallback for the hot path)")
     device = torch.device(f"cuda:{xdist.local_device(local_rank)}")
     torch.cuda.set_device(device)
 

@@ -45,6 +45,10 @@ extern "C" {
 #define X3D_EPI_ADD_STRIDED 2 /* dx = W^T dY + upsample_zero(add, 2)   (shortcut conv, stride 2) */
 #define X3D_EPI_SWISH_BWD 3   /* dv = (W^T dY) * swish'(gate*bn_b(braw)); per-(n,c) sums */
 
+/* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
+ * the library was built with; a binding must refuse a library whose version differs from the header it was written against
+ * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
+#define X3D_ABI_VERSION 120
 int x3d_version(void);
 const char* x3d_last_error(void);
 

@@ -1,0 +1,53 @@
+"""Randomised kernel-parity cases: the kernel-level tests of tests/test_kernels_gpu.py (depthwise forward / fused backward,
+pointwise forward / data gradient / weight gradient, strided shortcut) on RANDOM shapes -- odd widths, ragged rows, point
+counts that are not a multiple of 8, strips cut by row ends, channel counts off the 32-grid -- in all three storage types.
+One generator for the in-suite slice (tests/test_fuzz_gpu.py) and the long sweep (tools/fuzz_parity.py)."""
+import random
+
+import torch
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+WIDTHS = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 17, 19, 20, 21, 23, 26, 28, 31, 37, 39, 40, 45, 46, 53, 56, 57, 78, 91]
+CHANS = [24, 48, 54, 96, 108, 192, 216, 432, 40, 72, 200]
+
+
+def case_calls(rng: random.Random):
+    """One fuzz case = 7 kernel-test calls: [(test function name, positional args after `gpu`)]."""
+    dt = rng.choice(DTYPES)
+    out = []
+    shp = (rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 5, 8]), rng.choice(WIDTHS), rng.choice(WIDTHS),
+           rng.choice([1, 2]))
+    out.append(("test_dw3d_fwd", (dt, shp)))
+    out.append(("test_dw3d_bwd", (dt, shp)))
+    t, h, w = rng.choice([1, 2, 3, 5, 13]), rng.choice([3, 5, 7, 8, 10, 12, 14]), rng.choice([3, 5, 7, 8, 10, 12, 14])
+    cin, cout = rng.choice(CHANS), rng.choice(CHANS)
+    n = rng.choice([1, 2])
+    half = dt != torch.float32
+    out.append(("test_pw_fwd", (dt, (n, cin, cout, t, h, w, 1, rng.choice([None, "swish", "relu"])), rng.choice([False, True]) and half)))
+    epi = rng.choice(["store", "add", "add_strided", "swish_bwd"])
+    out.append(("test_pw_dgrad", (dt, (n, cin, cout, t, h, w), epi, rng.choice([False, True]) and half)))
+    out.append(("test_pw_wgrad", (dt, (n, cin, cout, t, h, w, 1, rng.choice([None, "swish"])))))
+    # strided shortcut (stride 2, no prologue): odd and even input widths, P a multiple of 8 or not
+    ts, hs, ws = rng.choice([1, 2, 4, 8]), rng.choice([3, 5, 7, 8, 9, 13, 16, 20, 39]), rng.choice([3, 7, 8, 11, 13, 16, 23, 27, 39, 40, 46])
+    out.append(("test_pw_fwd", (dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None), False)))
+    out.append(("test_pw_wgrad", (dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None))))
+    return out
+
+
+def run_cases(gpu, cases: int, seed: int, log=None):
+    """Runs `cases` fuzz cases; returns the list of failures as (name, args, message)."""
+    import traceback
+    from tests import test_kernels_gpu as K
+    rng = random.Random(seed)
+    fails = []
+    for i in range(cases):
+        for name, args in case_calls(rng):
+            try:
+                getattr(K, name)(gpu, *args)
+            except Exception as e:   # noqa: BLE001  (a failing case must not stop the sweep)
+                fails.append((name, args, f"{type(e).__name__}: {str(e)[:300]}"))
+                if log:
+                    log(f"FAIL {name} {args}\n{traceback.format_exc(limit=2)}")
+        if log and (i + 1) % 10 == 0:
+            log(f"{i + 1} cases ({7 * (i + 1)} kernel checks), {len(fails)} failures")
+    return fails

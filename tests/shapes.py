@@ -38,6 +38,9 @@ PW_FWD = [
     (1, 192, 432, 13, 5, 5, 1, None), (1, 24, 54, 1, 3, 4, 1, None),   # (... and a row shorter than two vectors: P = 12)
     # strided shortcut with an ODD input width on the vector gather (groups of 4 / 2 / 1, the row's last group loaded early)
     (1, 24, 48, 2, 11, 23, 2, None), (1, 32, 32, 4, 9, 27, 2, None), (1, 24, 48, 8, 13, 13, 2, None),
+    # ... whose rows are ONE gather group wide (7 -> 4, 3 -> 2: stage 5 of 112-pixel crops): the early load of the last
+    # group would start before the row (before the tensor for its first row) -- these take the next smaller group
+    (1, 96, 192, 8, 7, 7, 2, None), (2, 96, 192, 8, 3, 3, 2, None),
 ]
 # X3D-XL widths (configs/kinetics/X3D_XL.yaml: width factor 2.9, bottleneck 2.25): 32/72, 72/162, 136/306, 280/630, conv5 630
 PW_FWD_XL = [
@@ -74,6 +77,7 @@ PW_WGRAD = [
     (2, 96, 216, 13, 10, 10, 1, None), (2, 216, 96, 13, 10, 10, 1, "swish"), (1, 192, 432, 13, 5, 5, 1, None),   # X3D-S stages 4 / 5: ragged rows
     (1, 432, 192, 13, 5, 5, 1, "swish"),
     (1, 24, 48, 2, 11, 23, 2, None), (1, 32, 32, 4, 9, 27, 2, None), (1, 24, 48, 8, 13, 13, 2, None),   # strided, odd input width: vector gather
+    (1, 96, 192, 8, 7, 7, 2, None), (2, 96, 192, 8, 3, 3, 2, None),   # rows one gather group wide (7 -> 4, 3 -> 2)
 ]
 
 # ---- x3d_pw_bwd (fused dgrad + wgrad): N, Cin, Cout, T, H, W, epilogue ---------------------------------------------------

@@ -22,8 +22,17 @@ def test_library_exports_every_declared_symbol():
     lib = hip.load()
     for name in _declared():
         assert getattr(lib, name) is not None
-    assert lib.x3d_version() >= 100
+    header = int(re.search(r"#define X3D_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "x3d_hip.h")).read()).group(1))
+    assert lib.x3d_version() == header == hip.ABI_VERSION
     assert lib.x3d_last_error() is not None
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """a library built from another version of the header must not load (its argument lists may have shifted)"""
+    import pytest
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION + 1)
+    with pytest.raises(hip.X3DHipError, match="ABI version"):
+        hip.load(hip.LIB_PATH)
 
 
 def test_struct_layouts_match_header():

@@ -102,6 +102,41 @@ def test_bundle_roundtrip_with_reference_layout(tmp_path):
     assert tuple(tfk.shape) == (2048, 400)
 
 
+def test_adam_bundle_roundtrip(tmp_path):
+    """the optimizer branch train.py:93-95 saved by ModelCheckpoint (utils.py:128-132): Keras Adam's slot variables `m` /
+    `v` per trainable variable and its hyper variables (iter, learning_rate, decay, beta_1, beta_2) round trip; no SGD
+    `momentum` key is written, and the object graph names both slot kinds."""
+    arch, specs = _specs("XS")
+    state = randomize_bn_(init_params(arch, seed=5), seed=6)
+    m1 = {k: torch.randn_like(v) for k, v in state.items() if specs[k].trainable}
+    m2 = {k: torch.rand_like(v) for k, v in state.items() if specs[k].trainable}
+    prefix = str(tmp_path / "ckpt-2")
+    ck.write_checkpoint(prefix, state, specs, slots={"m": m1, "v": m2},
+                        optimizer_hyper=dict(iter=17, learning_rate=0.25, beta_1=0.9, beta_2=0.999, decay=0.0))
+    _, ent = ck.read_index(prefix + ".index")
+    assert not [k for k in ent if "/optimizer/momentum/" in k or k.startswith("optimizer/momentum")]
+    assert {k[len("optimizer/"):-len(ck.SUFFIX)] for k in ent if k.startswith("optimizer/")} == set(ck.ADAM_HYPER)
+    assert sum("/.OPTIMIZER_SLOT/optimizer/m/" in k for k in ent) == len(m1)
+    assert sum("/.OPTIMIZER_SLOT/optimizer/v/" in k for k in ent) == len(m2)
+    back, slots, hyper = ck.read_checkpoint(prefix, specs, with_slots=("momentum", "m", "v"))
+    assert hyper["iter"] == 17 and abs(hyper["learning_rate"] - 0.25) < 1e-7 and abs(hyper["beta_2"] - 0.999) < 1e-7
+    assert not slots["momentum"]
+    for k in m1:
+        assert torch.equal(slots["m"][k], m1[k]) and torch.equal(slots["v"][k], m2[k]), k
+    for k in state:
+        assert torch.equal(back[k], state[k]), k
+    nodes = ck.read_object_graph(prefix)
+    opt = nodes[nodes[0]["children"]["optimizer"]]
+    kinds = {}
+    for var_node, slot_name, slot_node in opt["slots"]:
+        vkey = nodes[var_node]["attributes"]["VARIABLE_VALUE"]
+        assert nodes[slot_node]["attributes"]["VARIABLE_VALUE"] == \
+            vkey[:-len(ck.SUFFIX)] + f"/.OPTIMIZER_SLOT/optimizer/{slot_name}" + ck.SUFFIX
+        kinds[slot_name] = kinds.get(slot_name, 0) + 1
+    assert kinds == {"m": len(m1), "v": len(m2)}
+    assert set(opt["children"]) == set(ck.ADAM_HYPER)
+
+
 def test_corruption_and_partial_are_detected(tmp_path):
     arch, specs = _specs("XS")
     state = init_params(arch, seed=1)

@@ -149,6 +149,37 @@ def test_shuffle_buffer_and_failed_decode():
     assert v.shape == (3, 8, 8, 3) and int(v[0, 0, 0, 0]) == 9 and lab == 2
 
 
+def test_rank_shards_are_disjoint_and_cover_the_dataset(tmp_path):
+    """MirroredStrategy splits ONE global batch over the replicas (reference utils.py:160-167); here each process owns a
+    reader, so rank r keeps records r, r + world, ... of the same record stream: disjoint, covering, batch_size // world
+    per step -- in evaluation order and through the training shuffles (file order is rank-independent)."""
+    import x3d_tf_amd as x
+    cfg = x.get_config("XS")
+    recs = [bytes([i]) * (3 + i) for i in range(14)]
+    for k in range(0, 14, 4):
+        DL.write_tfrecords(str(tmp_path / f"part-{k // 4}.tfrecord"), recs[k:k + 4])
+    pattern = str(tmp_path / "part-*.tfrecord")
+    for training in (False, True):
+        shards = []
+        for r in range(2):
+            rd = DL.InputReader(cfg, training, True, device="cpu", seed=9, rank=r, world=2)
+            assert rd.local_batch(8) == 4 and rd.local_batch(None) is None
+            shards.append(list(rd._records(pattern, rd.local_batch(8))))
+        assert not set(shards[0]) & set(shards[1])
+        assert sorted(shards[0] + shards[1]) == sorted(recs) and abs(len(shards[0]) - len(shards[1])) <= 1
+    one = list(DL.InputReader(cfg, False, True, device="cpu", rank=0, world=1)._records(pattern, 8))
+    assert sorted(one) == sorted(recs)
+    with pytest.raises(ValueError):
+        DL.InputReader(cfg, True, True, device="cpu", rank=0, world=3).local_batch(8)
+    with pytest.raises(ValueError):
+        DL.InputReader(cfg, True, True, device="cpu", rank=2, world=2)
+    # text-file path: the same sharding of the line list
+    (tmp_path / "list.txt").write_text("".join(f"v{i}.mp4 {i}\n" for i in range(7)))
+    a = list(DL.InputReader(cfg, False, False, device="cpu", rank=0, world=2)._records(str(tmp_path / "list.txt"), None))
+    b = list(DL.InputReader(cfg, False, False, device="cpu", rank=1, world=2)._records(str(tmp_path / "list.txt"), None))
+    assert a == [f"v{i}.mp4 {i}" for i in (0, 2, 4, 6)] and b == [f"v{i}.mp4 {i}" for i in (1, 3, 5)]
+
+
 # ---- the pipeline end to end on the GPU ------------------------------------------------------------
 def _write_dataset(tmp_path, vids, per_file=3):
     paths = []

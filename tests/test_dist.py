@@ -213,3 +213,63 @@ def test_bench_refuses_to_time_fewer_gpus_than_asked():
     assert r.returncode != 0
     assert "GPU" in (r.stderr + r.stdout)
     assert '"n_gpus"' not in r.stdout          # no benchmark line was printed
+
+
+def test_bench_launcher_parent_never_touches_the_hip_runtime(monkeypatch, tmp_path):
+    """The `--gpus N` launcher parent counts GPUs from sysfs (x3d_tf_amd.dist.visible_gpu_count) and starts torchrun as a
+    child process without a single torch.cuda call: device_count / is_available / init are patched to raise."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from x3d_tf_amd import dist as xd
+
+    def boom(*a, **k):
+        raise AssertionError("the launcher parent called into torch.cuda")
+    for name in ("device_count", "is_available", "init", "set_device", "current_device"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "X3D_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: (calls.append(cmd), subprocess.CompletedProcess(cmd, 0))[1])
+    monkeypatch.setattr(xd, "visible_gpu_count", lambda *a, **k: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    # fewer GPUs than asked for: refused before anything is launched
+    calls.clear()
+    monkeypatch.setattr(xd, "visible_gpu_count", lambda *a, **k: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code not in (0, None) and not calls
+    # topology unreadable: the parent launches and leaves the check to the ranks
+    monkeypatch.setattr(xd, "visible_gpu_count", lambda *a, **k: None)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+
+
+def test_visible_gpu_count_reads_kfd_topology(monkeypatch, tmp_path):
+    from x3d_tf_amd import dist as xd
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, 0), (0, 0), (1024, 128), (1024, 129), (1024, 130)]):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for m in (128, 129):                       # renderD130 is not passed into this container
+        (dri / f"renderD{m}").write_text("")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert xd.visible_gpu_count(str(nodes), str(dri)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert xd.visible_gpu_count(str(nodes), str(dri)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,5")
+    assert xd.visible_gpu_count(str(nodes), str(dri)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert xd.visible_gpu_count(str(nodes), str(dri)) == 0
+    assert xd.visible_gpu_count(str(tmp_path / "absent"), str(dri)) is None

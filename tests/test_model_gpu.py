@@ -234,8 +234,7 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
         worst["y"] = max(worst["y"], _scaled(pre + "/out", B.y, y_ref, atol_))
         grads = torch.autograd.grad(y_ref, [xin] + [leaf[k] for k in names], grad_outputs=dy)
         dx_ref = grads[0]
-        if B.spec.has_shortcut_conv or True:
-            _scaled(pre + "/dx", dx_dev, dx_ref, atol_)
+        _scaled(pre + "/dx", dx_dev, dx_ref, atol_)       # every block: identity shortcuts add dy, conv shortcuts their dgrad
         for k, g_ref in zip(names, grads[1:]):
             e = rel_l2(m.grads[k], g_ref)
             worst["dw"] = max(worst["dw"], e)
@@ -341,25 +340,76 @@ def test_trainer_checkpoint_resume(gpu, tmp_path):
         assert d <= 1e-5 * max(1.0, m.params[k].abs().max().item()), (k, d)
 
 
-def test_full_size_headline_plan_properties(gpu):
-    """BASELINE config 3 at FULL size (X3D-M, 64 clips of 16x224x224, bf16 -- the plan bench.py times), checked through
-    size-independent properties, since no CPU oracle finishes this size:
+def test_trainer_adam_checkpoint_resume_matches_uninterrupted_run(gpu, tmp_path):
+    """OPTIMIZER adam (train.py:93-95) through save_checkpoint -> resume: both moments and the step count (`optimizer/iter`,
+    Adam's bias correction) are restored, so the step after a resume equals the step of the run that never stopped.
+    (Round 2 restored the first moment only, with v = 0 and t = 1: a ~10x first update.)"""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.train import Trainer
+    cfg = x.get_config("XS", ["TRAIN.OPTIMIZER", "adam", "NETWORK.NUM_CLASSES", 7])
+    arch = x.build_arch(cfg)
+    m = X3D(cfg, dtype=torch.float32, device=gpu, seed=5)
+    tr = Trainer(m, cfg)
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(2, 4, 64, 64, 3, generator=g).to(gpu)
+    y1 = torch.randint(0, 7, (2,), generator=g).to(gpu)
+    m.set_dropout_mask(torch.ones(2, arch.fc1_out))
+    for _ in range(3):
+        tr.step(x1, y1, 1e-3)
+    tr.save_checkpoint(str(tmp_path / "run"), epoch=1)
+    m2 = X3D(cfg, dtype=torch.float32, device=gpu, seed=99)
+    tr2 = Trainer(m2, cfg)
+    assert tr2.resume(str(tmp_path / "run")) == 1 and tr2.opt_step == 3
+    for k in m.grads:
+        o, nel = m._offsets[k], m.params[k].numel()
+        assert torch.equal(m.params[k], m2.params[k]), k
+        assert torch.equal(m.flat_velocity[o:o + nel], m2.flat_velocity[o:o + nel]), k
+        assert torch.equal(m.flat_second[o:o + nel], m2.flat_second[o:o + nel]), k
+    m2.set_dropout_mask(torch.ones(2, arch.fc1_out))
+    before = m.flat_params[:m.n_trainable_flat].clone()
+    tr.step(x1, y1, 1e-3)
+    tr2.step(x1, y1, 1e-3)
+    torch.cuda.synchronize()
+    step = (m.flat_params[:m.n_trainable_flat] - before).abs().max().item()
+    assert step <= 1.5e-3                      # an Adam step is bounded by ~lr; the broken resume moved weights by ~10 lr
+    for k in m.grads:   # the continued step agrees to fp32 atomic-summation order (weight gradients use fp32 atomics)
+        d = (m.params[k] - m2.params[k]).abs().max().item()
+        assert d <= 2e-5 * max(1.0, m.params[k].abs().max().item()), (k, d)
+    # a checkpoint of the OTHER optimizer branch: variables restored, slots start from zero (never SGD momentum as Adam's m)
+    cfg_s = x.get_config("XS", ["TRAIN.OPTIMIZER", "sgd", "NETWORK.NUM_CLASSES", 7])
+    m3 = X3D(cfg_s, dtype=torch.float32, device=gpu, seed=7)
+    tr3 = Trainer(m3, cfg_s)
+    assert tr3.resume(str(tmp_path / "run")) == 1 and tr3.opt_step == 0
+    assert float(m3.flat_velocity.abs().max()) == 0.0
+
+
+FULL_SIZE_TRAIN = [          # BASELINE configs at FULL size: variant, clips, T, S, storage, clips per inference sub-plan
+    ("M", 64, 16, 224, torch.bfloat16, 8),      # config 3: the plan bench.py times
+    ("S", 32, 13, 160, torch.float32, 8),       # config 2: fp32, 13 frames (rows of P % 8 != 0 points in stages 4 / 5)
+    ("L", 16, 16, 312, torch.bfloat16, 4),      # config 4: 156 / 78 / 39 / 20 / 10 planes (odd 39 -> 20), 55 blocks
+]
+
+
+@pytest.mark.parametrize("name,n,t,s,dtype,part", FULL_SIZE_TRAIN, ids=[c[0] for c in FULL_SIZE_TRAIN])
+def test_full_size_plan_properties(gpu, name, n, t, s, dtype, part):
+    """BASELINE configs 3, 2 and 4 at FULL size (the workgroup counts, 32-bit offsets and replica indexing of the real
+    plans), checked through size-independent properties, since no CPU oracle finishes these sizes:
       * loss and every gradient finite;
       * the BatchNorm batch statistics the kernels' epilogues accumulated equal an fp64 reduction of the stored tensors;
       * linearity of the explicit backward pass: doubling the upstream gradient (loss_scale = 2) doubles every gradient;
-      * per-sample independence in inference mode (moving statistics): the 64-clip plan gives the same probabilities as
-        eight 8-clip plans -- tile / workgroup partitioning across samples does not leak between clips."""
+      * per-sample independence in inference mode (moving statistics): the n-clip plan gives the same probabilities as
+        n / part plans of `part` clips -- tile / workgroup partitioning across samples does not leak between clips."""
     import x3d_tf_amd as x
     from x3d_tf_amd.model import X3D
     from x3d_tf_amd.params import init_params, randomize_bn_
-    cfg = x.get_config("M", ["TEST.NUM_TEMPORAL_VIEWS", 1, "TEST.NUM_SPATIAL_CROPS", 1])
+    cfg = x.get_config(name, ["TEST.NUM_TEMPORAL_VIEWS", 1, "TEST.NUM_SPATIAL_CROPS", 1])
     arch = x.build_arch(cfg)
-    m = X3D(cfg, dtype=torch.bfloat16, device=gpu, seed=0)
+    m = X3D(cfg, dtype=dtype, device=gpu, seed=0)
     m.load_state_dict(randomize_bn_(init_params(arch, seed=3), seed=4))
-    n, t, s = 64, 16, 224
     g = torch.Generator(device=gpu)
     g.manual_seed(7)
-    clips = torch.randn((n, t, s, s, 3), generator=g, device=gpu).to(torch.bfloat16)
+    clips = torch.randn((n, t, s, s, 3), generator=g, device=gpu).to(dtype)
     labels = torch.randint(0, arch.num_classes, (n,), generator=g, device=gpu)
     mask = (torch.rand((n, arch.fc1_out), generator=g, device=gpu) >= arch.dropout_rate).float()
     m.set_dropout_mask(mask)
@@ -369,8 +419,9 @@ def test_full_size_headline_plan_properties(gpu):
     assert torch.isfinite(pl.loss_rows).all() and torch.isfinite(m.flat_grads).all()
     assert 4.0 < pl.loss_rows.mean().item() < 9.0           # ~ln(400) = 5.99 for a random-init classifier
     g1 = m.flat_grads.clone()
-    # batch statistics: stage 2 (112^2 and 56^2 planes), stage 4 (14^2), stage 5 (7^2)
-    for bi in (0, 1, 12, len(pl.blocks) - 1):
+    # batch statistics: first two blocks (the widest planes), a mid-network block, the last block
+    nb = len(pl.blocks)
+    for bi in (0, 1, nb // 2, nb - 1):
         B = pl.blocks[bi]
         for raw, bn in ((B.a_raw, B.bn_a), (B.b_raw, B.bn_b), (B.c_raw, B.bn_c)):
             d = raw.double()
@@ -390,11 +441,45 @@ def test_full_size_headline_plan_properties(gpu):
     assert num <= 2e-3 * (2 * g1).norm().item(), f"backward pass not linear in the upstream gradient: {num}"
     # per-sample independence (inference)
     m.moving_stats_flat().copy_(moving0)
+    m.release_plans()
     full = m(clips, training=False).clone()
     assert tuple(full.shape) == (n, arch.num_classes) and torch.isfinite(full).all()
-    parts = torch.cat([m(clips[i:i + 8], training=False).clone() for i in range(0, n, 8)], 0)
-    report("probs 64 vs 8x8", full, parts, 0, 1e-6)
+    parts = torch.cat([m(clips[i:i + part], training=False).clone() for i in range(0, n, part)], 0)
+    report(f"probs {n} vs {n // part}x{part}", full, parts, 0, 1e-6)
     m.release_plans()
+
+
+def test_full_size_xl_30_view_inference_properties(gpu):
+    """BASELINE config 5 at FULL size: X3D-XL, one video = 10 temporal views x 3 spatial crops of 16x312x312, fp16 storage
+    (the reference's mixed_float16), inference.  Properties: the output is one finite probability row that sums to 1; the
+    30-clip plan equals the mean of three 10-clip plans (view averaging, model.py:123-126, and no leakage between clips
+    across the tile / workgroup partitioning of the large plan); a second video in the same batch does not change the
+    first one's row."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd.model import X3D
+    from x3d_tf_amd.params import init_params, randomize_bn_
+    cfg30 = x.get_config("XL", ["TEST.NUM_TEMPORAL_VIEWS", 10, "TEST.NUM_SPATIAL_CROPS", 3])
+    cfg10 = x.get_config("XL", ["TEST.NUM_TEMPORAL_VIEWS", 10, "TEST.NUM_SPATIAL_CROPS", 1])
+    arch = x.build_arch(cfg30)
+    params = randomize_bn_(init_params(arch, seed=3), seed=4)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(11)
+    clips = torch.randn((60, 16, 312, 312, 3), generator=g, device=gpu).to(torch.float16)
+    m30 = X3D(cfg30, dtype=torch.float16, device=gpu, seed=0)
+    m30.load_state_dict(params)
+    one = m30(clips[:30]).clone()
+    assert tuple(one.shape) == (1, arch.num_classes) and torch.isfinite(one).all()
+    assert abs(one.sum().item() - 1.0) < 1e-5 and one.min().item() >= 0
+    two = m30(clips).clone()                                  # two videos in one batch
+    assert tuple(two.shape) == (2, arch.num_classes)
+    report("video 0 alone vs in a batch of two", two[:1], one, 0, 1e-6)
+    m30.release_plans()
+    del m30
+    m10 = X3D(cfg10, dtype=torch.float16, device=gpu, seed=0)
+    m10.load_state_dict(params)
+    parts = torch.cat([m10(clips[i:i + 10]).clone() for i in range(0, 30, 10)], 0)
+    report("30-view row vs mean of three 10-view rows", one, parts.mean(0, keepdim=True), 0, 1e-6)
+    m10.release_plans()
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adam"])

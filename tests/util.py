@@ -54,12 +54,24 @@ def rel_l2(got, ref):
     return ((got - ref).norm() / (ref.norm() + 1e-30)).item()
 
 
-def tol_for(dtype):
-    """(rtol, atol-per-unit-of-scale) for outputs of kernels whose 16-bit GEMM operands are re-rounded for the matrix
-    cores (pointwise convs: weights and prologue outputs are rounded to the storage type, fp32 accumulation)."""
+def round_to(x, dtype):
+    """x (fp32 / fp64) rounded to the storage type `dtype`, as fp64: what a 16-bit GEMM operand holds after the kernel's
+    fp32 prologue.  float32: unchanged (the fp32 kernels feed the exact-fp32 matrix instruction)."""
+    if dtype == torch.float32:
+        return x.double()
+    return x.float().to(dtype).double()
+
+
+def tol_gemm(dtype):
+    """(rtol, atol-per-unit-of-scale) for the pointwise (matrix-core) kernels against an fp64 GEMM whose OPERANDS were
+    rounded to the storage type first (weights; the fp32 prologue's output -- round_to), so that what is left is the
+    rounding of the stored output (rtol, as tol_store), fp32 accumulation order, and the rare operand whose fp32
+    prologue value sits on a rounding boundary and lands on the other side in the reference's arithmetic (one product
+    off by an operand ulp: << 1e-3 of the tensor's scale).  Round 2 compared with UNROUNDED operands at 1.6e-2 of the
+    tensor maximum, which a dropped k-element of a K = 432 GEMM (1.2 %) passed."""
     if dtype == torch.float32:
         return (2e-5, 2e-5)
-    return (1.6e-2, 1.6e-2) if dtype == torch.bfloat16 else (2e-3, 2e-3)
+    return (4e-3, 1e-3) if dtype == torch.bfloat16 else (1e-3, 2.5e-4)
 
 
 def tol_store(dtype):

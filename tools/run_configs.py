@@ -10,6 +10,7 @@ from x3d_tf_amd.train import Trainer
 
 def train_rate(variant, batch, t, s, dtype, steps=5):
     cfg = x.get_config(variant)
+    torch.cuda.reset_peak_memory_stats()          # the footprint of THIS configuration, not the largest one so far
     m = X3D(cfg, dtype=dtype, device="cuda:0")
     tr = Trainer(m, cfg)
     clips = torch.randn(batch, t, s, s, 3, device="cuda").to(dtype)
@@ -21,13 +22,15 @@ def train_rate(variant, batch, t, s, dtype, steps=5):
         pl = tr.step(clips, labels, 0.01)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     loss = float(tr.loss(pl).item())
+    mem = torch.cuda.max_memory_allocated() / 1e9
     del m, tr
     torch.cuda.empty_cache()
     return dict(variant=variant, mode="train", dtype=str(dtype), batch=batch, clip=f"{t}x{s}x{s}", clips_per_s=steps * batch / el,
-                ms_per_step=1e3 * el / steps, loss=loss, mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+                ms_per_step=1e3 * el / steps, loss=loss, mem_GB=mem)
 
 def infer_rate(variant, videos, views, crops, t, s, dtype, steps=5):
     cfg = x.get_config(variant, ["TEST.NUM_TEMPORAL_VIEWS", views, "TEST.NUM_SPATIAL_CROPS", crops])
+    torch.cuda.reset_peak_memory_stats()
     m = X3D(cfg, dtype=dtype, device="cuda:0")
     n = videos * views * crops
     clips = torch.randn(n, t, s, s, 3, device="cuda").to(dtype)
@@ -38,10 +41,11 @@ def infer_rate(variant, videos, views, crops, t, s, dtype, steps=5):
         out = m(clips, training=False)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     ok = bool(torch.isfinite(out).all()) and tuple(out.shape) == (videos, 400)
+    mem = torch.cuda.max_memory_allocated() / 1e9
     del m
     torch.cuda.empty_cache()
     return dict(variant=variant, mode="inference", dtype=str(dtype), videos=videos, views=views * crops, clip=f"{t}x{s}x{s}",
-                clips_per_s=steps * n / el, videos_per_s=steps * videos / el, ok=ok)
+                clips_per_s=steps * n / el, videos_per_s=steps * videos / el, ms_per_batch=1e3 * el / steps, ok=ok, mem_GB=mem)
 
 if __name__ == "__main__":
     res = []

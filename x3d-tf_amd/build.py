@@ -22,6 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
          # hipcc SLP-packs adjacent fp32 mul/add into v_pk_mul + v_pk_add (no FMA, weights no longer SGPR operands):
          # 2.4x the VALU instructions and 2x the VGPRs in the depthwise stencils (measured in the .s)
          "-fno-slp-vectorize"]
+if os.environ.get("X3D_EXPERIMENTS") == "1":   # compiles the result-changing timing hooks in (X3D_PW_WG_NOFLUSH, X3D_DW_PK_NOLOAD)
+    FLAGS.append("-DX3D_EXPERIMENTS")
 
 
 def _hipcc():
@@ -35,7 +37,7 @@ def _digest(paths, extra=""):
     h = hashlib.sha256(extra.encode())
     for p in paths:
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
+            h.update(os.path.relpath(p, HERE).encode() + b"\0" + f.read())   # relative: a snapshot copied elsewhere is not rebuilt
     return h.hexdigest()
 
 

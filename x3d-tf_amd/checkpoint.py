@@ -332,12 +332,14 @@ def resolve_prefix(path: str) -> str:
 
 
 def read_checkpoint(path: str, specs: Dict[str, object], expect_partial: bool = True, verify_crc: bool = True,
-                    with_momentum: bool = False):
+                    with_momentum: bool = False, with_slots: Tuple[str, ...] = ()):
     """Read every model variable named in `specs` from a bundle -> {native name: fp32 CPU tensor}.
 
     Keys of the bundle that the model does not own (optimizer iter/lr/momentum slots, the object graph) are
     ignored when expect_partial (eval.py:81 ``.expect_partial()``); model variables missing from the bundle
-    always raise."""
+    always raise.  with_momentum: also return the SGD momentum slots ({name: tensor}).  with_slots=("momentum", "m",
+    "v"): return (variables, {slot kind: {name: tensor}}, {optimizer hyper-parameter: value}) -- everything the
+    reference's `model.load_weights(latest)` (train.py:131-136) restores of the optimizer."""
     prefix = resolve_prefix(path)
     header, entries = read_index(prefix + ".index")
     n_shards = header.get("num_shards", 1)
@@ -375,18 +377,33 @@ def read_checkpoint(path: str, specs: Dict[str, object], expect_partial: bool = 
     if missing:
         raise KeyError(f"{len(missing)} model variables missing from {prefix}: {missing[:4]}...")
     owned = {n + SUFFIX for n in specs}
-    if with_momentum:   # train.py:135 loads the optimizer slots too
-        owned |= {f"{n}/.OPTIMIZER_SLOT/optimizer/momentum{SUFFIX}" for n in specs}
+    slot_kinds = tuple(with_slots) + (("momentum",) if with_momentum and "momentum" not in with_slots else ())
+    for sk in slot_kinds:   # train.py:135 loads the optimizer slots too
+        owned |= {f"{n}/.OPTIMIZER_SLOT/optimizer/{sk}{SUFFIX}" for n in specs}
     extra = [k for k in entries if k not in owned]
     if extra and not expect_partial:
         raise KeyError(f"{len(extra)} checkpoint keys unused by the model: {extra[:4]}...")
-    mom = {}
-    if with_momentum:
+    slots = {sk: {} for sk in slot_kinds}
+    for sk in slot_kinds:
         for name, spec in specs.items():
-            k = f"{name}/.OPTIMIZER_SLOT/optimizer/momentum{SUFFIX}"
+            k = f"{name}/.OPTIMIZER_SLOT/optimizer/{sk}{SUFFIX}"
             if k in entries:
-                mom[name] = fetch(k, spec)
-        return out, mom
+                slots[sk][name] = fetch(k, spec)
+    if with_slots:
+        hyper = {}
+        for k, e in entries.items():      # optimizer/<hyper>/.ATTRIBUTES/VARIABLE_VALUE scalars (iter int64, the rest float32)
+            if k.startswith("optimizer/") and k.endswith(SUFFIX) and not e.shape:
+                raw = bytes(shard(e.shard_id)[e.offset:e.offset + e.size])
+                if verify_crc and mask_crc(crc32c(raw)) != e.crc32c:
+                    raise ValueError(f"{k}: CRC32C mismatch")
+                h = k[len("optimizer/"):-len(SUFFIX)]
+                if e.dtype == DT_INT64:
+                    hyper[h] = struct.unpack("<q", raw)[0]
+                elif e.dtype == DT_FLOAT:
+                    hyper[h] = struct.unpack("<f", raw)[0]
+        return out, slots, hyper
+    if with_momentum:
+        return out, slots["momentum"]
     return out
 
 
@@ -407,6 +424,10 @@ def read_checkpoint(path: str, specs: Dict[str, object], expect_partial: bool = 
 # ------------------------------------------------------------------------------------------------
 OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
 OPTIMIZER_HYPER = ("decay", "iter", "learning_rate", "momentum")   # optimizer/<name>/.ATTRIBUTES/VARIABLE_VALUE in the released bundles
+# tf.keras.optimizers.Adam (OptimizerV2, TF 2.4): hyper variables set with _set_hyper -- learning_rate, decay, beta_1, beta_2
+# (epsilon and amsgrad are Python attributes, not variables) -- plus `iter`; slot variables "m" and "v" per trainable
+# variable.  [TF-3p]: the reference ships no Adam checkpoint to compare with.
+ADAM_HYPER = ("beta_1", "beta_2", "decay", "iter", "learning_rate")
 
 
 def _pb_len(field: int, payload: bytes) -> bytes:
@@ -417,11 +438,13 @@ def _pb_int(field: int, v: int) -> bytes:
     return _put_varint((field << 3) | 0) + _put_varint(v)
 
 
-def build_object_graph(var_names: List[str], slot_names: List[str], slot: str = "momentum",
+def build_object_graph(var_names: List[str], slot_names, slot: str = "momentum",
                        hyper: Tuple[str, ...] = OPTIMIZER_HYPER) -> bytes:
     """Serialized TrackableObjectGraph for model variables `var_names` (object paths without the VARIABLE_VALUE suffix),
     an `optimizer` child of the root with its hyper-parameter variables and one `slot` variable per entry of
-    `slot_names`.  Node 0 is the root; nodes are numbered in breadth-first order."""
+    `slot_names` (a list of variable names for the one slot kind `slot`, or {slot kind: [variable names]} -- Adam has
+    two, "m" and "v").  Node 0 is the root; nodes are numbered in breadth-first order."""
+    slot_map = slot_names if isinstance(slot_names, dict) else ({slot: list(slot_names)} if slot_names else {})
     children: List[Dict[str, int]] = [{}]          # node -> {local name: node id}
     attr_key: Dict[int, str] = {}                  # variable node -> checkpoint key
     full_name: Dict[int, str] = {}
@@ -443,19 +466,20 @@ def build_object_graph(var_names: List[str], slot_names: List[str], slot: str = 
         nid = node_of(name)
         attr_key[nid] = name + SUFFIX
         full_name[nid] = name
-    slots: List[Tuple[int, int]] = []
-    if hyper or slot_names:
+    slots: List[Tuple[int, int, str]] = []
+    if hyper or slot_map:
         for h in hyper:
             nid = node_of("optimizer/" + h)
             attr_key[nid] = f"optimizer/{h}{SUFFIX}"
             full_name[nid] = h
         opt = node_of("optimizer")
-        for name in slot_names:       # slot variables hang off the optimizer node by reference, not by a named edge
-            children.append({})
-            sid = len(children) - 1
-            attr_key[sid] = f"{name}/.OPTIMIZER_SLOT/optimizer/{slot}{SUFFIX}"
-            full_name[sid] = f"{name}/{slot}"
-            slots.append((node_of(name, create=False), sid))
+        for kind, names in slot_map.items():
+            for name in names:        # slot variables hang off the optimizer node by reference, not by a named edge
+                children.append({})
+                sid = len(children) - 1
+                attr_key[sid] = f"{name}/.OPTIMIZER_SLOT/optimizer/{kind}{SUFFIX}"
+                full_name[sid] = f"{name}/{kind}"
+                slots.append((node_of(name, create=False), sid, kind))
     else:
         opt = -1
     # breadth-first renumbering from the root (the order TF writes; restore does not depend on it)
@@ -467,7 +491,7 @@ def build_object_graph(var_names: List[str], slot_names: List[str], slot: str = 
                 seen.add(c)
                 order.append(c)
         i += 1
-    order += [sid for _, sid in slots]
+    order += [sid for _, sid, _ in slots]
     new_id = {old: new for new, old in enumerate(order)}
     out = bytearray()
     for old in order:
@@ -478,8 +502,8 @@ def build_object_graph(var_names: List[str], slot_names: List[str], slot: str = 
             node += _pb_len(2, _pb_len(1, b"VARIABLE_VALUE") + _pb_len(2, full_name[old].encode()) +
                             _pb_len(3, attr_key[old].encode()))
         if old == opt:
-            for var, sid in slots:
-                node += _pb_len(3, _pb_int(1, new_id[var]) + _pb_len(2, slot.encode()) + _pb_int(3, new_id[sid]))
+            for var, sid, kind in slots:
+                node += _pb_len(3, _pb_int(1, new_id[var]) + _pb_len(2, kind.encode()) + _pb_int(3, new_id[sid]))
         out += _pb_len(1, bytes(node))
     return bytes(out)
 
@@ -534,30 +558,41 @@ def read_object_graph(path: str) -> List[dict]:
 
 
 def write_checkpoint(prefix: str, state: Dict[str, torch.Tensor], specs: Dict[str, object],
-                     momentum: Optional[Dict[str, torch.Tensor]] = None, optimizer_hyper: Optional[Dict[str, float]] = None):
+                     momentum: Optional[Dict[str, torch.Tensor]] = None, optimizer_hyper: Optional[Dict[str, float]] = None,
+                     slots: Optional[Dict[str, Dict[str, torch.Tensor]]] = None):
     """Write ``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` + the ``checkpoint`` state file with the
     reference's keys and TF layouts, including the ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry Keras' object-based
     ``load_weights`` restores by (build_object_graph) and the optimizer's hyper-parameter variables
-    (``optimizer/{iter,learning_rate,momentum,decay}``: `optimizer_hyper`, defaults 0 / 0.0)."""
+    (``optimizer/{iter,learning_rate,momentum,decay}``: `optimizer_hyper`, defaults 0 / 0.0).  `slots` = {slot kind:
+    {variable: tensor}} writes other slot variables than SGD's `momentum`: with the kinds "m" / "v" the optimizer is
+    written as Keras' Adam (hyper variables ADAM_HYPER)."""
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     items = []
-    slot_names = []
+    slots = dict(slots or {})
+    if momentum:
+        slots["momentum"] = momentum
+    slot_names = {kind: [] for kind in slots}
     for name, spec in specs.items():
         items.append((name + SUFFIX, to_tf(spec, state[name].detach().float().cpu())))
-        if momentum and name in momentum:
-            items.append((f"{name}/.OPTIMIZER_SLOT/optimizer/momentum{SUFFIX}",
-                          to_tf(spec, momentum[name].detach().float().cpu())))
-            slot_names.append(name)
-    hyper = dict(decay=0.0, iter=0, learning_rate=0.0, momentum=0.0)
-    hyper.update(optimizer_hyper or {})
+        for kind, tensors in slots.items():
+            if name in tensors:
+                items.append((f"{name}/.OPTIMIZER_SLOT/optimizer/{kind}{SUFFIX}",
+                              to_tf(spec, tensors[name].detach().float().cpu())))
+                slot_names[kind].append(name)
+    slot_names = {k: v for k, v in slot_names.items() if v}
+    adam = "m" in slots or "v" in slots
+    hyper_names = ADAM_HYPER if adam else OPTIMIZER_HYPER
+    hyper = dict(decay=0.0, iter=0, learning_rate=0.0, beta_1=0.9, beta_2=0.999) if adam else \
+        dict(decay=0.0, iter=0, learning_rate=0.0, momentum=0.0)
+    hyper.update({k: v for k, v in (optimizer_hyper or {}).items() if k in hyper_names})
     raw_items = []     # (key, dtype, shape, raw bytes, masked crc)
     for key, t in items:
         raw = t.numpy().astype("<f4").tobytes()
         raw_items.append((key, DT_FLOAT, tuple(t.shape), raw, mask_crc(crc32c(raw))))
-    for h in OPTIMIZER_HYPER:
+    for h in hyper_names:
         raw = struct.pack("<q", int(hyper[h])) if h == "iter" else struct.pack("<f", float(hyper[h]))
         raw_items.append((f"optimizer/{h}{SUFFIX}", DT_INT64 if h == "iter" else DT_FLOAT, (), raw, mask_crc(crc32c(raw))))
-    graph = build_object_graph(list(specs), slot_names)
+    graph = build_object_graph(list(specs), slot_names, hyper=hyper_names)
     graw, gcrc = _string_tensor_bytes(graph)
     raw_items.append((OBJECT_GRAPH_KEY, DT_STRING, (), graw, gcrc))
     raw_items.sort(key=lambda it: it[0])
@@ -575,19 +610,39 @@ def write_checkpoint(prefix: str, state: Dict[str, torch.Tensor], specs: Dict[st
     return prefix
 
 
+def _flat_slot(model, flat, k):
+    o = model._offsets[k]
+    return flat[o:o + model.params[k].numel()].view(model.params[k].shape)
+
+
 def load_tf_checkpoint(model, path, expect_partial=True):
-    sd, mom = read_checkpoint(path, model.specs, expect_partial=expect_partial, with_momentum=True)
+    """Variables + optimizer state (reference train.py:131-136 `model.load_weights(latest)`): SGD `momentum` slots or
+    Adam `m` / `v` slots into the model's flat slot buffers; the optimizer's hyper-parameter variables (`iter`, ...) are
+    left in `model.optimizer_state` for the trainer (Trainer.resume restores its step counter from `iter`)."""
+    sd, slots, hyper = read_checkpoint(path, model.specs, expect_partial=expect_partial, with_slots=("momentum", "m", "v"))
     model.load_state_dict(sd)
-    for k, v in mom.items():
+    first = slots["m"] or slots["momentum"]
+    for k, v in first.items():
         if k in model.grads:
-            o = model._offsets[k]
-            model.flat_velocity[o:o + v.numel()].copy_(v.reshape(-1))
+            _flat_slot(model, model.flat_velocity, k).copy_(v)
+    if slots["v"]:
+        if getattr(model, "flat_second", None) is None:
+            model.flat_second = torch.zeros_like(model.flat_velocity)
+        for k, v in slots["v"].items():
+            if k in model.grads:
+                _flat_slot(model, model.flat_second, k).copy_(v)
+    model.optimizer_state = dict(hyper=hyper, kind=("adam" if slots["m"] or slots["v"] else "sgd" if slots["momentum"] else None))
     return model
 
 
-def save_tf_checkpoint(model, prefix, optimizer_hyper=None):
-    mom = {}
-    for k in model.grads:
-        o = model._offsets[k]
-        mom[k] = model.flat_velocity[o:o + model.params[k].numel()].view(model.params[k].shape)
-    return write_checkpoint(prefix, model.state_dict(), model.specs, momentum=mom, optimizer_hyper=optimizer_hyper)
+def save_tf_checkpoint(model, prefix, optimizer_hyper=None, optimizer="sgd"):
+    """optimizer="sgd": the first slot buffer is written as Keras SGD's `momentum` slots (the released bundles' layout);
+    "adam": both moments as Keras Adam's `m` / `v` slots with Adam's hyper variables."""
+    first = {k: _flat_slot(model, model.flat_velocity, k) for k in model.grads}
+    if optimizer == "adam":
+        second = getattr(model, "flat_second", None)
+        if second is None:
+            second = torch.zeros_like(model.flat_velocity)
+        return write_checkpoint(prefix, model.state_dict(), model.specs, optimizer_hyper=optimizer_hyper,
+                                slots={"m": first, "v": {k: _flat_slot(model, second, k) for k in model.grads}})
+    return write_checkpoint(prefix, model.state_dict(), model.specs, momentum=first, optimizer_hyper=optimizer_hyper)

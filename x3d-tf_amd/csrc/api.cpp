@@ -17,7 +17,7 @@ struct X3dDescribe { char* out; int cap; };
 thread_local X3dDescribe x3d_describe = {nullptr, 0};
 
 extern "C" const char* x3d_last_error(void) { return g_err; }
-extern "C" int x3d_version(void) { return 111; }   // 111: relu_scale_shift argument of x3d_dwt_bwd; 110: X3D_F16, x3d_pw_kernel_name
+extern "C" int x3d_version(void) { return X3D_ABI_VERSION; }   // history: include/x3d_hip.h
 
 // CRC32C (Castagnoli) for the TF tensor-bundle checkpoint reader/writer (host code; not part of the
 // device hot path).  Slicing-by-1 table; 15 MB checkpoints take ~40 ms.

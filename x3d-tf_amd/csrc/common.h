@@ -287,7 +287,9 @@ static inline bool strided_odd_enabled() {
 static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
   if ((P % 8) != 0 && !pw_ragged_rows(P, 2)) return 0;   // (P % 8 != 0: the RAG instantiations; P % GV == 0 since GV | Wo)
   for (int gv = 4; gv >= 1; gv >>= 1)
-    if ((Wo % gv) == 0 && ((W % (2 * gv)) == 0 || ((W & 1) && strided_odd_enabled())) && ((uintptr_t)x % (4 * gv)) == 0) return gv;
+    // odd W: the row's last group is loaded one element early -- it must not also be the row's first group (Wo == gv: the
+    // load of the tensor's very first row would start 2 bytes before the allocation; 7 -> 4 then takes gv = 2, 3 -> 2 gv = 1)
+    if ((Wo % gv) == 0 && ((W % (2 * gv)) == 0 || ((W & 1) && Wo > gv && strided_odd_enabled())) && ((uintptr_t)x % (4 * gv)) == 0) return gv;
   return 0;
 }
 

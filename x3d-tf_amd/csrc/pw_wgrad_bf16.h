@@ -489,8 +489,12 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
   if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
   a.steps_per_block = (int)spb;
+#ifdef X3D_EXPERIMENTS   // result-changing timing hooks exist only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)
   static const char* nf_env = getenv("X3D_PW_WG_NOFLUSH");   // timing experiment: how much of the run time is the atomic flush
   a.noflush = (nf_env && atoi(nf_env) == 1) ? 1 : 0;
+#else
+  a.noflush = 0;
+#endif
   long long gx = ceil_div_ll(total_steps, spb);
   if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(NTHR), lds, st, a);

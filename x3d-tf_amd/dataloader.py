@@ -167,18 +167,38 @@ class InputReader:
 
     Additional arguments (the reference gets them from TF's globals): `device`, `dtype` (the compute type clips are cast
     to under mixed precision, dataloader.py:111-113), `seed`, `decoder` (path -> uint8 [F, H, W, 3] array for the
-    non-TFRecord path), `num_workers` (decode threads), `prefetch` (batches kept ready)."""
+    non-TFRecord path), `num_workers` (decode threads), `prefetch` (batches kept ready).
+
+    Data parallelism (`rank`, `world`; default: the torchrun environment).  The reference feeds ONE dataset of global
+    batches to MirroredStrategy, which splits each batch over the replicas (train.py:145-152, utils.py:160-167).  Here
+    every process owns its reader, so the split is made at the source: `batch_size` stays the reference's GLOBAL batch
+    (cfg.TRAIN.BATCH_SIZE), rank r keeps records r, r + world, ... of the interleaved record stream (disjoint shards that
+    cover the dataset) and yields batch_size // world clips per step -- `Trainer.fit`'s DATASET_SIZE // BATCH_SIZE steps
+    are then one pass over the data, and the lr schedule sees the reference's epochs.  The file order is drawn from a
+    generator seeded by `seed` alone (identical on every rank, or the shards would overlap: with world > 1 an unset seed
+    becomes 0); shuffle buffer and augmentation draws use (seed, rank)."""
 
     def __init__(self, cfg, is_training: bool, use_tfrecord: bool, mixed_precision: bool = False, device=None,
                  dtype: torch.dtype = torch.float32, seed: Optional[int] = None, decoder: Optional[Callable] = None,
-                 num_workers: int = 4, prefetch: int = 2):
+                 num_workers: int = 4, prefetch: int = 2, rank: Optional[int] = None, world: Optional[int] = None):
         self._cfg = cfg
         self._is_training = bool(is_training)
         self._use_tfrecord = bool(use_tfrecord)
         self._mixed_prec = bool(mixed_precision)
         self._device = torch.device(device if device is not None else "cuda")
         self._dtype = dtype if mixed_precision else torch.float32
-        self._rng = np.random.default_rng(seed)
+        if rank is None or world is None:
+            from .dist import env_world
+            env_rank, _, env_size = env_world()
+            rank = env_rank if rank is None else rank
+            world = env_size if world is None else world
+        self._rank, self._world = int(rank), max(1, int(world))
+        if not 0 <= self._rank < self._world:
+            raise ValueError(f"rank {rank} outside [0, {world})")
+        if self._world > 1 and seed is None:
+            seed = 0
+        self._rng_files = np.random.default_rng(seed)                       # the same stream on every rank
+        self._rng = np.random.default_rng(seed if self._world == 1 else [int(seed), self._rank])
         self._gen = torch.Generator()
         self._gen.manual_seed(int(self._rng.integers(0, 2 ** 31)))
         self._decoder = decoder
@@ -231,7 +251,7 @@ class InputReader:
             raise FileNotFoundError(f"no files match {file_pattern}")
         if self._use_tfrecord:
             if self._is_training:
-                files = [files[i] for i in self._rng.permutation(len(files))]     # list_files(shuffle=True)
+                files = [files[i] for i in self._rng_files.permutation(len(files))]     # list_files(shuffle=True)
             its = [read_tfrecords(f) for f in files]
 
             def interleave():                    # cycle over the open files, one record each (dataloader.py:149-155)
@@ -242,14 +262,28 @@ class InputReader:
                             yield next(it)
                         except StopIteration:
                             live.remove(it)
-            recs = interleave()
+            recs = self._shard(interleave())
             if self._is_training:
                 recs = self._shuffle(recs, batch_size * 16 if batch_size else 1024)
             return recs
         lines = [ln for f in files for ln in open(f).read().splitlines() if ln.strip()]   # TextLineDataset(...).cache()
         if self._is_training:
-            return self._shuffle(iter(lines), max(int(self._cfg.TRAIN.DATASET_SIZE), 1))
-        return iter(lines)
+            return self._shuffle(self._shard(iter(lines)), max(int(self._cfg.TRAIN.DATASET_SIZE) // self._world, 1))
+        return self._shard(iter(lines))
+
+    def _shard(self, it: Iterator) -> Iterator:
+        """this rank's records of the (rank-independent) record stream: r, r + world, ... (tf.data's `shard`)"""
+        if self._world == 1:
+            return it
+        return (x for i, x in enumerate(it) if i % self._world == self._rank)
+
+    def local_batch(self, batch_size: Optional[int]) -> Optional[int]:
+        """clips (videos in evaluation) per step on this rank for the reference's global `batch_size`"""
+        if batch_size is None or self._world == 1:
+            return batch_size
+        if batch_size % self._world:
+            raise ValueError(f"global batch {batch_size} is not divisible by {self._world} replicas")
+        return batch_size // self._world
 
     def _decoded(self, recs_factory: Callable[[], Iterator]) -> Iterator[Tuple[np.ndarray, int]]:
         fn = self.parse_and_decode if self._use_tfrecord else self.decode_video
@@ -296,7 +330,9 @@ class InputReader:
         # drop_remainder=True (dataloader.py:186): a trailing partial batch is not emitted
 
     def __call__(self, file_pattern: str, batch_size: Optional[int] = None) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
-        """dataloader.py:126-197.  Iterate to get batches; a background thread keeps `prefetch` of them ready."""
+        """dataloader.py:126-197.  Iterate to get batches; a background thread keeps `prefetch` of them ready.
+        `batch_size` is the GLOBAL batch; with world > 1 this rank yields its batch_size // world share (class docstring)."""
+        batch_size = self.local_batch(batch_size)
         q: "queue.Queue" = queue.Queue(self._prefetch)
         stop = threading.Event()
         END = object()

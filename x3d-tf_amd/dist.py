@@ -27,6 +27,46 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def visible_gpu_count(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes", dev_root: str = "/dev/dri") -> Optional[int]:
+    """GPUs this process could open, counted WITHOUT loading the HIP / HSA runtime: the KFD topology in sysfs (nodes with
+    simd_count > 0 whose render node exists and is accessible), then the *_VISIBLE_DEVICES filters.  None when the
+    topology cannot be read (no amdgpu driver in this namespace) -- callers then leave the check to the ranks.
+
+    For a launcher parent: torch.cuda.device_count() falls through to hipGetDeviceCount when amdsmi is not importable,
+    which opens /dev/kfd, and a process that initialised the GPU must not fork-exec its ranks on this pool."""
+    try:
+        nodes = sorted(os.listdir(sysfs_root), key=lambda d: (len(d), d))
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(sysfs_root, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue            # a node this cgroup may not read is a device it may not use
+        if int(props.get("simd_count", "0")) <= 0:
+            continue            # CPU node
+        minor = props.get("drm_render_minor")
+        if minor is not None and int(minor) > 0:
+            if not os.access(os.path.join(dev_root, f"renderD{int(minor)}"), os.R_OK | os.W_OK):
+                continue
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None:
+            continue
+        ids = [t.strip() for t in v.split(",") if t.strip()]
+        k = 0
+        for t in ids:           # the runtime stops at the first invalid entry
+            if t.startswith("GPU-") or (t.lstrip("-").isdigit() and 0 <= int(t) < n):
+                k += 1
+            else:
+                break
+        n = min(n, k)
+    return n
+
+
 def local_device(local_rank: int) -> int:
     """Device index of a local rank: one GPU per rank; ranks wrap around only in a gloo rehearsal."""
     n = torch.cuda.device_count()

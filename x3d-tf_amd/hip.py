@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3d_hip.so")
 
+ABI_VERSION = 120   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -159,6 +160,11 @@ def load(path=None):
             f"{p} not found: build it with `python x3d-tf_amd/build.py` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the X3D hot path.")
     lib = C.CDLL(p)
+    lib.x3d_version.restype = _i
+    have = int(lib.x3d_version())
+    if have != ABI_VERSION:     # a stale .so (they ship out of band, git-ignored) would take shifted arguments silently
+        raise X3DHipError(f"{p} has ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+                          "(`python x3d-tf_amd/build.py`)")
     for name, (argtypes, restype) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes

@@ -480,9 +480,9 @@ class X3D:
         from .checkpoint import load_tf_checkpoint
         return load_tf_checkpoint(self, path, expect_partial=expect_partial)
 
-    def save_weights(self, prefix, optimizer_hyper=None):
+    def save_weights(self, prefix, optimizer_hyper=None, optimizer="sgd"):
         from .checkpoint import save_tf_checkpoint
-        return save_tf_checkpoint(self, prefix, optimizer_hyper)
+        return save_tf_checkpoint(self, prefix, optimizer_hyper, optimizer)
 
     # ---------------------------------------------------------------------------------------------
     # plan construction

@@ -98,8 +98,10 @@ class Trainer:
         with its LearningRateScheduler (per-epoch `lr_schedule`, train.py:114-125) and ModelCheckpoint (`ckpt-{epoch}`
         after every epoch, utils.py:128-132) callbacks -- nothing else of the Keras harness (TensorBoard / wandb callbacks
         are out of scope).  `dataset`: an iterator of (clips, labels) batches, e.g. `dataloader.InputReader(cfg, True,
-        True)(pattern, cfg.TRAIN.BATCH_SIZE)` (infinite in training mode, like `dataset.repeat()`).  Returns the per-epoch
-        mean losses."""
+        True)(pattern, cfg.TRAIN.BATCH_SIZE)` (infinite in training mode, like `dataset.repeat()`; under torchrun the reader
+        shards the records by rank and yields BATCH_SIZE // world clips per step, so `steps_per_epoch` = DATASET_SIZE //
+        BATCH_SIZE is one pass over the data on every world size, as with MirroredStrategy).  Returns the per-epoch mean
+        losses."""
         tr = self.cfg.TRAIN
         epochs = int(tr.EPOCHS if epochs is None else epochs)
         steps = int(steps_per_epoch if steps_per_epoch is not None else tr.DATASET_SIZE // tr.BATCH_SIZE)
@@ -148,15 +150,20 @@ class Trainer:
 
     # -- checkpoints in the reference's layout (utils.py:128-132 ModelCheckpoint 'ckpt-{epoch:d}', train.py:131-136) --
     def save_checkpoint(self, model_dir: str, epoch: int) -> str:
-        """Writes `<model_dir>/ckpt-<epoch>` as a TF tensor bundle -- weights, SGD momentum slots, the optimizer's
-        hyper-parameter variables and the `_CHECKPOINTABLE_OBJECT_GRAPH` Keras' `load_weights` restores by -- and the
-        `checkpoint` state file, so that the reference's `tf.train.latest_checkpoint(model_dir)` finds it.  (Adam's
-        second-moment slots are not written: only the SGD branch round-trips its optimizer state.)"""
+        """Writes `<model_dir>/ckpt-<epoch>` as a TF tensor bundle -- weights, the optimizer's slot variables (SGD:
+        `momentum`; Adam: `m` and `v`), its hyper-parameter variables (`iter`, `learning_rate`, `decay` + `momentum` |
+        `beta_1`, `beta_2`) and the `_CHECKPOINTABLE_OBJECT_GRAPH` Keras' `load_weights` restores by -- and the
+        `checkpoint` state file, so that the reference's `tf.train.latest_checkpoint(model_dir)` finds it (ModelCheckpoint
+        saves the whole optimizer, utils.py:128-132)."""
         import os
         os.makedirs(model_dir, exist_ok=True)
         prefix = os.path.join(model_dir, f"ckpt-{int(epoch)}")
-        self.model.save_weights(prefix, optimizer_hyper=dict(iter=self.opt_step, momentum=self.momentum,
-                                                             learning_rate=lr_schedule(self.epoch, self.cfg), decay=0.0))
+        hyper = dict(iter=self.opt_step, learning_rate=lr_schedule(self.epoch, self.cfg), decay=0.0)
+        if self.optimizer == "adam":
+            hyper.update(beta_1=0.9, beta_2=0.999)
+        else:
+            hyper.update(momentum=self.momentum)
+        self.model.save_weights(prefix, optimizer_hyper=hyper, optimizer=self.optimizer)
         return prefix
 
     def resume(self, model_dir: str) -> int:
@@ -167,7 +174,23 @@ class Trainer:
         path = latest_checkpoint(model_dir)
         if not path:
             return 0
-        self.model.load_weights(path)   # weights + momentum slots; unknown keys tolerated as Keras does (warning only)
+        m = self.model
+        m.load_weights(path)   # weights + optimizer slots; unknown keys tolerated as Keras does (warning only)
+        st = getattr(m, "optimizer_state", None) or {}
+        kind = st.get("kind")
+        if kind is not None and kind != self.optimizer:
+            # a checkpoint written by the other optimizer branch: Keras restores the variables and leaves the new
+            # optimizer's slots at their initial value -- never reuse SGD momentum as Adam's first moment or vice versa
+            m.flat_velocity.zero_()
+            if getattr(m, "flat_second", None) is not None:
+                m.flat_second.zero_()
+            self.opt_step = 0
+        else:
+            # optimizer/iter: Adam's bias correction continues from the saved step count
+            self.opt_step = int(st.get("hyper", {}).get("iter", 0))
+            if self.optimizer == "adam" and kind is None:
+                m.flat_velocity.zero_()
+                self.opt_step = 0
         self.epoch = int(os.path.basename(path).split("-")[1])
         return self.epoch
 
