@@ -15,6 +15,8 @@ Extra objects on the JSON line:
                 events on the launch stream inside the timed region; peak 8 TB/s.
   kernels       the same figure for every depthwise instantiation launched.
   roofline_model  BASELINE.md's whole-step figure: clips/s * 1.262 GB / 8 TB/s.
+  mfma_util     MFMA utilisation of the pointwise convs (north_star's second figure): their FLOPs over their HIP-event
+                time in three extra steps after the timed region, against the dense 16-bit matrix-core peak.
   cpu_baseline  the CPU oracle (a PyTorch-CPU restatement of the reference graph; TensorFlow is not
                 available) timed on the host cores over a bounded sample of the same workload.
 """
@@ -38,6 +40,7 @@ from x3d_tf_amd import dist as xdist  # noqa: E402
 
 CLIP = {"XS": (4, 160), "S": (13, 160), "M": (16, 224), "L": (16, 312), "XL": (16, 312)}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 matrix-core peak (MI355X_MICROARCH.md; the sparse headline figure is 2x this)
 
 
 def dw_key(pl, lst, i):
@@ -115,6 +118,60 @@ class KernelTimer:
                             achieved_GBs=a["bytes"] / (a["ms"] * 1e-3) / 1e9))
         out.sort(key=lambda d: -d["total_ms"])
         return out
+
+
+PW_ENTRIES = ("x3d_pw_fwd", "x3d_pw_dgrad", "x3d_pw_wgrad", "x3d_pw_bwd")
+
+
+def mfma_utilisation(model, pl, trainer, clips, labels, lr, steps=3):
+    """north_star's second figure: MFMA utilisation of the pointwise convs.  Every pointwise launch of `steps` extra steps
+    (AFTER the timed region) is bracketed by HIP events on the launch stream; FLOPs = 2 * Cin * Cout * output points per
+    GEMM (the fused backward x3d_pw_bwd is two GEMMs), over the dense 16-bit matrix-core peak."""
+    slots = {}
+    for lname, lst in (("fwd", pl.fwd), ("bwd", pl.bwd)):
+        for i, item in enumerate(lst):
+            if item is None or item[0] not in PW_ENTRIES:
+                continue
+            st = pl.structs[(id(lst), i)]
+            s_ = getattr(st, "stride", 1) or 1
+            ho, wo = -(-st.H // s_), -(-st.W // s_)
+            gemms = 2 if item[0] == "x3d_pw_bwd" else 1
+            slots[(lname, i)] = 2.0 * st.Cin * st.Cout * st.N * st.T * ho * wo * gemms
+    events = []
+    orig_fwd = pl.fwd
+    prev_run = pl.run
+
+    def run(lst, start=0, stop=None):
+        lname = "fwd" if lst is orig_fwd else "bwd"
+        stream = torch.cuda.current_stream().cuda_stream
+        for i in range(start, len(lst) if stop is None else stop):
+            name, fn, args = lst[i]
+            fl = slots.get((lname, i))
+            if fl is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, stream)
+                e1.record()
+                events.append((fl, e0, e1))
+            else:
+                rc = fn(*args, stream)
+            if rc != 0:
+                from x3d_tf_amd import hip
+                hip.check(rc, name)
+    pl.run = run
+    try:
+        for _ in range(steps):
+            trainer.step(clips, labels, lr)
+        torch.cuda.synchronize()
+    finally:
+        pl.run = prev_run
+    ms = sum(e0.elapsed_time(e1) for _, e0, e1 in events)
+    flops = sum(fl for fl, _, _ in events)
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"kernels": "pointwise convs (x3d_pw_fwd / dgrad / wgrad / bwd): %d launches per step" % (len(events) // max(steps, 1)),
+            "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+            "flop_per_step": flops / steps, "ms_per_step": ms / steps,
+            "note": "K, N <= 432 GEMMs moving 2-4 bytes per 2*K flops: HBM-bound by construction, the figure is reported, not optimised for"}
 
 
 def cpu_baseline(variant, seconds_budget=25.0, batch=1):
@@ -224,6 +281,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = xdist.max_over_ranks(elapsed, device)
     loss = float(trainer.loss(pl).item())
+    mfma = mfma_utilisation(model, pl, trainer, clips, labels, lr) if (world == 1 and rank == 0) else None
 
     if rank == 0:
         clips_s = args.steps * B * world / elapsed
@@ -258,6 +316,7 @@ def main():
                 "launches": dom["launches"], "avg_us": dom["avg_us"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
             "kernels": kernels,
+            "mfma_util": mfma,
             "roofline_model": {"bound": "hbm", "achieved": clips_s / world * step_bytes_per_clip / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": clips_s / world * step_bytes_per_clip / 1e9 / HBM_PEAK_GBS,

@@ -67,9 +67,11 @@ int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, i
  * K2  stem temporal depthwise conv: tf.pad(KT/2,0,0) + Conv3D(k=(KT,1,1), groups=C, no bias)
  *     reference model.py:170-175,187-194,205-206.   x,y [N][C][T][HW]; w [C][KT] fp32.
  *     stats [C][2] += (sum, sum of squares) of y as stored.
+ *     INFERENCE epilogue (out_scale_shift [C][2] != NULL; stats must be NULL): y = out_act(s*conv + t) -- the stem's
+ *     BatchNorm folded from the moving statistics + ReLU (model.py:196-200,207-208), so the raw conv output is not stored.
  * ------------------------------------------------------------------------------------------ */
-int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
-                int KT, int dtype, void* stream);
+int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, const float* out_scale_shift, int out_act, int N,
+                int C, int T, int HW, int KT, int dtype, void* stream);
 /* backward of K2 through the stem's BN+ReLU: dY = A*g + B*yraw + C (coef [C][4]), g = grad wrt relu(bn(y)) masked by
  * the sign of bn(y).
  *   relu_scale_shift == NULL : g is already masked (x3d_relu_bn_bwd_reduce wrote it);
@@ -143,6 +145,12 @@ int x3d_bn_bwd_finalize(const double* sums, double count, const float* mean_invs
  *     Input prologue (folded producer BN / SE gate / activation), applied on load:
  *       v = x ; if in_scale_shift: v = s*v + t ; if in_gate: v *= gate[n][ci] ; v = act(v)
  *     Epilogue: y stored raw; stats [Cout][2] += (sum, sumsq) of y as stored (may be NULL).
+ *     INFERENCE epilogue (out_scale_shift != NULL; stats must be NULL): the BatchNorm that follows the conv -- folded from
+ *     the moving statistics, model.py:300-303,368-371 -- and the residual Add + ReLU (model.py:381-392) run on the fp32
+ *     accumulators, so neither the raw conv output nor a separate tail pass touches HBM:
+ *       v = s_o*acc + t_o ; if out_add: v += (out_add_scale_shift ? s_r*add + t_r : add) ; y = out_act(v)
+ *     (`c` conv of a block: out_add = block input (identity) or the raw shortcut conv output with bn_r as
+ *     out_add_scale_shift; out_act = ReLU).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const void* x;               /* [N][Cin][T][H][W] */
@@ -154,6 +162,10 @@ typedef struct {
   int in_act;
   int N, Cin, Cout, T, H, W, stride, dtype;
   const void* w_panel;         /* optional (bf16 path): forward panel from x3d_pw_pack_weights, else NULL */
+  const float* out_scale_shift;     /* [Cout][2] or NULL (training form: raw store + stats) */
+  const void* out_add;              /* [N][Cout][T][Ho][Wo] or NULL */
+  const float* out_add_scale_shift; /* [Cout][2] applied to out_add, or NULL */
+  int out_act;                      /* X3D_ACT_NONE / X3D_ACT_RELU */
 } x3d_pw_fwd_args;
 int x3d_pw_fwd(const x3d_pw_fwd_args* a, void* stream);
 

@@ -51,6 +51,18 @@ PW_FWD_XL = [
     (1, 32, 72, 8, 78, 78, 2, None), (1, 32, 32, 8, 156, 156, 2, None),
 ]
 
+# ---- x3d_pw_fwd with the INFERENCE epilogue (folded BN + residual Add + ReLU on the accumulators): the stride-1 cases above
+# that carry the `c` conv's prologue, with the shortcut alternating between the block input ("identity") and a raw
+# shortcut-conv output with its own BN ("conv"); plus plain BN (+ ReLU) epilogues without a residual.
+#   N, Cin, Cout, T, H, W, prologue, residual, out_act
+PW_FWD_INFER = [(n, ci, co, t, h, w, pro, ("identity", "conv")[i % 2], "relu")
+                for i, (n, ci, co, t, h, w, st, pro) in enumerate(PW_FWD + PW_FWD_XL) if st == 1 and pro == "swish"] + [
+    (2, 24, 54, 4, 12, 12, None, None, "relu"), (1, 48, 108, 13, 5, 5, "relu", None, None), (2, 192, 432, 2, 8, 8, None, "identity", None),
+    (2, 96, 216, 2, 14, 14, None, None, "relu"), (1, 280, 630, 1, 8, 8, None, "conv", "relu"),
+    (1, 54, 24, 2, 20, 20, "swish", "identity", "relu"), (1, 108, 48, 2, 10, 10, "swish", "conv", "relu"),   # fp32 panels of 1 / 2 row tiles
+    (1, 216, 96, 2, 10, 10, "swish", "identity", "relu"), (1, 432, 192, 4, 5, 5, "swish", "identity", "relu"),   # ... 3 / 4 (X3D-XS, config 1)
+]
+
 # ---- x3d_pw_dgrad: N, Cin, Cout, T, H, W  x  epilogue -----------------------------------------------------------------
 PW_DGRAD = [
     (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
@@ -158,6 +170,16 @@ def pw_fwd_struct(shape, dtype, panel):
     return hip.PwFwdArgs(A(), A(), A(), A(), A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, stride, _code(dtype),
                          A() if panel else None)
+
+
+def pw_fwd_infer_struct(shape, dtype, panel):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w, pro, res, oact = shape
+    A = _Addr.new
+    return hip.PwFwdArgs(A(), A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
+                         {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, 1, _code(dtype),
+                         A() if panel else None, A(), A() if res else None, A() if res == "conv" else None,
+                         1 if oact == "relu" else 0)
 
 
 def pw_dgrad_struct(shape, epi, dtype, panel):

@@ -25,6 +25,10 @@ def _kernel_case_names():
             add(S.pw_fwd_struct(shp, dt, False), f"test_pw_fwd[{shp}, {dt}]")
             if half:
                 add(S.pw_fwd_struct(shp, dt, True), f"test_pw_fwd[{shp}, {dt}, panel]")
+        for shp in S.PW_FWD_INFER:
+            add(S.pw_fwd_infer_struct(shp, dt, False), f"test_pw_fwd_infer[{shp}, {dt}]")
+            if half:
+                add(S.pw_fwd_infer_struct(shp, dt, True), f"test_pw_fwd_infer[{shp}, {dt}, panel]")
         for shp in S.PW_DGRAD:
             for epi in S.PW_DGRAD_EPI:
                 add(S.pw_dgrad_struct(shp, epi, dt, False), f"test_pw_dgrad[{shp}, {epi}, {dt}]")
@@ -82,3 +86,40 @@ def test_dry_model_cannot_run():
     pl = m._plan(2, 4, 32, 32, True)
     with pytest.raises(hip.X3DHipError):
         pl.run(pl.fwd)
+
+
+@pytest.mark.parametrize("index", [1, 5])
+def test_inference_plan_is_inference_shaped(index):
+    """BASELINE configs 1 and 5 (eval.py:83-89, model.py:113-127 at training=False): the recorded forward list has no
+    residual-tail pass, no per-layer BatchNorm launch (one batched coefficient launch at the head) and per block exactly
+    a -> b -> [SE] -> [shortcut conv] -> c, the last with the folded BN + Add + ReLU epilogue."""
+    import x3d_tf_amd as x
+    from x3d_tf_amd import dispatch as D
+    from x3d_tf_amd.model import X3D
+    variant, n, t, s, dtype, training, over = D.BASELINE_CONFIGS[index]
+    flat = []
+    for k, v in over.items():
+        flat += [k, v]
+    m = X3D(x.get_config(variant, flat or None), dtype=dtype, device="dry")
+    pl = m._plan(n, t, s, s, training)
+    names = [item[0] for item in pl.fwd]
+    assert names[0] == "x3d_bn_eval_coef_batched" and names.count("x3d_bn_eval_coef_batched") == 1
+    assert not [k for k in names if k.startswith(("x3d_tail", "x3d_bn_finalize"))]
+    assert names[1:3] == ["x3d_stem_s_fwd", "x3d_dwt_fwd"]
+    blocks = m.arch.blocks
+    want = []
+    for b in blocks:
+        want += ["x3d_pw_fwd", "x3d_dw3d_fwd"] + (["x3d_se_fwd"] if b.has_se else []) + \
+                (["x3d_pw_fwd"] if b.has_shortcut_conv else []) + ["x3d_pw_fwd"]
+    assert names[3:3 + len(want)] == want
+    assert names[3 + len(want):] == ["x3d_pw_fwd", "x3d_pool_fwd", "x3d_dense_fwd", "x3d_dense_fwd", "x3d_softmax_xent", "x3d_view_mean"]
+    assert len(want) <= 5 * len(blocks) and sum(3 + b.has_se + b.has_shortcut_conv for b in blocks) == len(want)
+    for B in pl.blocks:                      # the `c` conv carries the epilogue; `a` and the shortcut stay raw
+        assert B.sc.out_scale_shift and B.sc.out_add and B.sc.out_act == 1 and not B.sc.stats
+        assert bool(B.sc.out_add_scale_shift) == bool(B.spec.has_shortcut_conv)
+        assert not B.sa.out_scale_shift
+    # activation buffers are shared between blocks: two block outputs ping-pong
+    ys = {B.y.data_ptr() for B in pl.blocks}
+    assert len(ys) == 2 and len({B.a_raw.data_ptr() for B in pl.blocks}) == 1
+    for prev, cur in zip(pl.blocks, pl.blocks[1:]):
+        assert cur.x.data_ptr() == prev.y.data_ptr() and cur.y.data_ptr() != cur.x.data_ptr()

@@ -99,6 +99,52 @@ def test_pw_fwd(gpu, dtype, shape, panel):
     report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
+@pytest.mark.parametrize("panel", [False, True])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", S.PW_FWD_INFER)
+def test_pw_fwd_infer(gpu, dtype, shape, panel):
+    """x3d_pw_fwd with the inference epilogue (out_scale_shift): y = act(s_o * conv(f(x)) + t_o [+ s_r * add + t_r]) -- the
+    BatchNorm after the conv folded from the moving statistics and the residual Add + ReLU (reference model.py:300-303,
+    368-371, 381-392 at training=False) -- against the oracle's pointwise conv + the same affine arithmetic in fp64."""
+    if panel and dtype == torch.float32:
+        pytest.skip("weight panels exist for the 16-bit storage types only")
+    ops, O = _ops(), _oracle()
+    n, cin, cout, t, h, w, pro, res, oact = shape
+    g = _gen(17)
+    x, xd = rnd((n, cin, t, h, w), dtype, g)
+    wt = torch.randn((cout, cin), generator=g) * 0.2
+    ss = gate = None
+    act = 0
+    xin = xd
+    if pro:
+        ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)], 1)
+        act = 2 if pro == "swish" else 1
+        if pro == "swish":
+            gate = torch.rand((n, cin), generator=g)
+        xin = _affine(x.float(), ss, gate, act)
+    oss = torch.stack([1 + 0.3 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)], 1)
+    ref = _affine(O.pointwise(round_to(xin, dtype), round_to(wt, dtype), 1), oss.double())
+    add = ass = None
+    if res:
+        add, addd = rnd((n, cout, t, h, w), dtype, g)
+        if res == "conv":
+            ass = torch.stack([1 + 0.3 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)], 1)
+            addd = _affine(addd, ass.double())
+        ref = ref + addd
+    if oact == "relu":
+        ref = F.relu(ref)
+    fp = _panels(ops, wt, dtype, gpu)[0] if panel else None
+    dev = lambda v: None if v is None else v.to(gpu)
+    y = ops.pw_fwd(dev(x), dev(wt), in_ss=dev(ss), in_gate=dev(gate), in_act=act, w_panel=fp, out_ss=dev(oss),
+                   out_add=dev(add), out_add_ss=dev(ass), out_act=1 if oact == "relu" else 0)
+    torch.cuda.synchronize()
+    rt, at = tol_gemm(dtype)
+    report("y", y, ref, rt, at * max(ref.abs().max().item(), 1.0))
+    # the training form of the same launch still refuses the epilogue operands it cannot honour
+    with pytest.raises(Exception):
+        ops.pw_fwd(dev(x), dev(wt), stats=torch.zeros((cout, 2), dtype=torch.float64, device=gpu), out_ss=dev(oss))
+
+
 def _dyraw(coef, gd, yd, dtype=None):
     """dYraw = A*g + B*yraw + C (BatchNorm backward folded into the load).  dtype given: evaluated in fp32 like the kernel's
     prologue and rounded to the storage type (the GEMM operand as the matrix cores see it), returned as fp64."""
@@ -221,7 +267,11 @@ def test_pw_bwd_fused(gpu, shape, bf):
 @pytest.mark.parametrize("shape", [(2, 432, 192, 2, 8, 8), (3, 336, 72, 1, 8, 12), (2, 440, 200, 2, 4, 6),
                                    (3, 192, 432, 8, 7, 7), (2, 420, 180, 1, 8, 8), (40, 432, 192, 8, 7, 7),
                                    (2, 216, 96, 2, 14, 14), (2, 96, 216, 2, 14, 14), (24, 216, 96, 8, 14, 14), (2, 210, 90, 1, 8, 8),
-                                   (3, 96, 432, 4, 14, 14), (20, 96, 432, 16, 14, 14)])   # (forward: K = 96 -> M = 432)   # stage-5 block 0: dgrad K = 432 -> M = 96 with the strided add
+                                   (3, 96, 432, 4, 14, 14), (20, 96, 432, 16, 14, 14),   # (forward: K = 96 -> M = 432)
+                                   # X3D-XL widths on the weights-stationary kernel (row blocks sliced over blockIdx.y; K = 630 on four waves)
+                                   (3, 630, 280, 2, 10, 10), (20, 630, 280, 16, 10, 10), (3, 280, 630, 2, 10, 10), (2, 306, 136, 4, 20, 20),
+                                   (2, 136, 306, 4, 20, 20), (2, 162, 72, 2, 39, 39), (2, 72, 162, 4, 20, 20), (2, 136, 630, 2, 20, 20),
+                                   (2, 72, 306, 2, 20, 20), (9, 306, 136, 16, 20, 20)])   # stage-5 block 0: dgrad K = 432 -> M = 96 with the strided add
 @pytest.mark.parametrize("bf", HALF)
 def test_pw_weights_streamed_path(gpu, shape, bf):
     """Deep, narrow layers (stage-5 shapes) with a packed panel run the weights-streamed 32-point-tile kernel
@@ -477,6 +527,13 @@ def test_stem(gpu, dtype, shape):
     rs, as_ = tol_store(dtype)
     report("conv_t", yt, ref_t, rs, as_ * ref_t.abs().max().item())
     report("stats", stats, _stats_ref(yt.float().cpu(), dtype), 1e-5, 1e-4)
+    # inference epilogue: the stem's BatchNorm (moving statistics) + ReLU on the accumulator, no raw tensor stored
+    oss = torch.stack([1 + 0.3 * torch.randn(c1, generator=g_), 0.3 * torch.randn(c1, generator=g_)], 1)
+    yi = ops.dwt_fwd(ys, wt.to(gpu), out_ss=oss.to(gpu), out_act=1)
+    ref_i = F.relu(_affine(ref_t, oss.double()))
+    report("conv_t + bn + relu", yi, ref_i, rs, as_ * max(1.0, ref_i.abs().max().item()))
+    yi0 = ops.dwt_fwd(ys, wt.to(gpu), out_ss=oss.to(gpu), out_act=0)
+    report("conv_t + bn", yi0, _affine(ref_t, oss.double()), rs, as_ * max(1.0, ref_i.abs().max().item()))
     # backward of conv_t (+BN coefficients) and wgrad of conv_s
     g, gd = rnd(tuple(yt.shape), dtype, g_)
     coef = torch.randn((c1, 4), generator=g_) * 0.5

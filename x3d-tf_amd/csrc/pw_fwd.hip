@@ -4,13 +4,15 @@
 template <typename H>
 static int pw_fwd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st) {
   const int shp_ = pw_wst_shape(a, vec, ovec);       // stage 4 / 5: weights stationary in registers
-  if (const int shp = (shp_ == 5 && pro) ? 0 : shp_)  // (shape 5 with a prologue: 129 VGPRs, one workgroup per CU)
+  if (const int shp = ((shp_ == 5 && pro) || (shp_ >= 6 && pw_wst_shape_has_prologue(shp_) != pro)) ? 0 : shp_)  // (shape 5 with a prologue: 129 VGPRs, one workgroup per CU)
     return pro ? pw_wst_launch<H, PRO_AFFINE, EPI_STATS>(a, shp, st) : pw_wst_launch<H, PRO_NONE, EPI_STATS>(a, shp, st);
   if (pw_ws_applies(a, vec, ovec))   // deep, narrow layers (stage 5): weights streamed, 32-point tiles
     return pro ? pw_ws_launch<H, PRO_AFFINE, EPI_STATS>(a, st) : pw_ws_launch<H, PRO_NONE, EPI_STATS>(a, st);
   return pro ? pw_bf16_launch_vec<H, PRO_AFFINE, EPI_STATS>(a, vec, ovec, st)
              : pw_bf16_launch_vec<H, PRO_NONE, EPI_STATS>(a, vec, ovec, st);
 }
+
+int pw_fwd_bnadd(PwGemmArgs& a, int dtype, int vec, int vec16, int ovec, bool pro, hipStream_t st);   // pw_fwd_infer.hip
 
 extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   X3D_REQUIRE(f && f->x && f->w && f->y, "pw_fwd: null pointer");
@@ -37,6 +39,20 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   const int vec = pick_vec(eb, a.P, f->x);
   const bool pro = f->in_scale_shift != nullptr || f->in_gate != nullptr || f->in_act != X3D_ACT_NONE;
   X3D_REQUIRE(!pro || f->in_scale_shift, "pw_fwd: gate/activation prologue needs in_scale_shift");
+  if (f->out_scale_shift) {      // inference epilogue: folded BN + residual Add + activation on the accumulators
+    X3D_REQUIRE(!f->stats, "pw_fwd: the inference epilogue (out_scale_shift) takes no statistics");
+    X3D_REQUIRE(f->stride == 1, "pw_fwd: the inference epilogue is for stride 1 (the strided shortcut stays raw)");
+    X3D_REQUIRE(f->out_act == X3D_ACT_NONE || f->out_act == X3D_ACT_RELU, "pw_fwd: out_act must be none or ReLU");
+    X3D_REQUIRE(!f->out_add_scale_shift || f->out_add, "pw_fwd: out_add_scale_shift without out_add");
+    a.e_ss = f->out_scale_shift; a.e_ass = f->out_add_scale_shift; a.add = f->out_add; a.eact = f->out_act;
+    int ovec_ = pick_vec(eb, a.P, f->y);
+    if (f->out_add) ovec_ = ovec_ < pick_vec(eb, a.P, f->out_add) ? ovec_ : pick_vec(eb, a.P, f->out_add);
+    int v16 = vec;
+    if (f->dtype != X3D_F32 && ((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->y % 16) == 0 &&
+        (!f->out_add || ((uintptr_t)f->out_add % 16) == 0) && pw_ragged_rows(a.P, eb)) v16 = ovec_ = 8;
+    return pw_fwd_bnadd(a, f->dtype, vec, v16, ovec_, pro, st);
+  }
+  X3D_REQUIRE(!f->out_add && !f->out_add_scale_shift, "pw_fwd: out_add needs out_scale_shift");
   if (f->dtype == X3D_F32)
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);

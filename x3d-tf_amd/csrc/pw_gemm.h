@@ -16,7 +16,8 @@
 
 enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_BNBWD = 2 };
 
-enum { EPI_STATS = 100 };  // forward epilogue: store raw + per-channel statistics
+enum { EPI_STATS = 100,     // forward epilogue (training): store raw + per-channel statistics
+       EPI_BNADD = 101 };   // forward epilogue (inference): y = act(s_o*acc + t_o [+ s_r*add + t_r]) -- folded BN, residual Add + ReLU
 
 struct PwGemmArgs {
   // streamed operand  [N][K][Pin]
@@ -44,7 +45,20 @@ struct PwGemmArgs {
   const float* egate;
   double* nc_sums;
   int eH, eW;          // EPI_ADD_STRIDED: geometry of dx (H, W); add is at ceil(H/2) x ceil(W/2)
+  // EPI_BNADD: per-output-row (scale, shift) [M][2]; `add` [N][M][P] or null with its own optional (scale, shift) [M][2];
+  // eact = X3D_ACT_NONE / X3D_ACT_RELU
+  const float* e_ss;
+  const float* e_ass;
+  int eact;
 };
+
+// EPI_BNADD coefficients of output row m: v = c0*acc + c1 + c2*add
+__device__ __forceinline__ void bnadd_coef(const PwGemmArgs& a, int m, bool ok, float& c0, float& c1, float& c2) {
+  c0 = ok ? a.e_ss[m * 2] : 0.f;
+  c1 = ok ? a.e_ss[m * 2 + 1] : 0.f;
+  c2 = 1.0f;
+  if (ok && a.e_ass) { c2 = a.e_ass[m * 2]; c1 += a.e_ass[m * 2 + 1]; }
+}
 
 // the same in two halves -- raw loads, then the arithmetic -- so that a thread can put ALL its staging loads of a tile in
 // flight before it touches the first value (stage_x below)
@@ -245,6 +259,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
       Em[m * 4 + 2] = (ok && a.egate) ? a.egate[(long long)n * a.M + gm] : 1.0f;
     }
   }
+  if constexpr (EPI == EPI_BNADD) {
+    for (int m = tid; m < BM; m += 256) {
+      float c0, c1, c2;
+      bnadd_coef(a, m0 + m, m0 + m < a.M, c0, c1, c2);
+      Em[m * 4] = c0; Em[m * 4 + 1] = c1; Em[m * 4 + 2] = c2;
+    }
+  }
   if (a.nchunks == 1) { stage_w(0); fill_pk(0); __syncthreads(); }
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -286,14 +307,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
         const long long p = p0 + nt * 32 + r;
         // the epilogue operand (residual / raw depthwise output) of all 16 rows first: inside the loop below every load
         // sat behind the previous row's store (the compiler must assume they alias) and exposed its latency 16 times
-        constexpr bool EPL = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
+        constexpr bool EPL = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD) || (EPI == EPI_BNADD);
         float eop[EPL ? 16 : 1];
         if constexpr (EPL) {
-          const T* esrc = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
+          const T* esrc = (const T*)(EPI == X3D_EPI_SWISH_BWD ? a.braw : a.add);
 #pragma unroll
           for (int j = 0; j < 16; j++) {
             const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-            eop[j] = ((m < a.M) && (p < a.P)) ? to_f<T>(esrc[((long long)n * a.M + m) * a.P + p]) : 0.f;
+            eop[j] = ((m < a.M) && (p < a.P) && esrc) ? to_f<T>(esrc[((long long)n * a.M + m) * a.P + p]) : 0.f;
           }
         }
 #pragma unroll
@@ -311,6 +332,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
             }
           } else if constexpr (EPI == X3D_EPI_STORE) {
             if (ok) ((T*)a.y)[o] = from_f<T>(val);
+          } else if constexpr (EPI == EPI_BNADD) {
+            if (ok) {
+              const float* em = Em + (m - m0) * 4;
+              float v = em[0] * val + em[1] + em[2] * eop[j];
+              if (a.eact == X3D_ACT_RELU) v = fmaxf(v, 0.f);
+              ((T*)a.y)[o] = from_f<T>(v);
+            }
           } else if constexpr (EPI == X3D_EPI_ADD) {
             if (ok) ((T*)a.y)[o] = from_f<T>(val + eop[j]);
           } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {

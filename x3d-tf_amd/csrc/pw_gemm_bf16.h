@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     // after a store would wait for that store's write latency (once per row), and the first use of the next
     // tile's prefetched registers would wait for the last stores.  With the loads first, their wait also covers
     // the (older) prefetch, and nothing ever waits on a store.
-    constexpr bool EPL8 = (OVEC == 8) && (EPI == X3D_EPI_ADD || EPI == X3D_EPI_SWISH_BWD);
+    constexpr bool BNA_ = (EPI == EPI_BNADD);
+    constexpr bool EPL8 = (OVEC == 8) && (EPI == X3D_EPI_ADD || EPI == X3D_EPI_SWISH_BWD || BNA_);
     constexpr bool EPL4 = (OVEC == 8) && (EPI == X3D_EPI_ADD_STRIDED);
     hx8 epl8[EPL8 ? ROWS_PT : 1];
     hx4 epl4[EPL4 ? ROWS_PT : 1];
@@ -366,7 +367,15 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     const int egv = !EPL4 ? 0 : ((a.eW & 7) == 0 ? 8 : ((a.eW & 3) == 0 ? 4 : ((a.eW & 1) == 0 ? 2 : 0)));
     const bool epl4_vec = egv != 0;
     constexpr bool SWB_ = (EPI == X3D_EPI_SWISH_BWD);
-    float esb[SWB_ ? ROWS_PT : 1], etb[SWB_ ? ROWS_PT : 1], egt[SWB_ ? ROWS_PT : 1];   // per-row BN_b scale/shift, SE gate
+    // per-row BN_b scale/shift, SE gate (SWISH_BWD) | output scale, shift, scale of `add` (BNADD)
+    float esb[(SWB_ || BNA_) ? ROWS_PT : 1], etb[(SWB_ || BNA_) ? ROWS_PT : 1], egt[(SWB_ || BNA_) ? ROWS_PT : 1];
+    if constexpr (BNA_) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        const int m = m0 + (tid >> 4) + 16 * i;
+        bnadd_coef(a, m, m < a.M, esb[i], etb[i], egt[i]);
+      }
+    }
     if constexpr (SWB_) {
 #pragma unroll
       for (int i = 0; i < ROWS_PT; i++) {
@@ -385,9 +394,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         if constexpr (EPL8) {
 #pragma unroll
           for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
-          if (m < a.M && p < a.P) {
+          if (m < a.M && p < a.P && (!BNA_ || a.add)) {
             const long long o = ((long long)n * a.M + m) * a.P + p;
-            const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw) + o;
+            const T* src = (const T*)(EPI == X3D_EPI_SWISH_BWD ? a.braw : a.add) + o;
             if (!RAG || a.P - p >= 8) epl8[i] = *(const hx8*)src;
             else epl8[i] = load8_ragged<T, hx8>(src, (int)(a.P - p));
           }
@@ -470,6 +479,17 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         } else {
           for (int e = 0; e < nvalid; e++) val[e] += to_f<T>(((const T*)a.add)[o + e]);
         }
+      } else if constexpr (BNA_) {
+        float ad[8];
+        if constexpr (OVEC == 8) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) ad[e] = (float)epl8[i][e];
+        } else {
+          for (int e = 0; e < 8; e++) ad[e] = (e < nvalid && a.add) ? to_f<T>(((const T*)a.add)[o + e]) : 0.f;
+        }
+        const float lo = a.eact == X3D_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int e = 0; e < 8; e++) val[e] = fmaxf(esb[i] * val[e] + etb[i] + egt[i] * ad[e], lo);
       } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
         const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;

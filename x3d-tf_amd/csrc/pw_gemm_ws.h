@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
           sb = a.b_ss[m * 2]; tb = a.b_ss[m * 2 + 1];
           gt = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
         }
+        if constexpr (EPI == EPI_BNADD) bnadd_coef(a, m, true, sb, tb, gt);
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
@@ -251,6 +252,14 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
             VecIO<T, 8>::load((const T*)a.add + o, ad);
 #pragma unroll
             for (int e = 0; e < 8; e++) val[e] += ad[e];
+          } else if constexpr (EPI == EPI_BNADD) {
+            float ad[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) ad[e] = 0.f;
+            if (a.add) VecIO<T, 8>::load((const T*)a.add + o, ad);
+            const float lo = a.eact == X3D_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 8; e++) val[e] = fmaxf(sb * val[e] + tb + gt * ad[e], lo);
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
             float b[8];
             VecIO<T, 8>::load((const T*)a.braw + o, b);

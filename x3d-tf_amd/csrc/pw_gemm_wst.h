@@ -21,15 +21,19 @@
 // RAG (round 2): rows of P % 8 != 0 points (16-bit X3D-S / XS stage 5).  A row's last vector is loaded from
 // row_end - 8 -- always inside the tensor, still one unconditional load per slot -- and moved into place when it is
 // consumed (shift_down8, common.h); its stores go element by element and its sums are masked.
-template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false>
-__global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemmArgs a) {
+// NWT: waves per workgroup.  8 everywhere but for the one shape whose stationary operand does not fit the 256 registers a
+// wave has at two waves per SIMD (K = 630: 40 k-steps x 4 VGPRs = 160 + staging): that one runs four waves (one per SIMD,
+// 512 registers each: the weights live in the accumulation-register half of the file).
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false, int NWT = WST_NWT>
+__global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemmArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
-  constexpr int BN = WS_BN, OP = WS_OP, NT = WST_NWT * 64, Kp = KS * 16, WP = Kp + 8;
-  static_assert(NW <= WST_NWT, "MFMA waves are a subset of the workgroup");
+  constexpr int BN = WS_BN, OP = WS_OP, NT = NWT * 64, Kp = KS * 16, WP = Kp + 8;
+  static_assert(NW <= NWT, "MFMA waves are a subset of the workgroup");
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
-  constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD);
+  constexpr bool BNA_ = (EPI == EPI_BNADD);
+  constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD) || BNA_;
   constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
   constexpr int NSV = (Kp * 4 + NT - 1) / NT;             // staging vectors (8 points) per thread
   H* Xs = (H*)smem_raw;                                               // [2][Kp][32]
@@ -38,6 +42,9 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int mt = (a.M + 31) >> 5;
+  // wide outputs (X3D-XL: M = 280 / 306 / 630 with K up to 630): the row blocks are split over blockIdx.y -- each slice is
+  // its own persistent workgroup set with NW * RB stationary row blocks (the streamed operand is staged once per slice)
+  const int mib = blockIdx.y * (NW * RB);
   const int rsh = 8 - (int)(a.P & 7);   // RAG: places a row's last vector (loaded from row_end - 8) moves down by
   const int tiles_per_n = (int)((a.P + BN - 1) / BN);
   const int total_tiles = tiles_per_n * a.N;
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
   hx8 A[RB][KS];
 #pragma unroll
   for (int j = 0; j < RB; j++) {
-    const int mi = wid + NW * j;
+    const int mi = mib + wid + NW * j;
     if (wid < NW && mi < mt) {
       const H* wt = (const H*)a.wp + (long long)a.wp_rows * WP + ((long long)mi * KS * 64 + lane) * 8;
 #pragma unroll
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     if constexpr (HAS_SUMS) {
 #pragma unroll
       for (int i = 0; i < RB; i++) {
-        const int mi = wid + NW * i;
+        const int mi = mib + wid + NW * i;
         const float s1 = st1[i] + dpp_get<0xB1, 0xF>(st1[i]), s2 = st2[i] + dpp_get<0xB1, 0xF>(st2[i]);
         const int m = mi * 32 + (lane >> 1);
         if (wid < NW && mi < mt && (lane & 1) == 0 && m < a.M) {
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       const int hw = a.eH * a.eW, Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1, T_ = (int)a.P / hw;
 #pragma unroll
       for (int j = 0; j < RB; j++) {
-        const int m = (wid + NW * j) * 32 + row;
+        const int m = (mib + wid + NW * j) * 32 + row;
         const T* abase = (const T*)a.add + ((long long)n * a.M + min(m, a.M - 1)) * T_ * Hh * Wh;
 #pragma unroll
         for (int hv = 0; hv < 2; hv++)
@@ -232,15 +239,16 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
       }
     }
     if constexpr (EPI_LOADS) {
-      const T* src = (const T*)(EPI == X3D_EPI_ADD ? a.add : a.braw);
+      // (BNADD without a residual: the loads go to the output tensor's own first vector -- in range, value unused)
+      const T* src = (const T*)(EPI == X3D_EPI_SWISH_BWD ? a.braw : (BNA_ && !a.add) ? a.y : a.add);
 #pragma unroll
       for (int j = 0; j < RB; j++) {
-        const int m = (wid + NW * j) * 32 + row;
+        const int m = (mib + wid + NW * j) * 32 + row;
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
           const long long pl = (RAG && a.P - p < 8) ? a.P - 8 : p;
-          const long long o = (m < a.M && p < a.P) ? ((long long)n * a.M + m) * a.P + pl : 0;
+          const long long o = (m < a.M && p < a.P && !(BNA_ && !a.add)) ? ((long long)n * a.M + m) * a.P + pl : 0;
           eo[j][hv] = *(const hx8*)(src + o);
         }
       }
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
     // ---- epilogue through the wave-private slab: lane -> row lane >> 1, points 16*(lane & 1) .. +15
 #pragma unroll
     for (int j = 0; j < RB; j++) {
-      const int mi = wid + NW * j;
+      const int mi = mib + wid + NW * j;
       if (mi >= mt) continue;
 #pragma unroll
       for (int e = 0; e < 16; e++) myOs[((e & 3) + 8 * (e >> 2) + 4 * half) * OP + r] = acc[j][e];
@@ -292,6 +300,10 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
         if constexpr (EPI == X3D_EPI_SWISH_BWD) {
           sb = a.b_ss[m * 2]; tb = a.b_ss[m * 2 + 1];
           gt = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
+        }
+        if constexpr (BNA_) {
+          bnadd_coef(a, m, true, sb, tb, gt);
+          if (!a.add) gt = 0.f;
         }
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
@@ -311,6 +323,10 @@ __global__ __launch_bounds__(WST_NWT * 64, OCC) void pw_gemm_wst_kernel(const Pw
           if constexpr (EPI == X3D_EPI_ADD) {
 #pragma unroll
             for (int e = 0; e < 8; e++) val[e] += (float)eo[j][hv][e];
+          } else if constexpr (BNA_) {
+            const float lo = a.eact == X3D_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 8; e++) val[e] = fmaxf(sb * val[e] + tb + (gt != 0.f ? gt * (float)eo[j][hv][e] : 0.f), lo);
           } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) val[2 * gq] += (float)es[j][hv][gq];
@@ -369,18 +385,34 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   if (ks == 14 && a.M <= 96) return 3;
   if (ks == 6 && a.M <= 224) return 4;
   if (ks == 6 && a.M <= 448) return 5;     // stage-5 block 0 `a` conv: 96 -> 432 (7 x 2 x 6)
+  // X3D-XL widths (72 / 162, 136 / 306, 280 / 630; round 3).  The resident-panel kernel re-reads every weight fragment from
+  // LDS in every wave (>= 1 KB of LDS traffic per MFMA: LDS-bound below a third of the matrix-core rate) and repeats the
+  // swish prologue per 32- / 64- / 96-row block; measured on 60 clips of 16x312x312 in fp16: 630 -> 280 279 us (floor 22),
+  // 306 -> 136 237 us (floor 42), 280 -> 630 108 us, 136 -> 306 137 us.  Row blocks beyond NW * RB go to blockIdx.y.
+  static const char* xl = getenv("X3D_PW_WST_XL");   // A/B switch: 0 = off
+  if (xl && atoi(xl) == 0) return 0;
+  if (ks == 20 && a.M <= 160) return 6;    // stage-4 `c`: 306 -> 136 (5 waves x 1 row block x 20 k-steps)
+  if (ks == 9 && a.M <= 640) return 7;     // stage-4 `a`: 136 -> 306 (5 x 2 x 9); stage-5 block 0: 136 -> 630 in two slices
+  if (ks == 40 && a.M <= 288) return 8;    // stage-5 `c`: 630 -> 280 (3 x 1 x 40, three slices)
+  if (ks == 18 && a.M <= 640) return 9;    // stage-5 `a` / conv5: 280 -> 630 (5 x 2 x 18, two slices)
+  if (ks == 11 && a.M <= 96) return 10;    // stage-3 `c`: 162 -> 72 (3 x 1 x 11)
+  // (72 -> 162, one slice, measured 227 us against 209 on the resident-panel kernel: only the two-slice case runs here)
+  if (ks == 5 && a.M > 192 && a.M <= 384) return 11;    // stage-4 block 0 `a`: 72 -> 306 (6 x 1 x 5, two slices)
   return 0;
 }
+// shapes 6.. exist for one kind of prologue only (the `c` convs carry BN_b * gate -> swish, the `a` convs none): the other
+// combination has no instantiation and falls back to the resident-panel kernel
+static inline bool pw_wst_shape_has_prologue(int shape) { return shape == 6 || shape == 8 || shape == 10; }
 
-template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false>
+template <typename H, int PRO, int EPI, int NW, int RB, int KS, int OCC, bool RAG = false, int NWT = WST_NWT>
 static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   if constexpr (!RAG) {
-    if (a.P % 8 != 0) return pw_wst_launch_t<H, PRO, EPI, NW, RB, KS, OCC, true>(a, st);
+    if (a.P % 8 != 0) return pw_wst_launch_t<H, PRO, EPI, NW, RB, KS, OCC, true, NWT>(a, st);
   }
   a.KC = KS * 16;
   const size_t lds = pw_wst_lds_bytes<NW, KS>();
   X3D_DESCRIBE("pw_gemm_wst_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", HV<H>::name, PRO, EPI, NW, RB, KS, OCC, (int)RAG);
-  auto kern = pw_gemm_wst_kernel<H, PRO, EPI, NW, RB, KS, OCC, RAG>;
+  auto kern = pw_gemm_wst_kernel<H, PRO, EPI, NW, RB, KS, OCC, RAG, NWT>;
   static bool attr_set = false;
   static int cus = 256;
   if (!attr_set) {
@@ -392,10 +424,12 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   }
   const long long total_tiles = ceil_div_ll(a.P, WS_BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_wst: too many tiles");
-  const long long tpb = ceil_div_ll(total_tiles, (long long)cus * OCC);
+  const int gy = ceil_div(ceil_div(a.M, 32), NW * RB);       // row-block slices (1 for every X3D-S / M / L layer)
+  const long long slots = (long long)cus * OCC / gy > 0 ? (long long)cus * OCC / gy : 1;
+  const long long tpb = ceil_div_ll(total_tiles, slots);
   a.tiles_per_block = (int)tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(WST_NWT * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(NWT * 64), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm_wst");
   return X3D_OK;
 }
@@ -407,6 +441,23 @@ static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
     case 2: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 12, 1>(a, st);
     case 3: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
     case 4: return pw_wst_launch_t<H, PRO, EPI, 7, 1, 6, 2>(a, st);
-    default: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 6, 2>(a, st);
+    case 5: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 6, 2>(a, st);
   }
+  // X3D-XL shapes: forward only, one prologue kind each (pw_wst_shape_has_prologue)
+  if constexpr (PRO == PRO_AFFINE) {
+    switch (shape) {
+      case 6: return pw_wst_launch_t<H, PRO, EPI, 5, 1, 20, 1>(a, st);
+      case 8: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 40, 1, false, 4>(a, st);
+      case 10: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 11, 2>(a, st);
+    }
+  }
+  if constexpr (PRO == PRO_NONE) {
+    switch (shape) {
+      case 7: return pw_wst_launch_t<H, PRO, EPI, 5, 2, 9, 2>(a, st);
+      case 9: return pw_wst_launch_t<H, PRO, EPI, 5, 2, 18, 1>(a, st);
+      case 11: return pw_wst_launch_t<H, PRO, EPI, 6, 1, 5, 2>(a, st);
+    }
+  }
+  x3d_set_error("pw_gemm_wst: shape %d has no instantiation for this prologue", shape);
+  return X3D_ERR_INVALID;
 }

@@ -510,7 +510,8 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
 
 template <typename T, int VEC, int KT>
 __global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                      T* __restrict__ y, double* stats, int C, int Tn, long long HW) {
+                                                      T* __restrict__ y, double* stats, const float* __restrict__ oss, int oact,
+                                                      int C, int Tn, long long HW) {
   __shared__ float scratch[2 * 4];
   const int nc = blockIdx.y, c = nc % C;
   const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
@@ -519,6 +520,10 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, c
 #pragma unroll
   for (int k = 0; k < KT; k++) wk[k] = w[c * KT + k];
   float red[2] = {0.f, 0.f};
+  // inference epilogue: the stem's BatchNorm (moving statistics) + ReLU on the accumulator -- the raw conv_t output and
+  // the separate BN + ReLU pass over the widest tensor of the network never touch HBM
+  const float os = oss ? oss[c * 2] : 1.0f, ot = oss ? oss[c * 2 + 1] : 0.f;
+  const float olo = (oss && oact == X3D_ACT_RELU) ? 0.f : -__builtin_inff();
   if (q < HW) {
     const T* xp = x + (long long)nc * Tn * HW + q;
     T* yp = y + (long long)nc * Tn * HW + q;
@@ -548,6 +553,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(const T* __restrict__ x, c
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < KT; k++) acc += wk[k] * win[k][e];
+        if (oss) acc = fmaxf(os * acc + ot, olo);
         o[e] = acc;
         const float vr = round_to<T>(acc);
         red[0] += vr;
@@ -691,35 +697,37 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(const T* __restrict__ g, c
 }
 
 template <typename T, int VEC>
-static int dwt_fwd_kt(const void* x, const float* w, void* y, double* stats, int NC, int C, int T_, long long HW,
-                      int KT, hipStream_t st) {
+static int dwt_fwd_kt(const void* x, const float* w, void* y, double* stats, const float* oss, int oact, int NC, int C, int T_,
+                      long long HW, int KT, hipStream_t st) {
   dim3 grid((unsigned)ceil_div_ll(HW, 256ll * VEC), (unsigned)NC);
   switch (KT) {
-    case 1: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 1>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
-    case 3: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 3>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
-    case 5: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 5>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
-    case 7: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 7>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, C, T_, HW); break;
+    case 1: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 1>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, oss, oact, C, T_, HW); break;
+    case 3: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 3>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, oss, oact, C, T_, HW); break;
+    case 5: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 5>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, oss, oact, C, T_, HW); break;
+    case 7: hipLaunchKernelGGL((dwt_fwd_kernel<T, VEC, 7>), grid, dim3(256), 0, st, (const T*)x, w, (T*)y, stats, oss, oact, C, T_, HW); break;
     default: x3d_set_error("dwt_fwd: KT must be 1,3,5 or 7"); return X3D_ERR_INVALID;
   }
   X3D_LAUNCH_CHECK("dwt_fwd");
   return X3D_OK;
 }
 
-extern "C" int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, int N, int C, int T, int HW,
-                           int KT, int dtype, void* stream) {
+extern "C" int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, const float* oss, int oact, int N, int C, int T,
+                           int HW, int KT, int dtype, void* stream) {
   X3D_REQUIRE(x && w && y && N > 0 && C > 0 && T > 0 && HW > 0, "dwt_fwd: bad args");
+  X3D_REQUIRE(!(oss && stats), "dwt_fwd: the inference epilogue (out_scale_shift) takes no statistics");
+  X3D_REQUIRE(oact == X3D_ACT_NONE || oact == X3D_ACT_RELU, "dwt_fwd: out_act must be none or ReLU");
   X3D_REQUIRE(x3d_dtype_ok(dtype), "dwt_fwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int eb = dtype == X3D_F32 ? 4 : 2;
   const int vec = pick_vec(eb, HW, x, y);
   if (dtype == X3D_F32)
-    return vec >= 4 ? dwt_fwd_kt<float, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
-                    : dwt_fwd_kt<float, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
+    return vec >= 4 ? dwt_fwd_kt<float, 4>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st)
+                    : dwt_fwd_kt<float, 1>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st);
   if (dtype == X3D_F16)
-    return vec >= 4 ? dwt_fwd_kt<f16, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
-                    : dwt_fwd_kt<f16, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
-  return vec >= 4 ? dwt_fwd_kt<bf16, 4>(x, w, y, stats, N * C, C, T, HW, KT, st)
-                  : dwt_fwd_kt<bf16, 1>(x, w, y, stats, N * C, C, T, HW, KT, st);
+    return vec >= 4 ? dwt_fwd_kt<f16, 4>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st)
+                    : dwt_fwd_kt<f16, 1>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st);
+  return vec >= 4 ? dwt_fwd_kt<bf16, 4>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st)
+                  : dwt_fwd_kt<bf16, 1>(x, w, y, stats, oss, oact, N * C, C, T, HW, KT, st);
 }
 
 template <typename T, int VEC>

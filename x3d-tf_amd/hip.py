@@ -26,7 +26,8 @@ class X3DHipError(RuntimeError):
 class PwFwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("stats", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i),
-                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("w_panel", _vp)]
+                ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("w_panel", _vp),
+                ("out_scale_shift", _vp), ("out_add", _vp), ("out_add_scale_shift", _vp), ("out_act", _i)]
 
 
 class PwDgradArgs(C.Structure):
@@ -99,7 +100,7 @@ _SIGS = {
     "x3d_last_error": ([], C.c_char_p),
     "x3d_stem_s_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_stem_s_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "x3d_dwt_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "x3d_dwt_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_dwt_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "x3d_stats_replicas": ([], _i),
     "x3d_stats_stride": ([_i], _ll),

@@ -188,6 +188,8 @@ class _Plan:
     # -- recording -------------------------------------------------------------------------------
     def rec(self, lst, name, *args):
         fn = getattr(self.lib, name)
+        if fn.argtypes is not None and len(args) + 1 != len(fn.argtypes):   # (+ the stream): caught when recording, dry plans too
+            raise hip.X3DHipError(f"{name}: recorded with {len(args)} arguments, the C ABI takes {len(fn.argtypes) - 1} + stream")
         conv = []
         for a in args:   # remember the argument struct of this launch (profiling tools read shapes from it)
             st = a if isinstance(a, C.Structure) else (a[1] if isinstance(a, tuple) and len(a) > 1 and isinstance(a[1], C.Structure) else None)
@@ -508,7 +510,162 @@ class X3D:
         for key in list(self._plans)[:len(self._plans) - keep]:
             del self._plans[key]
 
+    def _make_infer_plan(self, n, t, h, w) -> _Plan:
+        """The forward pass at training=False (reference model.py:113-127; eval.py:83-89) as its own launch list.
+
+        With the moving statistics every BatchNorm is a per-channel affine known before the first kernel, so nothing
+        waits for batch statistics and the training plan's materialised intermediates disappear:
+          stem     conv_s -> conv_t with BN + ReLU in its epilogue (x3d_dwt_fwd out_scale_shift): no raw t tensor, no tail
+          block    a (raw) -> b (BN_a + ReLU on load; SE squeeze in the epilogue) -> [SE MLP] -> [strided shortcut conv (raw)]
+                   -> c with BN_b * gate -> swish on load and  relu(bn_c(acc) + shortcut)  in its epilogue
+                   (x3d_pw_fwd out_scale_shift / out_add / out_add_scale_shift): no c_raw, no residual-tail pass
+          head     conv5 (raw) -> pool of relu(bn(.)) -> fc1 -> fc2 -> softmax -> view mean
+        3 launches per block (4 with SE, +1 for a stage's first block) instead of 4-6, and 2 tensor passes of Cout*P less
+        per block.  The per-layer coefficients still come from ONE batched launch at the head of the list (they depend on
+        the parameters only, but parameters may change between calls).  Activation buffers are shared between blocks
+        (two block outputs ping-pong; one a / b / shortcut scratch each), so a 30-view X3D-XL plan holds ~3 GB, not ~30."""
+        a, p = self.arch, self.params
+        pl = _Plan(self, n, t, h, w, False)
+        dt = hip.dtype_code(self.dtype)
+        eps = a.bn_eps
+        F = pl.fwd
+        if n % a.num_preds:
+            raise ValueError(f"inference batch {n} is not a multiple of views*crops={a.num_preds} "
+                             "(reference model.py:125)")
+
+        class BNBuf:
+            pass
+
+        pl.bn_eval_items = []
+
+        def bn_coef(prefix, c):
+            b = BNBuf()
+            b.prefix, b.c = prefix, c
+            b.ss, b.mi = pl.f32(c, 2), pl.f32(c, 2)
+            pl.bn_eval_items.append(hip.BnEvalItem(_p(p[f"{prefix}/gamma"]), _p(p[f"{prefix}/beta"]),
+                                                   _p(p[f"{prefix}/moving_mean"]), _p(p[f"{prefix}/moving_variance"]),
+                                                   _p(b.ss), _p(b.mi), c))
+            return b
+
+        F.append(None)   # slot 0: x3d_bn_eval_coef_batched, filled in once every BN layer is known
+        # ---- geometry first: the shared buffers are sized for their largest user ----------------------------------
+        h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        geo, hh, ww = [], h1, w1
+        for b in a.blocks:
+            ho, wo = same_pad(hh, 3, b.stride)[0], same_pad(ww, 3, b.stride)[0]
+            geo.append((hh, ww, ho, wo))
+            hh, ww = ho, wo
+        numel_y = max([n * a.c1 * t * h1 * w1] + [n * b.cout * t * g[2] * g[3] for b, g in zip(a.blocks, geo)])
+        numel_a = max(n * b.inner * t * g[0] * g[1] for b, g in zip(a.blocks, geo))
+        numel_b = max(n * b.inner * t * g[2] * g[3] for b, g in zip(a.blocks, geo))
+        numel_r = max([1] + [n * b.cout * t * g[2] * g[3] for b, g in zip(a.blocks, geo) if b.has_shortcut_conv])
+        ybuf = [pl.act(numel_y), pl.act(numel_y)]
+        abuf, bbuf, rbuf = pl.act(numel_a), pl.act(numel_b), pl.act(numel_r)
+
+        def view(buf, *shape):
+            numel = 1
+            for d in shape:
+                numel *= d
+            return buf[:numel].view(*shape)
+
+        # ---- input + stem ------------------------------------------------------------------------------------------
+        pl.x_in = None
+        pl.x = pl.act(n, self.in_channels, t, h, w)
+        pl.s_raw = view(abuf, n, a.c1, t, h1, w1)     # conv_s output: dead once conv_t has run, shares the `a` scratch
+        pl.y0 = view(ybuf[0], n, a.c1, t, h1, w1)
+        pl.bn1 = bn_coef("conv1/bn", a.c1)
+        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt)
+        pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.y0, None, pl.bn1.ss, ACT_RELU, n, a.c1, t, h1 * w1,
+               a.c1_temp_filter, dt)
+        # ---- residual stages ---------------------------------------------------------------------------------------
+        x_cur, cur = pl.y0, 0
+        pl.blocks = []
+        for b, (hh, ww, ho, wo) in zip(a.blocks, geo):
+            pre = block_prefix(b)
+            q = f"{pre}/bottleneck"
+            P_out = t * ho * wo
+
+            class B:
+                pass
+
+            B.spec, B.x, B.hh, B.ww, B.ho, B.wo = b, x_cur, hh, ww, ho, wo
+            B.a_raw = view(abuf, n, b.inner, t, hh, ww)
+            B.b_raw = view(bbuf, n, b.inner, t, ho, wo)
+            B.y = view(ybuf[1 - cur], n, b.cout, t, ho, wo)
+            B.bn_a, B.bn_b, B.bn_c = bn_coef(f"{q}/bn_a", b.inner), bn_coef(f"{q}/bn_b", b.inner), bn_coef(f"{q}/bn_c", b.cout)
+            B.pool = pl.acc64(n, b.inner) if b.has_se else None
+            B.gate = pl.f32(n, b.inner) if b.has_se else None
+            B.hidden = pl.f32(n, b.se_width) if b.has_se else None
+            sa = hip.PwFwdArgs(_p(x_cur), _p(p[f"{q}/a/kernel"]), _p(B.a_raw), None, None, None, ACT_NONE, n, b.cin,
+                               b.inner, t, hh, ww, 1, dt)
+            sa.w_panel = self._wp(f"{q}/a/kernel")
+            B.sa = sa
+            pl.rec(F, "x3d_pw_fwd", sa)
+            sb = hip.Dw3dFwdArgs(_p(B.a_raw), _p(p[f"{q}/b/kernel"]), _p(B.b_raw), _p(B.bn_a.ss), ACT_RELU, None, None,
+                                 n, b.inner, t, hh, ww, b.stride, dt)
+            B.sb = sb
+            pl.rec(F, "x3d_dw3d_fwd", ("dwstats", sb, None, B.pool))
+            if b.has_se:
+                pl.rec(F, "x3d_se_fwd", ("acc", B.pool), float(P_out), B.bn_b.ss, p[f"{q}/se_fc1/kernel"],
+                       p[f"{q}/se_fc1/bias"], p[f"{q}/se_fc2/kernel"], p[f"{q}/se_fc2/bias"], B.gate, B.hidden, n,
+                       b.inner, b.se_width)
+            if b.has_shortcut_conv:
+                B.r_raw = view(rbuf, n, b.cout, t, ho, wo)
+                B.bn_r = bn_coef(f"{pre}/bn_r", b.cout)
+                sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                   n, b.cin, b.cout, t, hh, ww, b.stride, dt)
+                sr.w_panel = self._wp(f"{pre}/residual/kernel")
+                B.sr = sr
+                pl.rec(F, "x3d_pw_fwd", sr)
+                add, add_ss = B.r_raw, B.bn_r.ss
+            else:
+                B.r_raw, B.bn_r = None, None
+                add, add_ss = x_cur, None
+            # c: BN_b * gate -> swish on load; relu(bn_c(acc) + shortcut) on the accumulators
+            sc = hip.PwFwdArgs(_p(B.b_raw), _p(p[f"{q}/c/kernel"]), _p(B.y), None, _p(B.bn_b.ss), _p(B.gate),
+                               ACT_SWISH, n, b.inner, b.cout, t, ho, wo, 1, dt, self._wp(f"{q}/c/kernel"),
+                               _p(B.bn_c.ss), _p(add), _p(add_ss), ACT_RELU)
+            B.sc = sc
+            pl.rec(F, "x3d_pw_fwd", sc)
+            pl.blocks.append(B)
+            x_cur, cur = B.y, 1 - cur
+        # ---- head --------------------------------------------------------------------------------------------------
+        hh, ww = geo[-1][2], geo[-1][3]
+        c_last, c5 = a.stages[-1].cout, a.conv5_out
+        P5 = t * hh * ww
+        pl.P5, pl.h5, pl.w5 = P5, hh, ww
+        pl.y_last = x_cur
+        pl.c5_raw = view(abuf, n, c5, t, hh, ww) if n * c5 * P5 <= numel_a else pl.act(n, c5, t, hh, ww)
+        pl.bn5 = bn_coef("conv5/layer_with_weights-1", c5)
+        s5 = hip.PwFwdArgs(_p(x_cur), _p(p["conv5/layer_with_weights-0/kernel"]), _p(pl.c5_raw), None, None, None,
+                           ACT_NONE, n, c_last, c5, t, hh, ww, 1, dt)
+        s5.w_panel = self._wp("conv5/layer_with_weights-0/kernel")
+        pl.s5 = s5
+        pl.rec(F, "x3d_pw_fwd", s5)
+        pl.pooled = pl.f32(n, c5)
+        pl.h1 = pl.f32(n, a.fc1_out)
+        pl.logits = pl.f32(n, a.num_classes)
+        pl.probs = pl.f32(n, a.num_classes)
+        pl.drop_mask, pl.drop_scale = None, 1.0
+        pl.rec(F, "x3d_pool_fwd", pl.c5_raw, pl.bn5.ss, pl.pooled, n, c5, P5, dt)
+        pl.rec(F, "x3d_dense_fwd", pl.pooled, None, 1.0, p["fc1/kernel"], None, pl.h1, ACT_RELU, n, c5, a.fc1_out)
+        pl.rec(F, "x3d_dense_fwd", pl.h1, None, 1.0, p["fc2/kernel"], p["fc2/bias"], pl.logits, ACT_NONE, n, a.fc1_out,
+               a.num_classes)
+        pl.rec(F, "x3d_softmax_xent", pl.logits, None, pl.probs, None, None, 1.0, n, a.num_classes)
+        pl.out = pl.f32(n // a.num_preds, a.num_classes)
+        pl.rec(F, "x3d_view_mean", pl.probs, pl.out, n // a.num_preds, a.num_preds, a.num_classes)
+        items = (hip.BnEvalItem * len(pl.bn_eval_items))(*pl.bn_eval_items)
+        pl.bn_eval_table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+        F[0] = ("x3d_bn_eval_coef_batched", pl.lib.x3d_bn_eval_coef_batched,
+                (pl.bn_eval_table.data_ptr(), len(pl.bn_eval_items), float(eps)))
+        pl.folds = []
+        pl.finalize_acc()
+        self._resolve(pl, pl.fwd)
+        return pl
+
     def _make_plan(self, n, t, h, w, training) -> _Plan:
+        if not training and os.environ.get("X3D_INFER_TRAIN_PLAN") != "1":   # (A/B: =1 replays the training-shaped list)
+            return self._make_infer_plan(n, t, h, w)
         a, p = self.arch, self.params
         pl = _Plan(self, n, t, h, w, training)
         dt = hip.dtype_code(self.dtype)
@@ -567,7 +724,7 @@ class X3D:
         pl.bn1 = bn_bufs("conv1/bn", a.c1)
         pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt)
         pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.t_raw,
-               ("acc", pl.bn1.stats) if training else None, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
+               ("acc", pl.bn1.stats) if training else None, None, ACT_NONE, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
         if fold_on:
             pl.rec(F, "x3d_tail_fwd_bn", pl.t_raw, bn_fold(pl.bn1, n * t * h1 * w1), None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
         else:

@@ -86,13 +86,14 @@ def _expand_stats(stats, c):
     return buf
 
 
-def dwt_fwd(x, w, y=None, stats=None):
-    _chk(x, w, y, stats)
+def dwt_fwd(x, w, y=None, stats=None, out_ss=None, out_act=ACT_NONE):
+    """out_ss [C][2]: the inference epilogue y = out_act(s*conv + t) (no statistics)."""
+    _chk(x, w, y, stats, out_ss)
     n, c, t, h, ww = x.shape
     if y is None:
         y = torch.empty_like(x)
     st = _Stats(stats, c)
-    hip.call("x3d_dwt_fwd", ptr(x), ptr(w), ptr(y), ptr(st.arg()), n, c, t, h * ww, w.shape[1],
+    hip.call("x3d_dwt_fwd", ptr(x), ptr(w), ptr(y), ptr(st.arg()), ptr(out_ss), out_act, n, c, t, h * ww, w.shape[1],
              hip.dtype_code(x.dtype))
     st.done()
     return y
@@ -157,8 +158,10 @@ def pw_pack_weights(weights, dgrad=True, dtype=torch.bfloat16):
     return out
 
 
-def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, w_panel=None):
-    _chk(x, w, y, stats, in_ss, in_gate, w_panel)
+def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, w_panel=None,
+           out_ss=None, out_add=None, out_add_ss=None, out_act=ACT_NONE):
+    """out_ss [Cout][2]: the inference epilogue y = out_act(s_o*acc + t_o [+ s_r*out_add + t_r]) (no statistics)."""
+    _chk(x, w, y, stats, in_ss, in_gate, w_panel, out_ss, out_add, out_add_ss)
     n, cin, t, h, ww = x.shape
     cout = w.shape[0]
     ho, wo = _out_hw(h, ww, stride)
@@ -166,7 +169,8 @@ def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, 
         y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
     st = _Stats(stats, cout)
     a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(st.arg()), ptr(in_ss), ptr(in_gate), in_act, n, cin,
-                      cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel))
+                      cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel), ptr(out_ss), ptr(out_add),
+                      ptr(out_add_ss), out_act)
     hip.call_struct("x3d_pw_fwd", a)
     st.done()
     return y
