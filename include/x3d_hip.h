@@ -210,6 +210,16 @@ typedef struct {
   const void* x;               /* [N][Cin][P] conv input (ADD epilogues) */
   float* dw;                   /* [Cout][Cin] += */
   int N, Cin, Cout, T, H, W, dtype;
+  /* folded residual-tail backward (ADD epilogues; tail_c == NULL: off).  The conv input x is the OUTPUT y of the previous
+   * residual block, so dx is the gradient that block's Add + ReLU receives (model.py:381-392): with tail_c set the
+   * epilogue applies that backward instead of a separate x3d_tail_bwd pass over dx,
+   *   dx = [x > 0] * (W^T dYraw + add) ;  tail_sums_c [Cin][2] += (sum dx, sum dx*tail_c) ;
+   *   tail_r != NULL (the previous block has a shortcut conv): tail_sums_r [Cin][2] += (sum dx, sum dx*tail_r)
+   * tail_c / tail_r: raw c-conv / shortcut-conv outputs of the previous block, [N][Cin][P]. */
+  const void* tail_c;
+  const void* tail_r;
+  double* tail_sums_c;
+  double* tail_sums_r;
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);

@@ -103,6 +103,16 @@ PW_BWD = [
     (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
 ]
 
+# ... with the residual-tail backward of the block below folded into the epilogue (the `a` convs: ADD epilogues, panels of
+# one or two row tiles): N, Cin, Cout, T, H, W, epilogue, tail (1 = identity shortcut below, 2 = shortcut conv below)
+PW_BWD_TAIL = [
+    (2, 24, 54, 4, 16, 16, "add", 1), (2, 24, 54, 2, 28, 28, "add_strided", 1), (2, 24, 54, 4, 16, 16, "add", 2),   # stage 2 (X3D-S / M / L)
+    (1, 24, 108, 3, 16, 16, "add_strided", 1), (1, 24, 108, 3, 16, 16, "add_strided", 2),                          # stage 3 block 0
+    (2, 48, 54, 2, 28, 28, "add", 1), (2, 48, 54, 2, 28, 28, "add", 2),                                            # two row tiles x two dY tiles
+    (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add", 2), (1, 32, 72, 1, 16, 16, "add_strided", 1),  # X3D-XL stage 2
+    (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2),                                              # ragged tiles, widths off the grid
+]
+
 # ---- x3d_dw3d_fwd / x3d_dw3d_bwd: N, C, T, H, W, stride --------------------------------------------------------------------
 DW = [
     (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2),       # even, SW=2
@@ -203,13 +213,15 @@ def pw_wgrad_struct(shape, dtype):
 
 def pw_bwd_struct(shape, dtype):
     from x3d_tf_amd import hip
-    n, cin, cout, t, h, w, epi = shape
+    n, cin, cout, t, h, w, epi = shape[:7]
+    tail = shape[7] if len(shape) > 7 else 0
     A = _Addr.new
     e = PW_DGRAD_EPI.index(epi)
     sw = epi == "swish_bwd"
     return hip.PwBwdArgs(A(), A(), A(), A(), A(), e, None if sw else A(), A() if sw else None, A() if sw else None,
                          A() if sw else None, A() if sw else None, None if sw else A(), A(), n, cin, cout, t, h, w,
-                         _code(dtype))
+                         _code(dtype), A() if tail else None, A() if tail == 2 else None, A() if tail else None,
+                         A() if tail == 2 else None)
 
 
 def dw_fwd_struct(shape, dtype):

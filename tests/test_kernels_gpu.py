@@ -218,6 +218,75 @@ def test_pw_bwd_oracle(gpu, dtype, shape):
         report("nc_sums", ncs, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", S.PW_BWD_TAIL)
+def test_pw_bwd_tail(gpu, dtype, shape):
+    """x3d_pw_bwd with the residual-tail backward of the block below folded into its epilogue (tail_c / tail_r): the conv
+    input x is that block's output y, so dx = [x > 0] * (W^T dY + add) -- what x3d_tail_bwd would have made of the unmasked
+    dx in a separate pass -- with the BN_c / BN_r backward sums (sum dx, sum dx * c_raw | r_raw).  Against an fp64
+    restatement; dW is unaffected by the fold."""
+    ops = _ops()
+    n, cin, cout, t, h, w, epi, tail = shape
+    g_ = _gen(33)
+    gy, gyd = rnd((n, cout, t, h, w), dtype, g_)
+    yraw, yrd = rnd((n, cout, t, h, w), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    dy = _dyraw(coef, gyd, yrd, dtype)
+    dx_ref = torch.einsum("oc,nothw->ncthw", round_to(wt, dtype), dy)
+    dp = _panels(ops, wt, dtype, gpu)[1]
+    x, xd = rnd((n, cin, t, h, w), dtype, g_)           # = relu output of the block below: about half of it positive
+    x = torch.relu(x)
+    xd = x.double()
+    if epi == "add":
+        add, addd = rnd((n, cin, t, h, w), dtype, g_)
+        dx_ref = dx_ref + addd
+        e = ops.EPI_ADD
+    else:
+        add, addd = rnd((n, cin, t, (h + 1) // 2, (w + 1) // 2), dtype, g_)
+        up = torch.zeros_like(dx_ref)
+        up[:, :, :, ::2, ::2] = addd
+        dx_ref = dx_ref + up
+        e = ops.EPI_ADD_STRIDED
+    mask = xd > 0
+    g_ref = dx_ref * mask
+    tc, tcd = rnd((n, cin, t, h, w), dtype, g_)
+    tr, trd = rnd((n, cin, t, h, w), dtype, g_)
+    dx = torch.empty((n, cin, t, h, w), dtype=dtype, device=gpu)
+    dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)
+    sc = torch.full((cin, 2), 0.25, dtype=torch.float64, device=gpu)     # += semantics
+    sr = torch.full((cin, 2), 0.25, dtype=torch.float64, device=gpu)
+    dev = lambda v: v.to(gpu)
+    ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, e, x=dev(x), add=dev(add), tail_c=dev(tc),
+                    tail_r=dev(tr) if tail == 2 else None, tail_sums_c=sc, tail_sums_r=sr if tail == 2 else None)
+    torch.cuda.synchronize()
+    assert ok, "the fused kernel with the tail epilogue should cover this shape"
+    rt, at = tol_gemm(dtype)
+    report("dx (masked)", dx, g_ref, rt, at * dx_ref.abs().max().item())
+    assert not bool((dx.float().cpu()[~mask] != 0).any()), "gradient leaked through a closed ReLU"
+    dw_ref = torch.einsum("nothw,ncthw->oc", dy, xd)
+    report("dw", dw, dw_ref + 0.5, _wtol(dtype), _wtol(dtype) * dw_ref.abs().max().item())
+    gs = dx.float().cpu().double()                       # the sums describe the gradient as stored
+    st = 10 * _stol(dtype)
+    ref_c = torch.stack([gs.sum((0, 2, 3, 4)), (gs * tcd).sum((0, 2, 3, 4))], 1) + 0.25
+    report("tail_sums_c", sc, ref_c, st, st * max(1.0, ref_c.abs().max().item()))
+    if tail == 2:
+        ref_r = torch.stack([gs.sum((0, 2, 3, 4)), (gs * trd).sum((0, 2, 3, 4))], 1) + 0.25
+        report("tail_sums_r", sr, ref_r, st, st * max(1.0, ref_r.abs().max().item()))
+    else:
+        assert float((sr - 0.25).abs().max()) == 0.0
+    # the same launch without the fold followed by x3d_tail_bwd gives the same masked gradient bit for bit
+    dx2 = torch.empty_like(dx)
+    dw2 = torch.zeros_like(dw)
+    ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx2, dw2, e, x=dev(x), add=dev(add))
+    s2c = torch.zeros((cin, 2), dtype=torch.float64, device=gpu)
+    s2r = torch.zeros((cin, 2), dtype=torch.float64, device=gpu)
+    ops.tail_bwd(dx2, dev(x), dev(tc), dev(tr) if tail == 2 else None, s2c, s2r if tail == 2 else None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)
+    report("sums vs x3d_tail_bwd", sc - 0.25, s2c.cpu(), 1e-6, 1e-6 * max(1.0, ref_c.abs().max().item()))   # both sum the STORED gradient
+
+
 @pytest.mark.parametrize("bf", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD)   # N, Cin, Cout, T, H, W, epi   (a conv: Cin = block input, Cout = inner; c conv: Cin = inner, Cout = out)
 def test_pw_bwd_fused(gpu, shape, bf):

@@ -1,7 +1,7 @@
 """Runs the other BASELINE.json configurations end to end on one MI355X and reports throughput
 (they are parity-test cases, not bench lines): S fp32 B=32 train, L bf16 train, XL 30-view inference in fp16 (the
 reference's mixed_float16) and bf16."""
-import os, sys, time, json
+import gc, os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import x3d_tf_amd as x
@@ -10,6 +10,7 @@ from x3d_tf_amd.train import Trainer
 
 def train_rate(variant, batch, t, s, dtype, steps=5):
     cfg = x.get_config(variant)
+    gc.collect(); torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()          # the footprint of THIS configuration, not the largest one so far
     m = X3D(cfg, dtype=dtype, device="cuda:0")
     tr = Trainer(m, cfg)
@@ -30,6 +31,7 @@ def train_rate(variant, batch, t, s, dtype, steps=5):
 
 def infer_rate(variant, videos, views, crops, t, s, dtype, steps=5):
     cfg = x.get_config(variant, ["TEST.NUM_TEMPORAL_VIEWS", views, "TEST.NUM_SPATIAL_CROPS", crops])
+    gc.collect(); torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     m = X3D(cfg, dtype=dtype, device="cuda:0")
     n = videos * views * crops

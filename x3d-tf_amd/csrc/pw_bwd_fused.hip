@@ -34,6 +34,10 @@ struct PwBwdArgs {
   int N, Co, Ci, Kp;
   long long P;
   int tiles_per_block;
+  // TAIL (ADD epilogues): dx is the gradient wrt the OUTPUT y of the previous residual block, whose Add + ReLU backward
+  // (x3d_tail_bwd) is applied here: dx = [y > 0] * (W^T dY + add) with y = this conv's input x (already staged for dW),
+  // tail_sums_c [Ci][2] += (sum dx, sum dx * tail_c), tail_sums_r likewise with tail_r (NULL: identity shortcut)
+  const void* tail_c; const void* tail_r; double* tail_sums_c; double* tail_sums_r;
 };
 
 #define FB_BN 128
@@ -47,13 +51,19 @@ struct PwBwdArgs {
 #define FB_WAVES(MT, KT) (((MT) * (KT) <= 2) ? 3 : 2)
 #endif
 // MT: 32-row tiles of Ci (dX rows / dW columns); KT: 32-row tiles of Co (dY rows / dW rows)
-template <typename H, int MT, int KT, int EPI>
-__global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(const PwBwdArgs a) {
+// (with the tail epilogue the two-tile panels need ~190 VGPRs: two workgroups per CU instead of three beat 44-88 bytes of
+// scratch traffic per lane in the tile loop -- 24<->54 @56x56: 273 us plain, 355 us with the spilling tail, r03e)
+template <typename H, int MT, int KT, int EPI, int TAIL = 0>
+__global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(const PwBwdArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
   constexpr int BN = FB_BN, YP = FB_YP, XP = FB_XP, OP = FB_OP;
   constexpr bool SWB = (EPI == X3D_EPI_SWISH_BWD);
+  // TAIL: 0 = off, 1 = folded residual-tail backward (identity shortcut in the block the gradient leaves), 2 = ... with a
+  // shortcut conv there (a second product sum).  Separate instantiations: the second operand costs 8-16 VGPRs
+  static_assert(!(TAIL && SWB), "the tail backward belongs to the `a` conv (ADD epilogues)");
+  constexpr bool TAILR = TAIL == 2;
   constexpr int NT = MT * KT;                       // dW tiles
   constexpr int TPW = (NT + 3) / 4;                 // dW tiles per wave
   constexpr int NKS = NT >= 4 ? 1 : 4 / NT;         // k-parts (points) per tile when there are fewer tiles than waves
@@ -105,6 +115,9 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
   // ---- register-staged prefetch of the next tile: row (tid>>4) + 16*i, 8 points at unit (tid&15)
   const int srow = tid >> 4, sunit = tid & 15;
   hx8 rg[NVY], ry[NVY], rx[SWB ? 1 : NVX];
+  // TAIL: [y > 0] of this thread's staged x vectors (8 bits each).  The epilogue owns the same (row, unit) positions as
+  // the staging -- row (tid >> 4) + 16 * i, unit tid & 15 -- and rx is re-loaded with the next tile before the epilogue runs
+  unsigned ymask[TAIL ? NVX : 1];
   auto issue = [&](int tile) {
     const int n = tile / tiles_per_n;
     const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
@@ -150,6 +163,12 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
       for (int i = 0; i < NVX; i++) {
         const int m = srow + 16 * i;
         *(hx8*)&Xs[m * XP + sunit * 8] = rx[i];   // zeros where m >= Ci or p >= P
+        if constexpr (TAIL) {
+          unsigned mk = 0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) mk |= ((float)rx[i][e] > 0.f ? 1u : 0u) << e;
+          ymask[i] = mk;
+        }
       }
     }
   };
@@ -159,6 +178,16 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
   if constexpr (SWB) {
 #pragma unroll
     for (int i = 0; i < ROWS_PT; i++) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
+  // TAIL: per-channel sums of the masked gradient (kept over all tiles of the workgroup: they are not per sample)
+  float tg[TAIL ? ROWS_PT : 1], tgc[TAIL ? ROWS_PT : 1], tgr[TAILR ? ROWS_PT : 1];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) { tg[i] = 0.f; tgc[i] = 0.f; }
+  }
+  if constexpr (TAILR) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) tgr[i] = 0.f;
   }
   auto flush_sums = [&](int n) {
     if constexpr (SWB) {
@@ -255,6 +284,7 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
     constexpr bool EPL8 = (EPI == X3D_EPI_ADD) || SWB;
     hx8 epl8[EPL8 ? ROWS_PT : 1];
     hx4 epl4[EPL8 ? 1 : ROWS_PT];
+    hx8 tc8[TAIL ? ROWS_PT : 1], tr8[TAILR ? ROWS_PT : 1];
     float esb[SWB ? ROWS_PT : 1], etb[SWB ? ROWS_PT : 1], egt[SWB ? ROWS_PT : 1];
     const bool epl4_vec = (a.eW & 7) == 0;
     // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills)
@@ -263,6 +293,19 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
       const int m = m0 + (tid >> 4) + 16 * i;
       const long long p = p0 + oc;
       const bool ok = m < a.Ci && p < a.P;
+      if constexpr (TAIL) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) tc8[i][e] = (H)0.f;
+        if constexpr (TAILR) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) tr8[i][e] = (H)0.f;
+        }
+        if (ok) {
+          const long long ot = ((long long)n * a.Ci + m) * a.P + p;
+          tc8[i] = *(const hx8*)((const T*)a.tail_c + ot);
+          if constexpr (TAILR) tr8[i] = *(const hx8*)((const T*)a.tail_r + ot);
+        }
+      }
       if constexpr (EPL8) {
 #pragma unroll
         for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
@@ -360,6 +403,17 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
           }
           VecIO<H, 8>::store(&Xs[ml * XP + oc], xh);
         }
+        if constexpr (TAIL) {   // Add + ReLU backward of the block this gradient leaves: mask, then the BN_c / BN_r backward sums
+          const unsigned mk = ymask[i];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float gm = ((mk >> e) & 1u) ? round_to<T>(val[e]) : 0.f;   // the sums describe dx as stored (as x3d_tail_bwd's do)
+            val[e] = gm;
+            tg[i] += gm;
+            tgc[i] += gm * (float)tc8[i][e];
+            if constexpr (TAILR) tgr[i] += gm * (float)tr8[i][e];
+          }
+        }
         VecIO<T, 8>::store((T*)a.dx + o, val);
       }
     }
@@ -369,6 +423,26 @@ __global__ __launch_bounds__(256, FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(con
     }
   }
   if (tile_begin < tile_end) flush_sums(n_prev);
+
+  if constexpr (TAIL) {
+    if (tile_begin < tile_end) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) {
+        const float s0 = row16_sum(tg[i]), s1 = row16_sum(tgc[i]);
+        float s2 = 0.f;
+        if constexpr (TAILR) s2 = row16_sum(tgr[i]);
+        const int m = m0 + (tid >> 4) + 16 * i;
+        if ((tid & 15) == 0 && m < a.Ci) {
+          atomic_add_d(&a.tail_sums_c[m * 2], (double)s0);
+          atomic_add_d(&a.tail_sums_c[m * 2 + 1], (double)s1);
+          if constexpr (TAILR) {
+            atomic_add_d(&a.tail_sums_r[m * 2], (double)s0);
+            atomic_add_d(&a.tail_sums_r[m * 2 + 1], (double)s2);
+          }
+        }
+      }
+    }
+  }
 
   // ---- dW partial -> global (fp32 atomics)
   if (tile_begin < tile_end) {
@@ -394,12 +468,13 @@ static inline size_t fb_lds_bytes(int MT, int KT, int Kp, bool swb) {
          (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0) + (size_t)KT * 32 * 16;
 }
 
-template <typename H, int MT, int KT, int EPI>
+template <typename H, int MT, int KT, int EPI, int TAIL = 0>
 static int fb_launch(PwBwdArgs& a, hipStream_t st) {
   const size_t lds = fb_lds_bytes(MT, KT, a.Kp, EPI == X3D_EPI_SWISH_BWD);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd: needs %zu B of LDS", lds);
-  X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d>", HV<H>::name, MT, KT, EPI);
-  auto kern = pw_bwd_fused_kernel<H, MT, KT, EPI>;
+  if constexpr (TAIL != 0) X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d, %d>", HV<H>::name, MT, KT, EPI, TAIL);
+  else X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d>", HV<H>::name, MT, KT, EPI);
+  auto kern = pw_bwd_fused_kernel<H, MT, KT, EPI, TAIL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -451,6 +526,15 @@ template <typename H, int EPI>
 static int fb_pick(PwBwdArgs& a, hipStream_t st) {
   int MT = 0, KT = 0;
   if (!fb_shape(a.Ci, a.Co, &MT, &KT)) { x3d_set_error("pw_bwd: unsupported tile shape"); return X3D_ERR_INVALID; }
+  if constexpr (EPI != X3D_EPI_SWISH_BWD) {
+    if (a.tail_c) {          // fb_supported: only panels of one or two row tiles carry the tail
+#define FB_TCASE(M_, K_) if (MT == M_ && KT == K_) return a.tail_r ? fb_launch<H, M_, K_, EPI, 2>(a, st) : fb_launch<H, M_, K_, EPI, 1>(a, st);
+      FB_TCASE(1, 1) FB_TCASE(1, 2) FB_TCASE(1, 3) FB_TCASE(1, 4) FB_TCASE(2, 2)
+#undef FB_TCASE
+      x3d_set_error("pw_bwd: no tail instantiation for this panel");
+      return X3D_ERR_INVALID;
+    }
+  }
 #define FB_CASE(M_, K_) if (MT == M_ && KT == K_) return fb_launch<H, M_, K_, EPI>(a, st);
   FB_CASE(1, 1) FB_CASE(1, 2) FB_CASE(1, 3) FB_CASE(1, 4) FB_CASE(2, 1) FB_CASE(2, 2) FB_CASE(2, 3) FB_CASE(2, 4)
   FB_CASE(4, 1) FB_CASE(4, 2)
@@ -473,6 +557,13 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
   for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;
   if (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8)) return false;
   if (b->epi != X3D_EPI_ADD && b->epi != X3D_EPI_ADD_STRIDED && b->epi != X3D_EPI_SWISH_BWD) return false;
+  if (b->tail_c) {     // the folded residual-tail backward: `a`-conv epilogues, panels of <= 2 row tiles, one slice
+    // panels whose tail instantiation stays inside the register file (r03e: the 2x3 / 2x4 panels spill 52-240 bytes per
+    // lane with the two extra epilogue operands and lose more than the separate tail pass costs: 108<->48 @28x28 128 -> 209 us)
+    if (b->epi == X3D_EPI_SWISH_BWD || ceil_div(ceil_div(b->Cin, 32), MT) > 1) return false;
+    if (!(MT == 1 || (MT == 2 && KT == 2))) return false;
+    if (((uintptr_t)b->tail_c % 16) || (b->tail_r && ((uintptr_t)b->tail_r % 16))) return false;
+  }
   const int Kp = (b->Cout + 15) & ~15;
   return fb_lds_bytes(MT, KT, Kp, b->epi == X3D_EPI_SWISH_BWD) <= 160 * 1024;
 }
@@ -488,6 +579,8 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
     X3D_REQUIRE(b->braw && b->b_scale_shift && b->nc_sums, "pw_bwd: SWISH_BWD needs braw/b_scale_shift/nc_sums");
   else
     X3D_REQUIRE(b->x && b->add, "pw_bwd: ADD epilogues need x (conv input) and add");
+  X3D_REQUIRE(!b->tail_c || (b->tail_sums_c && (!b->tail_r || b->tail_sums_r)) || x3d_describe.out, "pw_bwd: tail_c / tail_r need their sums");
+  X3D_REQUIRE(b->tail_c || !b->tail_r, "pw_bwd: tail_r without tail_c");
   PwBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
@@ -495,6 +588,7 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   a.dx = b->dx; a.add = b->add; a.braw = b->braw; a.b_ss = b->b_scale_shift; a.egate = b->gate; a.nc_sums = b->nc_sums;
   a.eH = b->H; a.eW = b->W;
   a.x = b->x; a.dw = b->dw;
+  a.tail_c = b->tail_c; a.tail_r = b->tail_r; a.tail_sums_c = b->tail_sums_c; a.tail_sums_r = b->tail_sums_r;
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin; a.Kp = (b->Cout + 15) & ~15;
   a.P = (long long)b->T * b->H * b->W;
   hipStream_t st = (hipStream_t)stream;

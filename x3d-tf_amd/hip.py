@@ -41,7 +41,8 @@ class PwBwdArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("w_panel", _vp), ("dx", _vp), ("epi", _i),
                 ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
                 ("x", _vp), ("dw", _vp),
-                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+                ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
+                ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp)]
 
 
 class EvalViewsArgs(C.Structure):

@@ -939,15 +939,23 @@ class X3D:
         pl.bwd_stage_marks[len(a.stages)] = len(Bk)   # head finished
 
         # ---- residual blocks, last to first ----------------------------------------------------
-        for B in reversed(pl.blocks):
+        # The Add + ReLU backward of a block (g = dy * [y > 0] with the BN_c / BN_r backward sums) is applied by the kernel that
+        # PRODUCES dy -- the `a`-conv backward of the next block, whose conv input is this block's y -- wherever the fused
+        # x3d_pw_bwd covers that layer with its tail epilogue; x3d_tail_bwd remains for the other blocks (and X3D_NO_TAIL_FOLD=1)
+        fold_tail = self._fuse_pw_bwd and os.environ.get("X3D_NO_TAIL_FOLD") != "1"
+        for bi in range(len(pl.blocks) - 1, -1, -1):
+            B = pl.blocks[bi]
+            prev = pl.blocks[bi - 1] if bi > 0 else None
             b: BlockSpec = B.spec
             pre = block_prefix(b)
             q = f"{pre}/bottleneck"
             P_in, P_out = t * B.hh * B.ww, t * B.ho * B.wo
             B.bwd_start, B.dy_view = len(Bk), dy.view(B.y.shape)
-            # dy -> g = dy*[y>0] in place, with the BN_c (and BN_r) backward sums
-            pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
-                   ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
+            B.tail_folded = getattr(B, "tail_folded", False)
+            if not B.tail_folded:
+                # dy -> g = dy*[y>0] in place, with the BN_c (and BN_r) backward sums
+                pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
+                       ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
             gten = dy
             pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_c.bsums), float(n * P_out), B.bn_c.mi, p[f"{q}/bn_c/gamma"],
                    B.bn_c.coef, g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout)
@@ -1014,7 +1022,18 @@ class X3D:
             da.w_panel = self._wp(f"{q}/a/kernel", True)
             fa = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
                                _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt)
-            if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
+            ft = None
+            if fold_tail and prev is not None:   # B.x is prev.y: this launch can apply prev's Add + ReLU backward to its dx
+                ft = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
+                                   _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt,
+                                   _p(prev.c_raw), _p(prev.r_raw), None, None)
+                if not pl.lib.x3d_pw_bwd_supported(C.byref(ft)):
+                    ft = None
+            if ft is not None:
+                prev.tail_folded = True
+                pl.rec(Bk, "x3d_pw_bwd", ("field", ft, {"tail_sums_c": prev.bn_c.bsums,
+                                                         "tail_sums_r": prev.bn_r.bsums if prev.bn_r else None}))
+            elif self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
                 pl.rec(Bk, "x3d_pw_bwd", fa)
             else:
                 pl.rec_side(Bk, "x3d_pw_wgrad", wa)

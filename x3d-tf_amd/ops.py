@@ -189,14 +189,17 @@ def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None
     return dx
 
 
-def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_ss=None, gate=None, nc_sums=None):
+def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_ss=None, gate=None, nc_sums=None,
+           tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None):
     """Fused dgrad + wgrad (x3d_pw_bwd).  g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]; dw: [Cout,Cin] +=.
+    tail_c (/ tail_r) + their [Cin, 2] fp64 sums: the folded Add + ReLU backward of the block whose output is x.
     Returns False (nothing launched) when the fused kernel does not cover the call."""
-    _chk(g, yraw, coef, w_panel, dx, dw, x, add, braw, b_ss, gate, nc_sums)
+    _chk(g, yraw, coef, w_panel, dx, dw, x, add, braw, b_ss, gate, nc_sums, tail_c, tail_r, tail_sums_c, tail_sums_r)
     n, cout, t, h, ww = g.shape
     cin = dx.shape[1]
     a = hip.PwBwdArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w_panel), ptr(dx), epi, ptr(add), ptr(braw), ptr(b_ss),
-                      ptr(gate), ptr(nc_sums), ptr(x), ptr(dw), n, cin, cout, t, h, ww, hip.dtype_code(g.dtype))
+                      ptr(gate), ptr(nc_sums), ptr(x), ptr(dw), n, cin, cout, t, h, ww, hip.dtype_code(g.dtype),
+                      ptr(tail_c), ptr(tail_r), ptr(tail_sums_c), ptr(tail_sums_r))
     import ctypes as C
     if not hip.load().x3d_pw_bwd_supported(C.byref(a)):
         return False
