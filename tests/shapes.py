@@ -98,7 +98,9 @@ PW_BWD = [
     (2, 24, 54, 2, 28, 28, "add_strided"),
     (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
     (1, 96, 32, 2, 10, 12, "swish_bwd"),
-    (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv
+    (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv: the weights-stationary fused kernel (pw_bwd_wst.hip)
+    (24, 216, 96, 8, 14, 14, "swish_bwd"),     # ... several tiles per persistent workgroup, across sample boundaries
+    (3, 200, 90, 1, 10, 12, "swish_bwd"),      # ... widths off the grid, a partial last tile per sample (P = 120)
     (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
     (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
 ]

@@ -375,6 +375,24 @@ __device__ __forceinline__ float swish_grad_(float v) {
   return s * (1.0f + v * (1.0f - s));
 }
 
+// swish backward of the `c` conv's input on FOLDED per-row coefficients (the forward prologue folds the SE gate the same way:
+// (s*g)*x + t*g):  u = su*b + tu ;  sigmoid(u) = 1 / (1 + 2^(nu*b + nt)),  (nu, nt) = -log2(e) * (su, tu) ;
+// xh = swish(u) = u*sg ;  d = swish'(u) = sg + xh*(1 - sg).  11 VALU + 2 transcendental per element where
+// (s*b + t)*g -> __expf -> s*(1 + u*(1 - s)) took 15 + 2: the epilogues that run it are VALU-bound (1.6 G elements per X3D-M step)
+struct SwishCoef { float su, tu, nu, nt; };
+__device__ __forceinline__ SwishCoef swish_coef(float s, float t, float g) {
+  SwishCoef c;
+  c.su = s * g; c.tu = t * g;
+  c.nu = -1.4426950408889634f * c.su; c.nt = -1.4426950408889634f * c.tu;
+  return c;
+}
+__device__ __forceinline__ void swish_bwd_(const SwishCoef& c, float b, float& xh, float& d) {
+  const float u = fmaf(c.su, b, c.tu);
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(c.nu, b, c.nt)));
+  xh = u * sg;
+  d = fmaf(xh, 1.0f - sg, sg);
+}
+
 // v[e] = act(v[e]) for a whole register vector with ONE uniform branch on the (runtime, kernel-uniform) activation.
 // Written per element -- `if (act == RELU) u = max(u, 0); else if (act == SWISH) u = swish(u);` inside the unrolled
 // loop -- the compiler kept a scalar compare + branch (+ s_nop) PER ELEMENT: 63 branches per staged chunk, +20 us on a

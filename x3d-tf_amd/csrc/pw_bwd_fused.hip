@@ -18,6 +18,8 @@
 // dW partials stay in accumulators across the tiles of a workgroup and are added to dw with fp32 atomics once.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pw_gemm.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_f;
@@ -53,7 +55,10 @@ struct PwBwdArgs {
 // MT: 32-row tiles of Ci (dX rows / dW columns); KT: 32-row tiles of Co (dY rows / dW rows)
 // (with the tail epilogue the two-tile panels need ~190 VGPRs: two workgroups per CU instead of three beat 44-88 bytes of
 // scratch traffic per lane in the tile loop -- 24<->54 @56x56: 273 us plain, 355 us with the spilling tail, r03e)
-template <typename H, int MT, int KT, int EPI, int TAIL = 0>
+// E4V (strided-add epilogue): rows of 8k points -- the shortcut gradient of an output vector is one 8-byte load; false: element
+// loads inside the epilogue.  A template parameter, not a runtime branch: the element path's conditional loads inside the tile
+// loop made every wait of the iteration a vmcnt(0), whichever path ran.
+template <typename H, int MT, int KT, int EPI, int TAIL = 0, bool E4V = true>
 __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT)) void pw_bwd_fused_kernel(const PwBwdArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4; typedef typename HV<H>::x2 hx2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -118,32 +123,30 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
   // TAIL: [y > 0] of this thread's staged x vectors (8 bits each).  The epilogue owns the same (row, unit) positions as
   // the staging -- row (tid >> 4) + 16 * i, unit tid & 15 -- and rx is re-loaded with the next tile before the epilogue runs
   unsigned ymask[TAIL ? NVX : 1];
-  auto issue = [&](int tile) {
+  // Every load of the tile loop is UNCONDITIONAL (clamped address; the value is zeroed / never used where the row or point
+  // is outside): vmcnt retires in order and the compiler cannot count conditional accesses, so one conditional load made
+  // every later wait of the iteration a vmcnt(0) -- the epilogue's wait for its own operands then also drained the next
+  // tile's prefetch, and the commit's wait for the prefetch drained the epilogue's stores (tools/scan_waitcnt.py).
+  auto issue = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tiles_per_n;
     const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
-    hx8 z;
-#pragma unroll
-    for (int e = 0; e < 8; e++) z[e] = (H)0.f;
 #pragma unroll
     for (int i = 0; i < NVY; i++) {
       const int k = srow + 16 * i;
-      rg[i] = z; ry[i] = z;
-      if (k < a.Co && p < a.P) {
-        const long long o = ((long long)n * a.Co + k) * a.P + p;
-        rg[i] = *(const hx8*)((const T*)a.g + o);
-        ry[i] = *(const hx8*)((const T*)a.yraw + o);
-      }
+      const long long o = (k < a.Co && p < a.P) ? ((long long)n * a.Co + k) * a.P + p : 0;   // (rows >= Co: coefficients are zero)
+      rg[i] = *(const hx8*)((const T*)a.g + o);
+      ry[i] = *(const hx8*)((const T*)a.yraw + o);
     }
     if constexpr (!SWB) {
 #pragma unroll
       for (int i = 0; i < NVX; i++) {
         const int m = m0 + srow + 16 * i;
-        rx[i] = z;
-        if (m < a.Ci && p < a.P) rx[i] = *(const hx8*)((const T*)a.x + ((long long)n * a.Ci + m) * a.P + p);
+        const long long o = (m < a.Ci && p < a.P) ? ((long long)n * a.Ci + m) * a.P + p : 0;
+        rx[i] = *(const hx8*)((const T*)a.x + o);
       }
     }
   };
-  auto commit = [&](int tile) {
+  auto commit = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tiles_per_n;
     const long long p = (long long)(tile - n * tiles_per_n) * BN + sunit * 8;
     const bool pin = p < a.P;
@@ -162,7 +165,11 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
 #pragma unroll
       for (int i = 0; i < NVX; i++) {
         const int m = srow + 16 * i;
-        *(hx8*)&Xs[m * XP + sunit * 8] = rx[i];   // zeros where m >= Ci or p >= P
+        if (!(pin && m0 + m < a.Ci)) {            // zeros where m >= Ci or p >= P
+#pragma unroll
+          for (int e = 0; e < 8; e++) rx[i][e] = (H)0.f;
+        }
+        *(hx8*)&Xs[m * XP + sunit * 8] = rx[i];
         if constexpr (TAIL) {
           unsigned mk = 0;
 #pragma unroll
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
 #pragma unroll
     for (int i = 0; i < ROWS_PT; i++) tgr[i] = 0.f;
   }
-  auto flush_sums = [&](int n) {
+  auto flush_sums = [&](int n) __attribute__((always_inline)) {
     if constexpr (SWB) {
 #pragma unroll
       for (int i = 0; i < ROWS_PT; i++) {
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
     for (int j = 0; j < 16; j++) acc_dw[s][j] = 0.f;
 
   // dW[co][ci] += dY[co][:] . Xh[ci][:] over the 128 points of the tile
-  auto wgrad_mfma = [&]() {
+  auto wgrad_mfma = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       int id = wid + 4 * s, kpart = 0;
@@ -244,19 +251,111 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
     }
   };
 
+  // BN_b scale / shift of the rows this thread owns in the epilogue (the same for every tile: loaded once -- except in the
+  // tallest panels, where sixteen more live registers spill: 48<->108 @28x28 162 -> 301 us; those reload them per tile)
+  constexpr bool COEF_ONCE = MT <= 2;
+  float esb[SWB ? ROWS_PT : 1], etb[SWB ? ROWS_PT : 1];
+  if constexpr (SWB && COEF_ONCE) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) {
+      const int m = m0 + (tid >> 4) + 16 * i;
+      esb[i] = m < a.Ci ? a.b_ss[m * 2] : 0.f;
+      etb[i] = m < a.Ci ? a.b_ss[m * 2 + 1] : 0.f;
+    }
+  }
+
   if (tile_begin < tile_end) issue(tile_begin);
   int n_prev = tile_begin < tile_end ? tile_begin / tiles_per_n : 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
+    __syncthreads();            // every reader of the previous tile's dY / Xh / slab is done
+    commit(tile);
+    __syncthreads();
+    // (the per-sample flush -- conditional atomics the compiler cannot count -- sits BEHIND the commit: in front of it the
+    // commit's wait for the prefetched tile was a vmcnt(0) that also drained the previous tile's stores)
     if constexpr (SWB) {
       if (n != n_prev) flush_sums(n_prev);
     }
     n_prev = n;
-    __syncthreads();            // every reader of the previous tile's dY / Xh / slab is done
-    commit(tile);
-    __syncthreads();
-    if (tile + 1 < tile_end) issue(tile + 1);
+
+    // ---- global loads of this tile's epilogue, THEN the next tile's prefetch: the epilogue's wait (vmcnt(#prefetch loads))
+    // leaves the prefetch in flight, and the matrix-core phase below covers the epilogue operands' latency
+    const int oc = (tid & 15) * 8;
+    constexpr bool EPL8 = (EPI == X3D_EPI_ADD) || SWB;
+    hx8 epl8[EPL8 ? ROWS_PT : 1];
+    hx4 epl4[EPL8 ? 1 : ROWS_PT];
+    hx8 tc8[TAIL ? ROWS_PT : 1], tr8[TAILR ? ROWS_PT : 1];
+    float egt[SWB ? ROWS_PT : 1];
+    constexpr bool epl4_vec = E4V;   // rows of 8k points: the strided shortcut gradient as 8-byte loads
+    // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills -- and so does the
+    // 2 x 4 panel of the `c` convs, whose hoisted braw rows live across both matrix-core phases: 48<->108 @28x28 162 -> 301 us)
+    constexpr bool HOIST = MT <= 2 && !(SWB && MT * KT >= 8);
+    auto epi_load = [&](int i) __attribute__((always_inline)) {
+      const int m = m0 + (tid >> 4) + 16 * i;
+      const long long p = p0 + oc;
+      const bool ok = m < a.Ci && p < a.P;
+      // HOIST: unconditional loads from a clamped address (countable: see issue()).  The tall panels load next to the use,
+      // inside the slab loop, and keep the load CONDITIONAL: without the branch the scheduler hoists all eight rows' loads to
+      // the top of the unrolled loop and the panel spills 300 bytes per lane (48<->108 @28x28: 162 -> 301 us)
+      const bool ld = HOIST || ok;
+      const long long orow = ok ? ((long long)n * a.Ci + m) * a.P + p : 0;
+      if constexpr (TAIL) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) tc8[i][e] = (H)0.f;
+        if constexpr (TAILR) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) tr8[i][e] = (H)0.f;
+        }
+        if (ld) {
+          const hx8 lc = *(const hx8*)((const T*)a.tail_c + orow);
+          if (ok) tc8[i] = lc;
+          if constexpr (TAILR) {
+            const hx8 lr = *(const hx8*)((const T*)a.tail_r + orow);
+            if (ok) tr8[i] = lr;
+          }
+        }
+      }
+      if constexpr (EPL8) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
+        if (ld) {
+          const hx8 l8 = *(const hx8*)((const T*)(SWB ? a.braw : a.add) + orow);
+          if (ok) epl8[i] = l8;
+        }
+        if constexpr (SWB) {
+          if constexpr (!COEF_ONCE) {
+            esb[i] = m < a.Ci ? a.b_ss[m * 2] : 0.f;
+            etb[i] = m < a.Ci ? a.b_ss[m * 2 + 1] : 0.f;
+          }
+          const bool okg = m < a.Ci && a.egate;
+          egt[i] = 1.0f;
+          if (HOIST || okg) {
+            const float gl = (a.egate ? a.egate : a.b_ss)[okg ? (long long)n * a.Ci + m : 0];
+            if (okg) egt[i] = gl;
+          }
+        }
+      } else {
+        const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
+        const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
+        const int T_ = (int)a.P / hw;
+        const int t = (int)p / hw;
+        const int rem = (int)p - t * hw;
+        const int h = rem / a.eW, w = rem - h * a.eW;
+        const bool okv = ok && epl4_vec && (h & 1) == 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) epl4[i][e] = (H)0.f;
+        if (HOIST || okv) {
+          const hx4 l4 = *(const hx4*)((const T*)a.add + (okv ? ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1) : 0));
+          if (okv) epl4[i] = l4;
+        }
+      }
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int i = 0; i < ROWS_PT; i++) epi_load(i);
+    }
+    issue(min(tile + 1, tile_end - 1));   // (past the end: the last tile again -- the number of loads in flight stays static)
 
     // ---- dX tile: acc[s] (rows s*32.., this wave's 32 points) = W^T dY
     f32x16 acc[MT];
@@ -278,62 +377,10 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
     if constexpr (!SWB) wgrad_mfma();   // Xh came with the tile: finish with the dY tile before the slab reuses its LDS
 
     // ---- epilogue in 32-row slabs through LDS: thread owns rows (tid>>4) + 16*ii, 8 points at (tid&15)*8
-    const int oc = (tid & 15) * 8;
-    // every global load of the epilogue before its first store (vmcnt retires in order, stores included: a load
-    // issued behind a store waits for the store's write latency)
-    constexpr bool EPL8 = (EPI == X3D_EPI_ADD) || SWB;
-    hx8 epl8[EPL8 ? ROWS_PT : 1];
-    hx4 epl4[EPL8 ? 1 : ROWS_PT];
-    hx8 tc8[TAIL ? ROWS_PT : 1], tr8[TAILR ? ROWS_PT : 1];
-    float esb[SWB ? ROWS_PT : 1], etb[SWB ? ROWS_PT : 1], egt[SWB ? ROWS_PT : 1];
-    const bool epl4_vec = (a.eW & 7) == 0;
-    // (the tallest panels keep the loads next to their use: hoisting eight rows' worth of registers spills)
-    constexpr bool HOIST = MT <= 2;
-    auto epi_load = [&](int i) {
-      const int m = m0 + (tid >> 4) + 16 * i;
-      const long long p = p0 + oc;
-      const bool ok = m < a.Ci && p < a.P;
-      if constexpr (TAIL) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) tc8[i][e] = (H)0.f;
-        if constexpr (TAILR) {
-#pragma unroll
-          for (int e = 0; e < 8; e++) tr8[i][e] = (H)0.f;
-        }
-        if (ok) {
-          const long long ot = ((long long)n * a.Ci + m) * a.P + p;
-          tc8[i] = *(const hx8*)((const T*)a.tail_c + ot);
-          if constexpr (TAILR) tr8[i] = *(const hx8*)((const T*)a.tail_r + ot);
-        }
-      }
-      if constexpr (EPL8) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) epl8[i][e] = (H)0.f;
-        if (ok) epl8[i] = *(const hx8*)((const T*)(SWB ? a.braw : a.add) + ((long long)n * a.Ci + m) * a.P + p);
-        if constexpr (SWB) {
-          esb[i] = m < a.Ci ? a.b_ss[m * 2] : 0.f;
-          etb[i] = m < a.Ci ? a.b_ss[m * 2 + 1] : 0.f;
-          egt[i] = (m < a.Ci && a.egate) ? a.egate[(long long)n * a.Ci + m] : 1.0f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) epl4[i][e] = (H)0.f;
-        if (ok && epl4_vec) {
-          const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
-          const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-          const int T_ = (int)a.P / hw;
-          const int t = (int)p / hw;
-          const int rem = (int)p - t * hw;
-          const int h = rem / a.eW, w = rem - h * a.eW;
-          if ((h & 1) == 0)
-            epl4[i] = *(const hx4*)((const T*)a.add + ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1));
-        }
-      }
-    };
-    if constexpr (HOIST) {
-#pragma unroll
-      for (int i = 0; i < ROWS_PT; i++) epi_load(i);
-    }
+    // dx stores are bounds-checked buffer stores (an offset past the sample's [Ci][P] matrix is dropped): a static number of
+    // stores per tile, which the commit's wait for the prefetched tile can count instead of draining
+    __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((T*)a.dx + (long long)n * a.Ci * a.P, 0,
+                                                                   (int)((long long)a.Ci * a.P * 2), 0x00020000);
 #pragma unroll
     for (int sl = 0; sl < MT; sl++) {
       if constexpr (!HALF_SLAB) {
@@ -355,14 +402,16 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
         const int ml = sl * 32 + (tid >> 4) + 16 * ii;   // row inside this workgroup's slice
         const int m = m0 + ml;
         const long long p = p0 + oc;
-        if (m >= a.Ci || p >= a.P) continue;
+        // no branch around the row: rows / points outside run the arithmetic on zeros (their accumulators, staged operands
+        // and coefficients are zero) and their store is dropped by the buffer bounds check
+        const bool rvalid = m < a.Ci && p < a.P;
+        if constexpr (!HOIST) { if (!rvalid) continue; }   // (the tall panels keep the branchy form: see epi_load)
         float val[8];
         {
           const f32x4 v0 = *(const f32x4*)&Os[row * OP + oc], v1 = *(const f32x4*)&Os[row * OP + oc + 4];
 #pragma unroll
           for (int e = 0; e < 4; e++) { val[e] = v0[e]; val[4 + e] = v1[e]; }
         }
-        const long long o = ((long long)n * a.Ci + m) * a.P + p;   // P % 8 == 0: the 8 points are all inside
         if constexpr (!HOIST) epi_load(i);
         if constexpr (EPI == X3D_EPI_ADD) {
 #pragma unroll
@@ -374,7 +423,7 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
           if (epl4_vec) {   // loaded above (zeros on odd rows)
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
-          } else {
+          } else if (rvalid) {
             for (int e = 0; e < 8; e++) {
               const int pe = (int)p + e;
               const int t = pe / hw;
@@ -390,13 +439,12 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
           float b[8], xh[8];
 #pragma unroll
           for (int e = 0; e < 8; e++) b[e] = (float)epl8[i][e];
-          const float sb = esb[i], tb = etb[i], gt = egt[i];
+          const SwishCoef sc_ = swish_coef(esb[i], etb[i], egt[i]);
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            const float u = (sb * b[e] + tb) * gt;
-            const float sg = sigmoidf_(u);
-            xh[e] = u * sg;                                        // conv input of the forward pass
-            const float dv = val[e] * (sg * (1.0f + u * (1.0f - sg)));
+            float d_;
+            swish_bwd_(sc_, b[e], xh[e], d_);                      // xh: conv input of the forward pass
+            const float dv = val[e] * d_;
             val[e] = dv;
             st1[i] += dv;
             st2[i] += dv * b[e];
@@ -414,7 +462,14 @@ __global__ __launch_bounds__(256, (TAIL && MT * KT == 2) ? 2 : FB_WAVES(MT, KT))
             if constexpr (TAILR) tgr[i] += gm * (float)tr8[i][e];
           }
         }
-        VecIO<T, 8>::store((T*)a.dx + o, val);
+        {
+          hx8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; e++) ov[e] = (H)val[e];
+          typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ov), dxr,
+                                                 rvalid ? (unsigned)(((long long)m * a.P + p) * 2) : 0x80000000u, 0, 0);
+        }
       }
     }
     if constexpr (SWB) {
@@ -468,13 +523,17 @@ static inline size_t fb_lds_bytes(int MT, int KT, int Kp, bool swb) {
          (swb ? (size_t)(MT == 4 ? 16 : 32) * FB_OP * 4 : 0) + (size_t)KT * 32 * 16;
 }
 
-template <typename H, int MT, int KT, int EPI, int TAIL = 0>
+template <typename H, int MT, int KT, int EPI, int TAIL = 0, bool E4V = true>
 static int fb_launch(PwBwdArgs& a, hipStream_t st) {
+  if constexpr (EPI == X3D_EPI_ADD_STRIDED && E4V) {
+    if ((a.eW & 7) != 0) return fb_launch<H, MT, KT, EPI, TAIL, false>(a, st);
+  }
   const size_t lds = fb_lds_bytes(MT, KT, a.Kp, EPI == X3D_EPI_SWISH_BWD);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd: needs %zu B of LDS", lds);
-  if constexpr (TAIL != 0) X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d, %d>", HV<H>::name, MT, KT, EPI, TAIL);
+  if constexpr (!E4V) X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d, %d, e>", HV<H>::name, MT, KT, EPI, TAIL);
+  else if constexpr (TAIL != 0) X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d, %d>", HV<H>::name, MT, KT, EPI, TAIL);
   else X3D_DESCRIBE("pw_bwd_fused_kernel<%s, %d, %d, %d>", HV<H>::name, MT, KT, EPI);
-  auto kern = pw_bwd_fused_kernel<H, MT, KT, EPI, TAIL>;
+  auto kern = pw_bwd_fused_kernel<H, MT, KT, EPI, TAIL, E4V>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -543,8 +602,13 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
   return X3D_ERR_INVALID;
 }
 
+// the weights-stationary fused backward of the stage-4 `c` conv (pw_bwd_wst.hip)
+bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b);
+int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st);
+
 // eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
 static bool fb_supported(const x3d_pw_bwd_args* b) {
+  if (pw_bwd_wst_applies(b)) return true;
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw) return false;
   int MT = 0, KT = 0;
   if (!fb_shape(b->Cin, b->Cout, &MT, &KT)) return false;
@@ -552,6 +616,7 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
   if (ceil_div(ceil_div(b->Cin, 32), MT) > 4) return false;
   const long long P = (long long)b->T * b->H * b->W;
   if (P % 8 || P >= (1ll << 31)) return false;      // 32-bit point indices in the kernel
+  if ((long long)b->Cin * P * 2 >= (1ll << 31)) return false;   // one sample's dx inside the 2 GB buffer-store window
   const void* ps[] = {b->g, b->yraw, b->dx, b->w_panel, b->epi == X3D_EPI_SWISH_BWD ? b->braw : b->x,
                       b->epi == X3D_EPI_ADD ? b->add : nullptr};
   for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;
@@ -575,6 +640,7 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   X3D_REQUIRE(b->N > 0 && b->Cin > 0 && b->Cout > 0 && b->T > 0 && b->H > 0 && b->W > 0, "pw_bwd: bad extents");
   X3D_REQUIRE(fb_supported(b), "pw_bwd: shape / alignment / epilogue not covered by the fused kernel "
                                "(x3d_pw_bwd_supported() == 0): use x3d_pw_dgrad + x3d_pw_wgrad");
+  if (pw_bwd_wst_applies(b)) return pw_bwd_wst(b, (hipStream_t)stream);
   if (b->epi == X3D_EPI_SWISH_BWD)
     X3D_REQUIRE(b->braw && b->b_scale_shift && b->nc_sums, "pw_bwd: SWISH_BWD needs braw/b_scale_shift/nc_sums");
   else

@@ -308,6 +308,16 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     }
   };
 
+  // EPI_BNADD: the output rows' coefficients are the same for every tile of the workgroup
+  float bna_s[EPI == EPI_BNADD ? ROWS_PT : 1], bna_t[EPI == EPI_BNADD ? ROWS_PT : 1], bna_g[EPI == EPI_BNADD ? ROWS_PT : 1];
+  if constexpr (EPI == EPI_BNADD) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) {
+      const int m = m0 + (tid >> 4) + 16 * i;
+      bnadd_coef(a, m, m < a.M, bna_s[i], bna_t[i], bna_g[i]);
+    }
+  }
+
   int n_prev = tile_begin < tile_end ? tile_begin / tiles_per_n : 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int n = tile / tiles_per_n;
@@ -367,14 +377,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     const int egv = !EPL4 ? 0 : ((a.eW & 7) == 0 ? 8 : ((a.eW & 3) == 0 ? 4 : ((a.eW & 1) == 0 ? 2 : 0)));
     const bool epl4_vec = egv != 0;
     constexpr bool SWB_ = (EPI == X3D_EPI_SWISH_BWD);
-    // per-row BN_b scale/shift, SE gate (SWISH_BWD) | output scale, shift, scale of `add` (BNADD)
+    // per-row BN_b scale/shift, SE gate (SWISH_BWD) | output scale, shift, scale of `add` (BNADD: loaded once, before the
+    // tile loop -- a global load here sits BEHIND the next tile's prefetch and its wait is a vmcnt(0))
     float esb[(SWB_ || BNA_) ? ROWS_PT : 1], etb[(SWB_ || BNA_) ? ROWS_PT : 1], egt[(SWB_ || BNA_) ? ROWS_PT : 1];
     if constexpr (BNA_) {
 #pragma unroll
-      for (int i = 0; i < ROWS_PT; i++) {
-        const int m = m0 + (tid >> 4) + 16 * i;
-        bnadd_coef(a, m, m < a.M, esb[i], etb[i], egt[i]);
-      }
+      for (int i = 0; i < ROWS_PT; i++) { esb[i] = bna_s[i]; etb[i] = bna_t[i]; egt[i] = bna_g[i]; }
     }
     if constexpr (SWB_) {
 #pragma unroll
@@ -518,10 +526,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         } else {
           for (int e = 0; e < 8; e++) b[e] = (e < nvalid) ? to_f<T>(((const T*)a.braw)[o + e]) : 0.f;
         }
-        const float sb = esb[i], tb = etb[i], g = egt[i];
+        const SwishCoef sc_ = swish_coef(esb[i], etb[i], egt[i]);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const float dv = val[e] * swish_grad_((sb * b[e] + tb) * g);
+          float xh_, d_;
+          swish_bwd_(sc_, b[e], xh_, d_);
+          const float dv = val[e] * d_;
           val[e] = dv;
           if (e < nvalid && rvalid) {   // sums of the fp32 values: equal to the sums of the stored (rounded) ones to ~2^-9/sqrt(count)
             st1[i] += dv;

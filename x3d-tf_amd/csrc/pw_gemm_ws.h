@@ -263,9 +263,12 @@ __global__ __launch_bounds__(256, WS_OCC) void pw_gemm_ws_kernel(const PwGemmArg
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
             float b[8];
             VecIO<T, 8>::load((const T*)a.braw + o, b);
+            const SwishCoef sc_ = swish_coef(sb, tb, gt);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-              const float dv = val[e] * swish_grad_((sb * b[e] + tb) * gt);
+              float xh_, d_;
+              swish_bwd_(sc_, b[e], xh_, d_);
+              const float dv = val[e] * d_;
               val[e] = dv;
               st1[i] += dv;
               st2[i] += dv * b[e];

@@ -194,6 +194,29 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
   const int row = lane >> 1, c0 = 16 * (lane & 1);
 
+  // EPI_BNADD: this lane's output rows and their coefficients are the same for every tile -- loaded once (inside the tile
+  // loop the loads sit behind the staging prefetches and their wait is a vmcnt(0): a full memory latency per tile)
+  float bna_s[BNA_ ? RB : 1], bna_t[BNA_ ? RB : 1], bna_g[BNA_ ? RB : 1];
+  if constexpr (BNA_) {
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+      const int m = (mib + wid + NW * j) * 32 + row;
+      bnadd_coef(a, m, wid < NW && m < a.M, bna_s[j], bna_t[j], bna_g[j]);
+      if (!a.add) bna_g[j] = 0.f;
+    }
+  }
+
+  float swb_s[EPI == X3D_EPI_SWISH_BWD ? RB : 1], swb_t[EPI == X3D_EPI_SWISH_BWD ? RB : 1];   // BN_b scale / shift of this lane's rows
+  if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+      const int m = (mib + wid + NW * j) * 32 + row;
+      const bool okm = wid < NW && m < a.M;
+      swb_s[j] = okm ? a.b_ss[m * 2] : 0.f;
+      swb_t[j] = okm ? a.b_ss[m * 2 + 1] : 0.f;
+    }
+  }
+
   int n_prev = tile_begin / tiles_per_n;
   fill_coef(n_prev);
   issue_loads(tile_begin, xr0, yr0);
@@ -212,7 +235,19 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
     }
     n_prev = n;
 
-    // ---- epilogue operands of this tile, in flight during the MFMAs
+    // ---- epilogue operands of this tile, in flight during the MFMAs.  The SE gate of this tile's sample goes FIRST: loaded
+    // next to its use in the epilogue it was the youngest load in flight, and waiting for it a vmcnt(0) -- every staging
+    // prefetch issued before it had to land too (in-order retirement), once per tile
+    float swg[EPI == X3D_EPI_SWISH_BWD ? RB : 1];
+    if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const int m = (mib + wid + NW * j) * 32 + row;
+        const bool okg = a.egate && wid < NW && m < a.M;
+        const float gl = (a.egate ? a.egate : a.b_ss)[okg ? (long long)n * a.M + m : 0];   // unconditional, clamped
+        swg[j] = okg ? gl : 1.0f;
+      }
+    }
     hx8 eo[EPI_LOADS ? RB : 1][2];
     f32x16 acc[RB];
     H es[EPI == X3D_EPI_ADD_STRIDED ? RB : 1][2][4];      // strided shortcut gradient: one value per even pixel
@@ -297,14 +332,8 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
       const int m = mi * 32 + row;
       if (m < a.M) {
         float sb = 0.f, tb = 0.f, gt = 1.f;
-        if constexpr (EPI == X3D_EPI_SWISH_BWD) {
-          sb = a.b_ss[m * 2]; tb = a.b_ss[m * 2 + 1];
-          gt = a.egate ? a.egate[(long long)n * a.M + m] : 1.0f;
-        }
-        if constexpr (BNA_) {
-          bnadd_coef(a, m, true, sb, tb, gt);
-          if (!a.add) gt = 0.f;
-        }
+        if constexpr (EPI == X3D_EPI_SWISH_BWD) { sb = swb_s[j]; tb = swb_t[j]; gt = swg[j]; }
+        if constexpr (BNA_) { sb = bna_s[j]; tb = bna_t[j]; gt = bna_g[j]; }
 #pragma unroll
         for (int hv = 0; hv < 2; hv++) {
           const long long p = p0 + c0 + 8 * hv;
@@ -331,10 +360,13 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) val[2 * gq] += (float)es[j][hv][gq];
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
+            const SwishCoef sc_ = swish_coef(sb, tb, gt);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
               const float b = (float)eo[j][hv][e];
-              const float dv = val[e] * swish_grad_((sb * b + tb) * gt);
+              float xh_, d_;
+              swish_bwd_(sc_, b, xh_, d_);
+              const float dv = val[e] * d_;
               val[e] = dv;
               if (!RAG || e < left) {
                 st1[j] += dv;
