@@ -95,7 +95,8 @@ PW_WGRAD = [
 # ---- x3d_pw_bwd (fused dgrad + wgrad): N, Cin, Cout, T, H, W, epilogue ---------------------------------------------------
 PW_BWD = [
     (2, 24, 54, 4, 16, 16, "add"), (2, 48, 108, 2, 28, 28, "add"), (1, 24, 108, 3, 16, 16, "add_strided"),
-    (2, 24, 54, 2, 28, 28, "add_strided"),
+    (2, 24, 54, 2, 28, 28, "add_strided"),     # rows of 28 points: element loads of the shortcut gradient in the epilogue
+    (1, 24, 54, 2, 16, 16, "add_strided"),     # rows of 8k points: 8-byte loads (a separate instantiation)
     (2, 54, 24, 4, 16, 16, "swish_bwd"), (2, 108, 48, 3, 12, 12, "swish_bwd"), (3, 40, 20, 1, 7, 8, "swish_bwd"),
     (1, 96, 32, 2, 10, 12, "swish_bwd"),
     (2, 216, 96, 2, 14, 14, "swish_bwd"),      # stage-4 `c` conv: the weights-stationary fused kernel (pw_bwd_wst.hip)
@@ -109,6 +110,7 @@ PW_BWD = [
 # one or two row tiles): N, Cin, Cout, T, H, W, epilogue, tail (1 = identity shortcut below, 2 = shortcut conv below)
 PW_BWD_TAIL = [
     (2, 24, 54, 4, 16, 16, "add", 1), (2, 24, 54, 2, 28, 28, "add_strided", 1), (2, 24, 54, 4, 16, 16, "add", 2),   # stage 2 (X3D-S / M / L)
+    (1, 24, 54, 2, 16, 16, "add_strided", 1), (1, 24, 54, 2, 16, 16, "add_strided", 2),
     (1, 24, 108, 3, 16, 16, "add_strided", 1), (1, 24, 108, 3, 16, 16, "add_strided", 2),                          # stage 3 block 0
     (2, 48, 54, 2, 28, 28, "add", 1), (2, 48, 54, 2, 28, 28, "add", 2),                                            # two row tiles x two dY tiles
     (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add", 2), (1, 32, 72, 1, 16, 16, "add_strided", 1),  # X3D-XL stage 2
