@@ -112,6 +112,7 @@ PW_BWD_TAIL = [
     (2, 24, 54, 4, 16, 16, "add", 1), (2, 24, 54, 2, 28, 28, "add_strided", 1), (2, 24, 54, 4, 16, 16, "add", 2),   # stage 2 (X3D-S / M / L)
     (1, 24, 54, 2, 16, 16, "add_strided", 1), (1, 24, 54, 2, 16, 16, "add_strided", 2),
     (1, 24, 108, 3, 16, 16, "add_strided", 1), (1, 24, 108, 3, 16, 16, "add_strided", 2),                          # stage 3 block 0
+    (1, 24, 108, 2, 12, 12, "add_strided", 1), (1, 24, 108, 2, 12, 12, "add_strided", 2),                          # ... X3D-L / XL rows (78: element form)
     (2, 48, 54, 2, 28, 28, "add", 1), (2, 48, 54, 2, 28, 28, "add", 2),                                            # two row tiles x two dY tiles
     (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add", 2), (1, 32, 72, 1, 16, 16, "add_strided", 1),  # X3D-XL stage 2
     (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2),                                              # ragged tiles, widths off the grid
