@@ -103,6 +103,7 @@ PW_BWD = [
     (24, 216, 96, 8, 14, 14, "swish_bwd"),     # ... several tiles per persistent workgroup, across sample boundaries
     (3, 200, 90, 1, 10, 12, "swish_bwd"),      # ... widths off the grid, a partial last tile per sample (P = 120)
     (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
+    (2, 96, 216, 2, 14, 14, "add"), (24, 96, 216, 8, 14, 14, "add"), (3, 90, 210, 1, 10, 12, "add"),   # stage-4 `a` conv: pw_bwd_wsta.hip
     (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
 ]
 
@@ -116,6 +117,7 @@ PW_BWD_TAIL = [
     (2, 48, 54, 2, 28, 28, "add", 1), (2, 48, 54, 2, 28, 28, "add", 2),                                            # two row tiles x two dY tiles
     (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add", 2), (1, 32, 72, 1, 16, 16, "add_strided", 1),  # X3D-XL stage 2
     (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2),                                              # ragged tiles, widths off the grid
+    (2, 96, 216, 2, 14, 14, "add", 1), (24, 96, 216, 8, 14, 14, "add", 1), (3, 90, 210, 1, 10, 12, "add", 1),      # stage-4 `a` conv (pw_bwd_wsta.hip)
 ]
 
 # ---- x3d_dw3d_fwd / x3d_dw3d_bwd: N, C, T, H, W, stride --------------------------------------------------------------------

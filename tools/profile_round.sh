@@ -23,4 +23,12 @@ if [ "${2:-}" = "pmc" ]; then
   rm -rf "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
 fi
 rm -rf "$OUT/prof"
+# the other BASELINE configurations: throughput lines, and one rocprofv3 kernel-stats table each for configs 2, 4 and 5
+python3 "$REPO/tools/run_configs.py" > "$OUT/other_configs.jsonl" 2> "$OUT/other_configs.err"
+for c in cfg2 cfg4 cfg5; do
+  rocprofv3 -M --kernel-trace --stats --output-format csv -d "$OUT/prof_$c" -- python3 "$REPO/tools/run_configs.py" --steps 2 $c > "$OUT/prof_$c.json" 2> "$OUT/prof_$c.err"
+  find "$OUT/prof_$c" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$c.csv" \;
+  rm -rf "$OUT/prof_$c"
+done
+python3 "$REPO/tools/bench_layers_infer.py" XL 30 16 312 fp16 > "$OUT/per_launch_layers_XL_infer.txt" 2>&1
 ls -la "$OUT"

@@ -49,16 +49,26 @@ def infer_rate(variant, videos, views, crops, t, s, dtype, steps=5):
     return dict(variant=variant, mode="inference", dtype=str(dtype), videos=videos, views=views * crops, clip=f"{t}x{s}x{s}",
                 clips_per_s=steps * n / el, videos_per_s=steps * videos / el, ms_per_batch=1e3 * el / steps, ok=ok, mem_GB=mem)
 
+CONFIGS = {   # name: (function, arguments)
+    "cfg2": (train_rate, ("S", 32, 13, 160, torch.float32)),            # BASELINE config 2
+    "cfg4": (train_rate, ("L", 16, 16, 312, torch.bfloat16)),           # config 4 (yaml batch 16)
+    "xl_train": (train_rate, ("XL", 8, 16, 312, torch.bfloat16)),
+    "cfg5": (infer_rate, ("XL", 2, 10, 3, 16, 312, torch.float16)),     # config 5: 30 views / video, fp16 (Keras mixed_float16)
+    "cfg5_bf16": (infer_rate, ("XL", 2, 10, 3, 16, 312, torch.bfloat16)),
+    "m_fp16": (train_rate, ("M", 64, 16, 224, torch.float16)),          # the headline workload in fp16 with loss scaling
+    "cfg1": (infer_rate, ("XS", 8, 10, 1, 4, 160, torch.float32)),      # config 1 on the GPU
+    "s_bf16": (train_rate, ("S", 64, 13, 160, torch.bfloat16)),         # config 2's model in 16-bit storage: 13 frames -> ragged rows (P % 8 != 0)
+    "xs_bf16": (train_rate, ("XS", 64, 4, 160, torch.bfloat16)),
+}
+
 if __name__ == "__main__":
-    res = []
-    res.append(train_rate("S", 32, 13, 160, torch.float32))          # config 2
-    res.append(train_rate("L", 16, 16, 312, torch.bfloat16))         # config 4 (yaml batch 16)
-    res.append(train_rate("XL", 8, 16, 312, torch.bfloat16))
-    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.float16))   # config 5: 30 views / video, fp16 (Keras mixed_float16)
-    res.append(infer_rate("XL", 2, 10, 3, 16, 312, torch.bfloat16))  #   the same in bf16
-    res.append(train_rate("M", 64, 16, 224, torch.float16))          # the headline workload in fp16 with loss scaling
-    res.append(infer_rate("XS", 8, 10, 1, 4, 160, torch.float32))    # config 1 on the GPU
-    res.append(train_rate("S", 64, 13, 160, torch.bfloat16))         # config 2's model in 16-bit storage: 13 frames -> ragged rows (P % 8 != 0)
-    res.append(train_rate("XS", 64, 4, 160, torch.bfloat16))
-    for r in res:
-        print(json.dumps(r))
+    # python tools/run_configs.py [--steps K] [name ...]      (no names: all of them)
+    argv = sys.argv[1:]
+    steps = 5
+    if argv[:1] == ["--steps"]:
+        steps, argv = int(argv[1]), argv[2:]
+    for name in (argv or list(CONFIGS)):
+        fn, args = CONFIGS[name]
+        r = fn(*args, steps=steps)
+        r["name"] = name
+        print(json.dumps(r), flush=True)

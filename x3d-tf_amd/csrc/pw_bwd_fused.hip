@@ -605,10 +605,13 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
 // the weights-stationary fused backward of the stage-4 `c` conv (pw_bwd_wst.hip)
 bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b);
 int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st);
+// ... and of the stage-4 `a` conv (pw_bwd_wsta.hip)
+bool pw_bwd_wsta_applies(const x3d_pw_bwd_args* b);
+int pw_bwd_wsta(const x3d_pw_bwd_args* b, hipStream_t st);
 
 // eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
 static bool fb_supported(const x3d_pw_bwd_args* b) {
-  if (pw_bwd_wst_applies(b)) return true;
+  if (pw_bwd_wst_applies(b) || pw_bwd_wsta_applies(b)) return true;
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw) return false;
   int MT = 0, KT = 0;
   if (!fb_shape(b->Cin, b->Cout, &MT, &KT)) return false;
@@ -641,6 +644,7 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   X3D_REQUIRE(fb_supported(b), "pw_bwd: shape / alignment / epilogue not covered by the fused kernel "
                                "(x3d_pw_bwd_supported() == 0): use x3d_pw_dgrad + x3d_pw_wgrad");
   if (pw_bwd_wst_applies(b)) return pw_bwd_wst(b, (hipStream_t)stream);
+  if (pw_bwd_wsta_applies(b)) return pw_bwd_wsta(b, (hipStream_t)stream);
   if (b->epi == X3D_EPI_SWISH_BWD)
     X3D_REQUIRE(b->braw && b->b_scale_shift && b->nc_sums, "pw_bwd: SWISH_BWD needs braw/b_scale_shift/nc_sums");
   else
