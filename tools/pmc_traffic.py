@@ -14,7 +14,7 @@ import re
 import sys
 
 
-_DW = re.compile(r"_Z\d+(dw3d_\w+?_kernel)I(DF16b|DF16_|f)((?:L[ib]\d+E)+)E")
+_DW = re.compile(r"_Z\d+(dw3d_\w+?_kernel)I(DF16b|DF16_|f)((?:L[ib]n?\d+E)+)E")
 _TYPES = {"DF16b": "bf16", "DF16_": "f16", "f": "float"}
 
 
@@ -24,7 +24,7 @@ def canonical(name):
     m = _DW.match(name)
     if not m:
         return name
-    args = re.findall(r"L[ib](\d+)E", m.group(3))
+    args = [x.replace("n", "-") for x in re.findall(r"L[ib](n?\d+)E", m.group(3))]   # (Lin8E = -8)
     return "%s<%s, %s>" % (m.group(1), _TYPES[m.group(2)], ", ".join(args))
 
 
