@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 120
+#define X3D_ABI_VERSION 121
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -162,12 +162,20 @@ typedef struct {
   int in_act;
   int N, Cin, Cout, T, H, W, stride, dtype;
   const void* w_panel;         /* optional (bf16 path): forward panel from x3d_pw_pack_weights, else NULL */
+  /* folded residual tail (training; NULL: off).  x is then the raw `c` output of the block BELOW and the conv input is that
+   * block's output, built on load and stored for its other readers -- the work of a separate x3d_tail_fwd pass:
+   *   v = relu(s*x + t + (in_add_scale_shift ? s_r*in_add + t_r : in_add)) ;  in_store = v
+   * (s, t) = in_scale_shift, in_act = X3D_ACT_RELU, no in_gate; 16-bit storage, stride 1: x3d_pw_fwd_tail_supported(). */
+  const void* in_add;               /* [N][Cin][P]: raw shortcut-conv output of the block below, or its input (identity) */
+  const float* in_add_scale_shift;  /* [Cin][2] (bn_r of the block below) or NULL */
+  void* in_store;                   /* [N][Cin][P] the block's output y */
   const float* out_scale_shift;     /* [Cout][2] or NULL (training form: raw store + stats) */
   const void* out_add;              /* [N][Cout][T][Ho][Wo] or NULL */
   const float* out_add_scale_shift; /* [Cout][2] applied to out_add, or NULL */
   int out_act;                      /* X3D_ACT_NONE / X3D_ACT_RELU */
 } x3d_pw_fwd_args;
 int x3d_pw_fwd(const x3d_pw_fwd_args* a, void* stream);
+int x3d_pw_fwd_tail_supported(const x3d_pw_fwd_args* a);   /* 1: the in_add / in_store form covers this call */
 
 /* data gradient: dYraw = A*g + B*yraw + C on load (coef [Cout][4]; NULL coef: dYraw = g),
  * dx = W^T dYraw with one of the X3D_EPI_* epilogues. All tensors at the conv's OUTPUT points. */

@@ -42,6 +42,14 @@ PW_FWD = [
     # group would start before the row (before the tensor for its first row) -- these take the next smaller group
     (1, 96, 192, 8, 7, 7, 2, None), (2, 96, 192, 8, 3, 3, 2, None),
 ]
+# ... with the residual tail of the block below folded into the prologue (16-bit storage; prologue "tail": identity shortcut,
+# "tail_conv": shortcut conv with its own BN): x = raw c output, in_add = shortcut, in_store = the block output y
+PW_FWD_TAIL = [
+    (2, 24, 54, 4, 12, 12, 1, "tail"), (1, 48, 108, 2, 16, 16, 1, "tail_conv"), (1, 24, 108, 1, 16, 16, 1, "tail"),   # stages 2 / 3
+    (1, 48, 216, 1, 16, 16, 1, "tail"), (1, 32, 72, 1, 16, 16, 1, "tail"), (1, 72, 162, 1, 8, 8, 1, "tail_conv"),     # stage-4 block 0; X3D-XL
+    (1, 48, 108, 13, 5, 5, 1, "tail"), (2, 96, 216, 13, 10, 10, 1, "tail_conv"), (1, 24, 54, 1, 3, 4, 1, "tail"),     # odd / ragged point counts
+    (3, 40, 72, 2, 7, 8, 1, "tail_conv"),
+]
 # X3D-XL widths (configs/kinetics/X3D_XL.yaml: width factor 2.9, bottleneck 2.25): 32/72, 72/162, 136/306, 280/630, conv5 630
 PW_FWD_XL = [
     (1, 32, 72, 1, 16, 16, 1, None), (1, 72, 32, 1, 16, 16, 1, "swish"), (1, 32, 32, 1, 16, 16, 2, None),
@@ -184,6 +192,9 @@ def pw_fwd_struct(shape, dtype, panel):
     from x3d_tf_amd import hip
     n, cin, cout, t, h, w, stride, pro = shape
     A = _Addr.new
+    if pro in ("tail", "tail_conv"):
+        return hip.PwFwdArgs(A(), A(), A(), A(), A(), None, 1, n, cin, cout, t, h, w, stride, _code(dtype), A() if panel else None,
+                             in_add=A(), in_add_scale_shift=A() if pro == "tail_conv" else None, in_store=A())
     return hip.PwFwdArgs(A(), A(), A(), A(), A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, stride, _code(dtype),
                          A() if panel else None)
@@ -195,8 +206,8 @@ def pw_fwd_infer_struct(shape, dtype, panel):
     A = _Addr.new
     return hip.PwFwdArgs(A(), A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, 1, _code(dtype),
-                         A() if panel else None, A(), A() if res else None, A() if res == "conv" else None,
-                         1 if oact == "relu" else 0)
+                         A() if panel else None, out_scale_shift=A(), out_add=A() if res else None,
+                         out_add_scale_shift=A() if res == "conv" else None, out_act=1 if oact == "relu" else 0)
 
 
 def pw_dgrad_struct(shape, epi, dtype, panel):

@@ -100,6 +100,49 @@ def test_pw_fwd(gpu, dtype, shape, panel):
 
 
 @pytest.mark.parametrize("panel", [False, True])
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", S.PW_FWD_TAIL)
+def test_pw_fwd_tail(gpu, dtype, shape, panel):
+    """x3d_pw_fwd with the residual tail of the block below folded into its prologue (in_add / in_store): x is that block's
+    raw `c` output, the conv input y = relu(bn_c(x) + shortcut) (reference model.py:381-392) is built on load, STORED (it is
+    the block's output: the shortcut conv, the next tail and the backward pass read it) and multiplied.  y against the fp64
+    formula at the storage tolerance, bit-identical to what x3d_tail_fwd stores up to one rounding of the fused affine; the
+    conv against the oracle on the stored y."""
+    ops, O = _ops(), _oracle()
+    n, cin, cout, t, h, w, stride, pro = shape
+    g = _gen(19)
+    c, cd = rnd((n, cin, t, h, w), dtype, g)
+    sc_, scd = rnd((n, cin, t, h, w), dtype, g)
+    wt = torch.randn((cout, cin), generator=g) * 0.2
+    ss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)], 1)
+    ssr = None
+    short = scd
+    if pro == "tail_conv":
+        ssr = torch.stack([1 + 0.3 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)], 1)
+        short = _affine(scd, ssr.double())
+    y_ref = F.relu(_affine(cd, ss.double()) + short)
+    dev = lambda v: None if v is None else v.to(gpu)
+    ystore = torch.full((n, cin, t, h, w), 7.0, dtype=dtype, device=gpu)
+    stats = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+    fp = _panels(ops, wt, dtype, gpu)[0] if panel else None
+    out = ops.pw_fwd(dev(c), dev(wt), stats=stats, in_ss=dev(ss), in_act=1, w_panel=fp, in_add=dev(sc_), in_add_ss=dev(ssr),
+                     in_store=ystore)
+    torch.cuda.synchronize()
+    rs, as_ = tol_store(dtype)
+    report("y (stored conv input)", ystore, y_ref, rs, as_ * y_ref.abs().max().item())
+    # the separate pass stores the same tensor (the two evaluate the affine sum in a different association: one ulp at most)
+    y2 = torch.empty_like(ystore)
+    ops.tail_fwd(dev(c), dev(ss), dev(sc_), dev(ssr), y2)
+    torch.cuda.synchronize()
+    report("y vs x3d_tail_fwd", ystore, y2.float().cpu(), 2 * rs, as_ * y_ref.abs().max().item())
+    ref = O.pointwise(ystore.float().cpu().double(), round_to(wt, dtype), 1)      # the GEMM operand is the stored y
+    rt, at = tol_gemm(dtype)
+    report("conv", out, ref, rt, at * ref.abs().max().item())
+    sref = _stats_ref(out.float().cpu(), dtype)
+    report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
+
+
+@pytest.mark.parametrize("panel", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", S.PW_FWD_INFER)
 def test_pw_fwd_infer(gpu, dtype, shape, panel):

@@ -243,8 +243,16 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
             dx_ref = dx_ref * (B.x.float().cpu() > 0)
             folded += 1
         _scaled(pre + "/dx", dx_dev, dx_ref, atol_)       # every block: identity shortcuts add dy, conv shortcuts their dgrad
+        # relative L2 per tensor, the denominator floored at 5 % of the block's typical gradient magnitude (rms over its
+        # tensors): the SE bias / kernel gradients of some blocks are sums that cancel to ~1e-3 of that -- any two correct
+        # 16-bit evaluations differ by more than such a remainder (measured: se_fc1/bias of stage 0 block 0 between 1e-2 and
+        # 0.8 of ITSELF from run to run of the same code, depending on where the 16-bit roundings of dy fall)
+        rms = [g_ref.double().norm().item() / max(g_ref.numel(), 1) ** 0.5 for g_ref in grads[1:]]
+        floor_rms = 0.05 * sorted(rms)[len(rms) // 2]
         for k, g_ref in zip(names, grads[1:]):
-            e = rel_l2(m.grads[k], g_ref)
+            num = (m.grads[k].detach().double().cpu() - g_ref.double()).norm().item()
+            den = max(g_ref.double().norm().item(), floor_rms * g_ref.numel() ** 0.5)
+            e = num / (den + 1e-30)
             worst["dw"] = max(worst["dw"], e)
             errs[k] = e
     print("bf16 teacher-forced worst:", worst, sorted(errs.items(), key=lambda kv: -kv[1])[:4], "tail folded in", folded, "blocks")

@@ -51,9 +51,9 @@ def main():
         fl = 2.0 * n * t * h * w * cin * cout
         st = hip.PwFwdArgs(x.data_ptr(), wt.data_ptr(), y.data_ptr(), None, kw["in_ss"].data_ptr() if pro == "s" else None,
                            kw["in_gate"].data_ptr() if pro == "s" else None, 2 if pro == "s" else 0, n, cin, cout, t, h, w, 1,
-                           hip.dtype_code(dtype), fp.data_ptr(), kw["out_ss"].data_ptr() if res != "n" else None,
-                           kw["out_add"].data_ptr() if res != "n" else None, kw["out_add_ss"].data_ptr() if res == "c" else None,
-                           1 if res != "n" else 0)
+                           hip.dtype_code(dtype), fp.data_ptr(), out_scale_shift=kw["out_ss"].data_ptr() if res != "n" else None,
+                           out_add=kw["out_add"].data_ptr() if res != "n" else None,
+                           out_add_scale_shift=kw["out_add_ss"].data_ptr() if res == "c" else None, out_act=1 if res != "n" else 0)
         print(f"{spec:34s} {us:8.1f} us  {by / us / 1e6:6.2f} TB/s  {fl / us / 1e6:7.1f} TFLOP/s  {hip.pw_kernel_name(st)}", flush=True)
 
 

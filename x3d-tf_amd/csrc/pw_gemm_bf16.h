@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   }
 
   // AFFINE rows are 2 floats (table always in LDS), BNBWD rows 4 floats (in LDS unless it costs a resident workgroup: K >= 320)
-  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
+  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;   // (BNBWD, TAIL: three coefficients per row)
   const bool use_cs = (PRO == PRO_AFFINE) || a.K < 320;
   auto fill_coef = [&](int n) {
     if (!use_cs) return;
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
             const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
             c[0] = a.coef[k * 2] * g;       // (s*x + t) * g
             c[1] = a.coef[k * 2 + 1] * g;
+          } else if constexpr (PRO == PRO_TAIL) {   // s_c*x + (s_r|1)*x2 + (t_c + t_r|0)
+            c[0] = a.coef[k * 2]; c[1] = a.coef2 ? a.coef2[k * 2] : 1.0f;
+            c[2] = a.coef[k * 2 + 1] + (a.coef2 ? a.coef2[k * 2 + 1] : 0.f);
           } else {
             c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2];
           }
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   if (tile_begin < tile_end) fill_coef(tile_begin / tiles_per_n);
 
   // ---- register-staged prefetch of one [kc][BN] chunk
-  hx8 xr[NSV], yr[(PRO == PRO_BNBWD || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
-  float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && PRO == PRO_BNBWD) ? NSV : 1];
+  constexpr bool TWO = (PRO == PRO_BNBWD) || (PRO == PRO_TAIL);   // a second streamed tensor (a.x2)
+  hx8 xr[NSV], yr[(TWO || STRIDED) ? NSV : 1];   // raw loads (VEC == 8); scalar path uses xs1[]
+  float xs1[(VEC == 1) ? NSV : 1], ys1[(VEC == 1 && TWO) ? NSV : 1];
   auto issue_loads = [&](int tile, int kc_idx) {
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) z[e] = (H)0.f;
         xr[i] = z;
-        if constexpr (PRO == PRO_BNBWD) yr[i] = z;
+        if constexpr (TWO) yr[i] = z;
         if constexpr (STRIDED) yr[i] = z;
         if (ok) {
           if constexpr (STRIDED) {
@@ -173,16 +177,16 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
             const long long left = RAG ? a.P - p : 8;          // RAG: the row may end inside its last vector
             if (left >= 8) {
               xr[i] = *(const hx8*)((const T*)a.x + o);
-              if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
+              if constexpr (TWO) yr[i] = *(const hx8*)((const T*)a.x2 + o);
             } else {
               xr[i] = load8_ragged<T, hx8>((const T*)a.x + o, (int)left);
-              if constexpr (PRO == PRO_BNBWD) yr[i] = load8_ragged<T, hx8>((const T*)a.x2 + o, (int)left);
+              if constexpr (TWO) yr[i] = load8_ragged<T, hx8>((const T*)a.x2 + o, (int)left);
             }
           }
         }
       } else {
         xs1[i] = 0.f;
-        if constexpr (PRO == PRO_BNBWD) ys1[i] = 0.f;
+        if constexpr (TWO) ys1[i] = 0.f;
         if (ok) {
           long long src = p;
           if constexpr (STRIDED) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           }
           const long long o = ((long long)n * a.K + gk) * a.Pin + src;
           xs1[i] = to_f<T>(((const T*)a.x)[o]);
-          if constexpr (PRO == PRO_BNBWD) ys1[i] = to_f<T>(((const T*)a.x2)[o]);
+          if constexpr (TWO) ys1[i] = to_f<T>(((const T*)a.x2)[o]);
         }
       }
     }
@@ -237,6 +241,9 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           if constexpr (PRO == PRO_AFFINE) {
             const float g = (inb && a.gate) ? a.gate[(long long)n * a.K + gk] : 1.0f;
             cf[0] = inb ? a.coef[gk * 2] * g : 0.f; cf[1] = inb ? a.coef[gk * 2 + 1] * g : 0.f; cf[2] = 0.f;
+          } else if constexpr (PRO == PRO_TAIL) {
+            cf[0] = inb ? a.coef[gk * 2] : 0.f; cf[1] = (inb && a.coef2) ? a.coef2[gk * 2] : (inb ? 1.0f : 0.f);
+            cf[2] = inb ? a.coef[gk * 2 + 1] + (a.coef2 ? a.coef2[gk * 2 + 1] : 0.f) : 0.f;
           } else {
             cf[0] = inb ? a.coef[gk * 4] : 0.f; cf[1] = inb ? a.coef[gk * 4 + 1] : 0.f; cf[2] = inb ? a.coef[gk * 4 + 2] : 0.f;
           }
@@ -245,14 +252,28 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) val[e] = cf[0] * val[e] + cf[1];
           act_vec<VEC>(val, a.act);
-        } else {  // PRO_BNBWD
+        } else {  // PRO_BNBWD, PRO_TAIL
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
             const float y2 = (VEC == 8) ? (float)yr[i][e] : ys1[i];
             val[e] = cf[0] * val[e] + cf[1] * y2 + cf[2];
+            if constexpr (PRO == PRO_TAIL) val[e] = fmaxf(val[e], 0.f);
           }
         }
         VecIO<H, VEC>::store(dst, val);
+        if constexpr (PRO == PRO_TAIL) {   // the activated input IS the output y of the block below: kept for its other readers
+          const int n_ = tile / tiles_per_n;
+          const long long p_ = (long long)(tile - n_ * tiles_per_n) * BN + (long long)pv * VEC;
+          if (blockIdx.y == 0 && gk < a.K && p_ < a.P) {
+            T* yd = (T*)a.ystore + ((long long)n_ * a.K + gk) * a.Pin + p_;
+            if constexpr (VEC == 8) {
+              if (!RAG || a.P - p_ >= 8) VecIO<T, 8>::store(yd, val);
+              else for (int e = 0; e < (int)(a.P - p_); e++) yd[e] = from_f<T>(val[e]);
+            } else {
+              yd[0] = from_f<T>(val[0]);
+            }
+          }
+        }
       }
     }
   };

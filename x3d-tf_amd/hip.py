@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx3d_hip.so")
 
-ABI_VERSION = 120   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 121   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -27,6 +27,7 @@ class PwFwdArgs(C.Structure):
     _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("stats", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i),
                 ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("w_panel", _vp),
+                ("in_add", _vp), ("in_add_scale_shift", _vp), ("in_store", _vp),
                 ("out_scale_shift", _vp), ("out_add", _vp), ("out_add_scale_shift", _vp), ("out_act", _i)]
 
 
@@ -110,6 +111,7 @@ _SIGS = {
     "x3d_bn_eval_coef_batched": ([_vp, _i, _f, _vp], _i),
     "x3d_bn_bwd_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
+    "x3d_pw_fwd_tail_supported": ([C.POINTER(PwFwdArgs)], _i),
     "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),

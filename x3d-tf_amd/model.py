@@ -624,7 +624,7 @@ class X3D:
             # c: BN_b * gate -> swish on load; relu(bn_c(acc) + shortcut) on the accumulators
             sc = hip.PwFwdArgs(_p(B.b_raw), _p(p[f"{q}/c/kernel"]), _p(B.y), None, _p(B.bn_b.ss), _p(B.gate),
                                ACT_SWISH, n, b.inner, b.cout, t, ho, wo, 1, dt, self._wp(f"{q}/c/kernel"),
-                               _p(B.bn_c.ss), _p(add), _p(add_ss), ACT_RELU)
+                               out_scale_shift=_p(B.bn_c.ss), out_add=_p(add), out_add_scale_shift=_p(add_ss), out_act=ACT_RELU)
             B.sc = sc
             pl.rec(F, "x3d_pw_fwd", sc)
             pl.blocks.append(B)
@@ -732,6 +732,27 @@ class X3D:
             pl.rec(F, "x3d_tail_fwd", pl.t_raw, pl.bn1.ss, None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
 
         # ---- residual stages -------------------------------------------------------------------
+        # The residual tail of a block (y = relu(bn_c(c) + shortcut), reference model.py:381-392) is DEFERRED to the first
+        # reader of y: the next block's `a` conv (or conv5) builds y on load and stores it (x3d_pw_fwd in_add / in_store) where
+        # that form exists and does not cost the layer its weights-stationary kernel; otherwise x3d_tail_fwd runs first.
+        pending = {"tail": None}
+        fold_fwd = training and not fold_on and os.environ.get("X3D_NO_TAIL_FWD_FOLD") != "1"
+
+        def fold_pending_tail(st):
+            """st: the x3d_pw_fwd arguments of the conv that reads the pending block output first."""
+            tl, pending["tail"] = pending["tail"], None
+            if tl is None:
+                return st
+            c_raw, c_ss, shortcut, r_ss, y, cout_, p_out_ = tl
+            ft = hip.PwFwdArgs(_p(c_raw), st.w, st.y, None, _p(c_ss), None, ACT_RELU, st.N, st.Cin, st.Cout, st.T, st.H, st.W,
+                               1, st.dtype, st.w_panel, in_add=_p(shortcut), in_add_scale_shift=_p(r_ss), in_store=_p(y))
+            if (fold_fwd and st.stride == 1 and pl.lib.x3d_pw_fwd_tail_supported(C.byref(ft))
+                    and not hip.pw_kernel_name(st).startswith("pw_gemm_wst")):
+                pl.blocks[-1].tail_fwd_folded = True
+                return ft
+            pl.rec(F, "x3d_tail_fwd", c_raw, c_ss, shortcut, r_ss, y, n, cout_, p_out_, dt)
+            return st
+
         x_cur, hh, ww = pl.y0, h1, w1
         pl.blocks = []
         for b in a.blocks:
@@ -752,10 +773,12 @@ class X3D:
             B.pool = pl.acc64(n, b.inner) if b.has_se else None
             B.gate = pl.f32(n, b.inner) if b.has_se else None
             B.hidden = pl.f32(n, b.se_width) if b.has_se else None
-            # a: 1x1x1 on the (materialised, already activated) block input
+            # a: 1x1x1 on the block input -- materialised and already activated, or (16-bit storage, resident-panel kernel) built
+            # on load from the raw `c` output + shortcut of the block below, whose residual tail is then not a pass of its own
             sa = hip.PwFwdArgs(_p(x_cur), _p(p[f"{q}/a/kernel"]), _p(B.a_raw), None, None, None, ACT_NONE, n, b.cin,
                                b.inner, t, hh, ww, 1, dt)
             sa.w_panel = self._wp(f"{q}/a/kernel")
+            sa = fold_pending_tail(sa)
             B.sa = sa
             pl.rec(F, "x3d_pw_fwd", ("stats", sa, B.bn_a.stats))
             # b: channelwise 3x3x3, BN_a (+ its finalize when folded) + ReLU folded into the load, BN_b statistics + SE
@@ -795,13 +818,14 @@ class X3D:
                            B.y, n, b.cout, P_out, dt)
                 else:
                     bn_finish(B.bn_r, n * P_out)
-                    pl.rec(F, "x3d_tail_fwd", B.c_raw, B.bn_c.ss, B.r_raw, B.bn_r.ss, B.y, n, b.cout, P_out, dt)
+                    pending["tail"] = (B.c_raw, B.bn_c.ss, B.r_raw, B.bn_r.ss, B.y, b.cout, P_out)
             else:
                 B.r_raw, B.bn_r = None, None
                 if fold_on:
                     pl.rec(F, "x3d_tail_fwd_bn", B.c_raw, bn_fold(B.bn_c, n * P_out), x_cur, None, B.y, n, b.cout, P_out, dt)
                 else:
-                    pl.rec(F, "x3d_tail_fwd", B.c_raw, B.bn_c.ss, x_cur, None, B.y, n, b.cout, P_out, dt)
+                    pending["tail"] = (B.c_raw, B.bn_c.ss, x_cur, None, B.y, b.cout, P_out)
+            B.tail_fwd_folded = None          # set by the consumer that takes the tail
             pl.blocks.append(B)
             x_cur, hh, ww = B.y, ho, wo
 
@@ -815,6 +839,7 @@ class X3D:
         s5 = hip.PwFwdArgs(_p(x_cur), _p(p["conv5/layer_with_weights-0/kernel"]), _p(pl.c5_raw), None, None, None,
                            ACT_NONE, n, c_last, c5, t, hh, ww, 1, dt)
         s5.w_panel = self._wp("conv5/layer_with_weights-0/kernel")
+        s5 = fold_pending_tail(s5)
         pl.s5 = s5
         pl.rec(F, "x3d_pw_fwd", ("stats", s5, pl.bn5.stats))
         bn_finish(pl.bn5, n * P5)

@@ -159,9 +159,10 @@ def pw_pack_weights(weights, dgrad=True, dtype=torch.bfloat16):
 
 
 def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, w_panel=None,
-           out_ss=None, out_add=None, out_add_ss=None, out_act=ACT_NONE):
-    """out_ss [Cout][2]: the inference epilogue y = out_act(s_o*acc + t_o [+ s_r*out_add + t_r]) (no statistics)."""
-    _chk(x, w, y, stats, in_ss, in_gate, w_panel, out_ss, out_add, out_add_ss)
+           out_ss=None, out_add=None, out_add_ss=None, out_act=ACT_NONE, in_add=None, in_add_ss=None, in_store=None):
+    """out_ss [Cout][2]: the inference epilogue y = out_act(s_o*acc + t_o [+ s_r*out_add + t_r]) (no statistics).
+    in_add / in_add_ss / in_store: the residual tail of the block below folded into the prologue (x = its raw c output)."""
+    _chk(x, w, y, stats, in_ss, in_gate, w_panel, out_ss, out_add, out_add_ss, in_add, in_add_ss, in_store)
     n, cin, t, h, ww = x.shape
     cout = w.shape[0]
     ho, wo = _out_hw(h, ww, stride)
@@ -169,8 +170,9 @@ def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, 
         y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
     st = _Stats(stats, cout)
     a = hip.PwFwdArgs(ptr(x), ptr(w), ptr(y), ptr(st.arg()), ptr(in_ss), ptr(in_gate), in_act, n, cin,
-                      cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel), ptr(out_ss), ptr(out_add),
-                      ptr(out_add_ss), out_act)
+                      cout, t, h, ww, stride, hip.dtype_code(x.dtype), ptr(w_panel), in_add=ptr(in_add),
+                      in_add_scale_shift=ptr(in_add_ss), in_store=ptr(in_store), out_scale_shift=ptr(out_ss),
+                      out_add=ptr(out_add), out_add_scale_shift=ptr(out_add_ss), out_act=out_act)
     hip.call_struct("x3d_pw_fwd", a)
     st.done()
     return y
