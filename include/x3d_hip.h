@@ -165,8 +165,10 @@ typedef struct {
   /* folded residual tail (training; NULL: off).  x is then the raw `c` output of the block BELOW and the conv input is that
    * block's output, built on load and stored for its other readers -- the work of a separate x3d_tail_fwd pass:
    *   v = relu(s*x + t + (in_add_scale_shift ? s_r*in_add + t_r : in_add)) ;  in_store = v
-   * (s, t) = in_scale_shift, in_act = X3D_ACT_RELU, no in_gate; 16-bit storage, stride 1: x3d_pw_fwd_tail_supported(). */
-  const void* in_add;               /* [N][Cin][P]: raw shortcut-conv output of the block below, or its input (identity) */
+   * (s, t) = in_scale_shift, in_act = X3D_ACT_RELU, no in_gate; 16-bit storage, stride 1: x3d_pw_fwd_tail_supported().
+   * in_store without in_add: v = relu(s*x + t) -- the stem's BatchNorm + ReLU (x = the raw conv_t output, reference
+   * model.py:202-210) folded into the first block's `a` conv. */
+  const void* in_add;               /* [N][Cin][P]: raw shortcut-conv output of the block below, or its input (identity); NULL: no Add */
   const float* in_add_scale_shift;  /* [Cin][2] (bn_r of the block below) or NULL */
   void* in_store;                   /* [N][Cin][P] the block's output y */
   const float* out_scale_shift;     /* [Cout][2] or NULL (training form: raw store + stats) */

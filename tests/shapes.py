@@ -49,6 +49,8 @@ PW_FWD_TAIL = [
     (1, 48, 216, 1, 16, 16, 1, "tail"), (1, 32, 72, 1, 16, 16, 1, "tail"), (1, 72, 162, 1, 8, 8, 1, "tail_conv"),     # stage-4 block 0; X3D-XL
     (1, 48, 108, 13, 5, 5, 1, "tail"), (2, 96, 216, 13, 10, 10, 1, "tail_conv"), (1, 24, 54, 1, 3, 4, 1, "tail"),     # odd / ragged point counts
     (3, 40, 72, 2, 7, 8, 1, "tail_conv"),
+    # "tail1": no Add -- the stem's BatchNorm + ReLU folded into the first block's `a` conv (x = raw conv_t output, in_store = y0)
+    (2, 24, 54, 2, 16, 16, 1, "tail1"), (1, 32, 72, 1, 16, 16, 1, "tail1"), (1, 24, 54, 1, 3, 4, 1, "tail1"), (2, 24, 54, 13, 5, 5, 1, "tail1"),
 ]
 # X3D-XL widths (configs/kinetics/X3D_XL.yaml: width factor 2.9, bottleneck 2.25): 32/72, 72/162, 136/306, 280/630, conv5 630
 PW_FWD_XL = [
@@ -192,9 +194,9 @@ def pw_fwd_struct(shape, dtype, panel):
     from x3d_tf_amd import hip
     n, cin, cout, t, h, w, stride, pro = shape
     A = _Addr.new
-    if pro in ("tail", "tail_conv"):
+    if pro in ("tail", "tail_conv", "tail1"):
         return hip.PwFwdArgs(A(), A(), A(), A(), A(), None, 1, n, cin, cout, t, h, w, stride, _code(dtype), A() if panel else None,
-                             in_add=A(), in_add_scale_shift=A() if pro == "tail_conv" else None, in_store=A())
+                             in_add=None if pro == "tail1" else A(), in_add_scale_shift=A() if pro == "tail_conv" else None, in_store=A())
     return hip.PwFwdArgs(A(), A(), A(), A(), A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, stride, _code(dtype),
                          A() if panel else None)

@@ -120,6 +120,8 @@ def test_pw_fwd_tail(gpu, dtype, shape, panel):
     if pro == "tail_conv":
         ssr = torch.stack([1 + 0.3 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)], 1)
         short = _affine(scd, ssr.double())
+    if pro == "tail1":          # no Add: the stem's BatchNorm + ReLU
+        sc_, short = None, 0.0
     y_ref = F.relu(_affine(cd, ss.double()) + short)
     dev = lambda v: None if v is None else v.to(gpu)
     ystore = torch.full((n, cin, t, h, w), 7.0, dtype=dtype, device=gpu)

@@ -236,10 +236,10 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
         worst["y"] = max(worst["y"], _scaled(pre + "/out", B.y, y_ref, atol_))
         grads = torch.autograd.grad(y_ref, [xin] + [leaf[k] for k in names], grad_outputs=dy)
         dx_ref = grads[0]
-        if bi > 0 and pl.blocks[bi - 1].tail_folded:
+        if (bi > 0 and pl.blocks[bi - 1].tail_folded) or (bi == 0 and getattr(pl, "stem_bwd_folded", False)):
             # this block's `a` backward already applied the Add + ReLU backward of the block below (whose y is B.x): what it
             # stored is the masked gradient.  (dy above is then masked as well: the oracle's ReLU backward re-applies the same
-            # mask, which changes nothing.)
+            # mask, which changes nothing.)  Block 0: the same fold with the stem's ReLU (B.x = y0 = relu(bn(t_raw))).
             dx_ref = dx_ref * (B.x.float().cpu() > 0)
             folded += 1
         _scaled(pre + "/dx", dx_dev, dx_ref, atol_)       # every block: identity shortcuts add dy, conv shortcuts their dgrad

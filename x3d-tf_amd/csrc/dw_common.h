@@ -294,6 +294,55 @@ __device__ __forceinline__ void dw_rotate(float (&fin)[SW], v2f (&acc01)[SW], v2
   for (int j = 0; j < (SW + 1) / 2; j++) acc2p[j] = (v2f){0.f, 0.f};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-element dot products for the fused BACKWARD with 16-bit storage: v_dot2c_f32_bf16 / v_dot2c_f32_f16 retire two
+// multiply-adds (16-bit operands, fp32 accumulator) per lane and instruction at the FULL VALU rate on gfx950
+// (tools/micro/dot2_rate.hip: 135-144 lanes per CU and ns against 113 for dependent v_fma_f32; v_cvt_pk_bf16_f32, which
+// forms a pair from two fp32 registers, runs at the v_fma_f32 rate).  The stride-1 fused backward is VALU-issue bound at
+// 54 FMAs + ~30 other instructions per output, so the tap loops pair their products: the operands are
+// rounded to the storage type first (what the matrix-core pointwise kernels do with theirs, and what the reference's
+// mixed-precision policy does with the whole convolution), the sums stay fp32.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Dot2 { static constexpr bool ok = false; };
+template <> struct Dot2<bf16> {
+  static constexpr bool ok = true;
+  static __device__ __forceinline__ uint32_t pk(float lo, float hi) {
+    bf16x2 q; q[0] = (bf16)lo; q[1] = (bf16)hi;
+    return __builtin_bit_cast(uint32_t, q);
+  }
+  static __device__ __forceinline__ float dot(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+  }
+};
+template <> struct Dot2<f16> {
+  static constexpr bool ok = true;
+  static __device__ __forceinline__ uint32_t pk(float lo, float hi) {
+    f16x2 q; q[0] = (f16)lo; q[1] = (f16)hi;
+    return __builtin_bit_cast(uint32_t, q);
+  }
+  static __device__ __forceinline__ float dot(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+  }
+};
+template <> struct Dot2<float> {
+  static constexpr bool ok = false;
+  static __device__ __forceinline__ uint32_t pk(float, float) { return 0u; }
+  static __device__ __forceinline__ float dot(uint32_t, uint32_t, float c) { return c; }
+};
+// X3D_DW_DOT=1 (bf16) / 2 (bf16 and fp16): the dot2 tap loops of dw3d_bwd_pk_kernel (A/B hook, default OFF).  Measured with
+// tools/ab_dot.py (variants alternating inside one process, 216 ch x 64 clips of 16x14x14): scalar FMAs 110.6 us, dW on
+// dot2 120.9, dA on dot2 112.4, both 113.0 on one box; 128.6 / 133.4 / 123.5 / 122.6 on another -- 13 % fewer VALU
+// instructions buy nothing.  tools/micro/vgpr_banks.hip says why the count is the wrong measure on gfx950: a v_fmac_f32 /
+// v_fma_f32 / v_mul / v_add / v_and / v_mov whose operands are all VGPRs (or inline constants) retires in ~3.0-3.4 clocks
+// per wave64 instruction at four waves per SIMD, while the same instruction with an SGPR operand, v_dot2c_f32_bf16,
+// v_pk_fma_f32, v_cvt_pk_bf16_f32, v_max_f32, v_lshlrev_b32 and every DPP form take ~4.9: a dot2 (2 MACs, 4.9 clocks) is no
+// cheaper than two all-VGPR FMAs, and the pair conversions come on top.
+static bool dw_use_dot(int dtype) {
+  const char* e = getenv("X3D_DW_DOT");   // (read per launch: tools/ab_dot.py switches it inside one process)
+  if (!e) return false;
+  return atoi(e) != 0 && dtype != X3D_F32 && (atoi(e) == 2 || dtype == X3D_BF16);
+}
+
 // tile geometry shared by forward and backward
 static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int SW, int elem_bytes,
                    const void* p0, const void* p1, const void* p2, int* block_dim, size_t* lds_floats) {

@@ -45,8 +45,13 @@ struct DwPkArgs {
 // valid element and is then stored as a single element.  The LOAD of a short last strip starts `shift` elements early
 // (columns W-4 .. W-1) so that it never leaves its row: a vector load that straddles the end of the tensor is dropped
 // whole by the bounds check, valid elements included.
-template <typename T, int SW, int PD, int UN, int LPC, int HC, bool ODD>
+// DOT (experiment, X3D_DW_DOT=1; bit 1: dW, bit 2: dA): the tap loops on two-element dot products (dw_common.h, Dot2): dW
+// pairs adjacent outputs of the strip, dA pairs the window rows kh = 0, 1 (weights as packed pairs in SGPRs; the kh = 2 row
+// stays scalar fp32): 216 FMAs -> 126 dot2 / FMA + 23 pair conversions per thread and plane of 4 outputs.  Not faster
+// (dw_common.h, dw_use_dot): off by default.
+template <typename T, int SW, int PD, int UN, int LPC, int HC, bool ODD, int DOT = 0>
 __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const DwPkArgs pa) {
+  static_assert(!(DOT & 3) || (Dot2<T>::ok && SW == 4), "dot2 form: 16-bit storage, strips of 4");
   static_assert(UN % 6 == 0 && UN % PD == 0, "roles have periods 2 (LDS buffers) and 3 (planes); slots period PD");
   static_assert(SW == 2 || SW == 4, "strips of 2 or 4 outputs");
   constexpr int WIN = SW + 2;
@@ -77,6 +82,12 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
   float wgt[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) wgt[k] = a.w[c * 27 + k];
+  uint32_t wgtP[DOT ? 9 : 1];          // DOT: (w[kt][0][kw], w[kt][1][kw]) as a storage-type pair
+  if constexpr ((DOT & 2) != 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++)   // (uniform: kept in SGPRs)
+      wgtP[k] = __builtin_amdgcn_readfirstlane(Dot2<T>::pk(wgt[(k / 3) * 9 + (k % 3)], wgt[(k / 3) * 9 + 3 + (k % 3)]));
+  }
   const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
   float cA = 0.f, cB = 0.f, cC = 0.f;
   if (active) {
@@ -148,10 +159,14 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
 #pragma unroll
   for (int k = 0; k < 27; k++) dW[k] = 0.f;
   float dBs[3][SW];            // own dB strips: dBs[p % 3] = plane p (planes t-1, t, t+1 during iteration t)
+  uint32_t dBp[3][DOT ? 2 : 1]; // DOT: the same strips as pairs (0, 1), (2, 3) of storage-type values
 #pragma unroll
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < 3; k++) {
 #pragma unroll
     for (int i = 0; i < SW; i++) dBs[k][i] = 0.f;
+    dBp[k][0] = 0u;
+    if constexpr (DOT) dBp[k][1] = 0u;
+  }
   float s1 = 0.f, s2 = 0.f;
   Raw own0, own1, own2;         // araw strips: at the top of iteration t of planes t, t-1, t-2 (own0 = the one staged last)
   own0.w[0] = own0.w[1] = own0.w[2] = own0.w[3] = 0u;
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
   }
   __syncthreads();                       // zero fill done
   stage(slot[0], 0, dBs[0], true);
+  if constexpr ((DOT & 1) != 0) { dBp[0][0] = Dot2<T>::pk(dBs[0][0], dBs[0][1]); dBp[0][1] = Dot2<T>::pk(dBs[0][2], dBs[0][3]); }
   own0 = aligned(slot[0].A);
   issue(PD, slot[0]);
   dummy_stores();
@@ -226,31 +242,71 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
       stage(slot[sl], prv, dBs[pp1], t + 1 < g.T);
       own0 = aligned(slot[sl].A);
       issue(t + 1 + PD, slot[sl]);
-      // weight gradient: one window of A[t] against the own strips dB[t+1], dB[t], dB[t-1] (temporal taps 0, 1, 2)
+      if constexpr ((DOT & 1) != 0) {
+        dBp[pp1][0] = Dot2<T>::pk(dBs[pp1][0], dBs[pp1][1]);
+        dBp[pp1][1] = Dot2<T>::pk(dBs[pp1][2], dBs[pp1][3]);
+        // weight gradient: pairs (i, i+1) of the strip against the window pairs (c, c+1), c = i + kw
 #pragma unroll
-      for (int kh = 0; kh < 3; kh++)
+        for (int kh = 0; kh < 3; kh++) {
+          uint32_t Ap[WIN - 1];
 #pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
+          for (int cc = 0; cc < WIN - 1; cc++) Ap[cc] = Dot2<T>::pk(winA[kh][cc], winA[kh][cc + 1]);
 #pragma unroll
-          for (int i = 0; i < SW; i++) {
-            const float av = winA[kh][i + kw];
-            dW[kh * 3 + kw] += dBs[pp1][i] * av;
-            dW[9 + kh * 3 + kw] += dBs[p0][i] * av;
-            dW[18 + kh * 3 + kw] += dBs[pm1][i] * av;
-          }
+          for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              dW[kh * 3 + kw] = Dot2<T>::dot(dBp[pp1][h], Ap[2 * h + kw], dW[kh * 3 + kw]);
+              dW[9 + kh * 3 + kw] = Dot2<T>::dot(dBp[p0][h], Ap[2 * h + kw], dW[9 + kh * 3 + kw]);
+              dW[18 + kh * 3 + kw] = Dot2<T>::dot(dBp[pm1][h], Ap[2 * h + kw], dW[18 + kh * 3 + kw]);
+            }
         }
-      // data gradient: the dB[t] windows scattered into the planes t-1, t, t+1
+      } else {
+        // weight gradient: one window of A[t] against the own strips dB[t+1], dB[t], dB[t-1] (temporal taps 0, 1, 2)
 #pragma unroll
-      for (int kh = 0; kh < 3; kh++)
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+              const float av = winA[kh][i + kw];
+              dW[kh * 3 + kw] += dBs[pp1][i] * av;
+              dW[9 + kh * 3 + kw] += dBs[p0][i] * av;
+              dW[18 + kh * 3 + kw] += dBs[pm1][i] * av;
+            }
+          }
+      }
+      if constexpr ((DOT & 2) != 0) {
+        // data gradient: window rows 2 and 1 (taps kh = 0, 1) as pairs against the weight pairs, row 0 (kh = 2) scalar
+        uint32_t Bp[WIN];
+#pragma unroll
+        for (int cc = 0; cc < WIN; cc++) Bp[cc] = Dot2<T>::pk(winB[2][cc], winB[1][cc]);
 #pragma unroll
         for (int kw = 0; kw < 3; kw++)
 #pragma unroll
           for (int i = 0; i < SW; i++) {
-            const float v = winB[2 - kh][i + 2 - kw];
-            dAr[pm1][i] += wgt[kh * 3 + kw] * v;
-            dAr[p0][i] += wgt[9 + kh * 3 + kw] * v;
-            dAr[pp1][i] += wgt[18 + kh * 3 + kw] * v;
+            const uint32_t bp = Bp[i + 2 - kw];
+            const float v = winB[0][i + 2 - kw];
+            dAr[pm1][i] = Dot2<T>::dot(wgtP[kw], bp, dAr[pm1][i]);
+            dAr[p0][i] = Dot2<T>::dot(wgtP[3 + kw], bp, dAr[p0][i]);
+            dAr[pp1][i] = Dot2<T>::dot(wgtP[6 + kw], bp, dAr[pp1][i]);
+            dAr[pm1][i] += wgt[6 + kw] * v;
+            dAr[p0][i] += wgt[15 + kw] * v;
+            dAr[pp1][i] += wgt[24 + kw] * v;
           }
+      } else {
+        // data gradient: the dB[t] windows scattered into the planes t-1, t, t+1
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int i = 0; i < SW; i++) {
+              const float v = winB[2 - kh][i + 2 - kw];
+              dAr[pm1][i] += wgt[kh * 3 + kw] * v;
+              dAr[p0][i] += wgt[9 + kh * 3 + kw] * v;
+              dAr[pp1][i] += wgt[18 + kh * 3 + kw] * v;
+            }
+      }
       __syncthreads();
     }
   }
@@ -318,9 +374,11 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
   const bool fixed = (SW == 4 && pa.LP == 16 && g.H == 14) || (SW == 2 && pa.LP == 12 && g.H == 10);
   const bool odd7 = SW == 4 && g.W == 7 && g.H == 7 && pa.LP == 12;
   if ((g.W & 1) && !odd7) return false;
+  // two-element dot products (16-bit storage, strips of 4, compile-time geometry)
+  const bool dot = SW == 4 && (fixed || odd7) && dw_use_dot(sizeof(T) == 4 ? X3D_F32 : (TypeName<T>::v[0] == 'b' ? X3D_BF16 : X3D_F16));
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d, %d>", TypeName<T>::v, SW,
-             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7);
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d, %d%s>", TypeName<T>::v, SW,
+             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7, dot ? ", 1" : "");
     return true;
   }
 #ifdef X3D_EXPERIMENTS   // result-changing timing hook: only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)
@@ -331,7 +389,9 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
   auto kern = fixed ? dw3d_bwd_pk_kernel<T, SW, 2, 6, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10), false>
                     : dw3d_bwd_pk_kernel<T, SW, 2, 6, 0, 0, false>;
   if constexpr (SW == 4 && sizeof(T) == 2) {
-    if (odd7) kern = dw3d_bwd_pk_kernel<T, 4, 2, 6, 12, 7, true>;
+    const int mask = pk_env("X3D_DW_DOTMASK", 3);
+    if (odd7) kern = dot ? dw3d_bwd_pk_kernel<T, 4, 2, 6, 12, 7, true, 3> : dw3d_bwd_pk_kernel<T, 4, 2, 6, 12, 7, true>;
+    else if (fixed && dot) kern = mask == 1 ? dw3d_bwd_pk_kernel<T, 4, 2, 6, 16, 14, false, 1> : mask == 2 ? dw3d_bwd_pk_kernel<T, 4, 2, 6, 16, 14, false, 2> : dw3d_bwd_pk_kernel<T, 4, 2, 6, 16, 14, false, 3>;
   }
   if (lds > 48 * 1024) {
     static bool attr_set = false;

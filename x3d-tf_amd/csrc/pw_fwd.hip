@@ -14,10 +14,12 @@ static int pw_fwd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st
 
 int pw_fwd_bnadd(PwGemmArgs& a, int dtype, int vec, int vec16, int ovec, bool pro, hipStream_t st);   // pw_fwd_infer.hip
 int pw_fwd_tail(PwGemmArgs& a, int dtype, int vec, int ovec, hipStream_t st);                          // pw_fwd_tail.hip
+int pw_fwd_affst(PwGemmArgs& a, int dtype, int vec, int ovec, hipStream_t st);
 
-// the folded residual tail (in_add / in_store): 16-bit storage, stride 1, BN + ReLU prologue without a gate, training epilogue
+// the folded residual tail (in_add / in_store) or, without in_add, the folded BatchNorm + ReLU pass of the stem: 16-bit
+// storage, stride 1, BN + ReLU prologue without a gate, training epilogue
 extern "C" int x3d_pw_fwd_tail_supported(const x3d_pw_fwd_args* f) {
-  if (!f || !f->in_add || !f->in_store || !f->in_scale_shift) return 0;
+  if (!f || !f->in_store || !f->in_scale_shift || (!f->in_add && f->in_add_scale_shift)) return 0;
   if (f->dtype == X3D_F32 || f->stride != 1 || f->in_gate || f->in_act != X3D_ACT_RELU || f->out_scale_shift) return 0;
   return 1;
 }
@@ -51,12 +53,12 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     X3D_REQUIRE(x3d_pw_fwd_tail_supported(f), "pw_fwd: in_add / in_store (folded residual tail) need 16-bit storage, stride 1, "
                                               "in_scale_shift + ReLU, no gate (x3d_pw_fwd_tail_supported)");
     a.x2 = f->in_add; a.coef2 = f->in_add_scale_shift; a.ystore = f->in_store;
-    const int vt = pick_vec(eb, a.P, f->x, f->in_add, f->in_store);
+    const int vt = pick_vec(eb, a.P, f->x, f->in_add ? f->in_add : f->x, f->in_store);
     int ot = pick_vec(eb, a.P, f->y);
     int v16 = vt;
     if (((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->in_add % 16) == 0 && ((uintptr_t)f->in_store % 16) == 0 &&
         ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) v16 = ot = 8;
-    return pw_fwd_tail(a, f->dtype, v16, ot, st);
+    return f->in_add ? pw_fwd_tail(a, f->dtype, v16, ot, st) : pw_fwd_affst(a, f->dtype, v16, ot, st);
   }
   if (f->out_scale_shift) {      // inference epilogue: folded BN + residual Add + activation on the accumulators
     X3D_REQUIRE(!f->stats, "pw_fwd: the inference epilogue (out_scale_shift) takes no statistics");

@@ -9,3 +9,9 @@ int pw_fwd_tail(PwGemmArgs& a, int dtype, int vec, int ovec, hipStream_t st) {
   return dtype == X3D_F16 ? pw_bf16_launch_vec<f16, PRO_TAIL, EPI_STATS>(a, vec, ovec, st)
                           : pw_bf16_launch_vec<bf16, PRO_TAIL, EPI_STATS>(a, vec, ovec, st);
 }
+
+// ... and its one-tensor form (PRO_AFFST): v = act(s * x + t) built on load and stored -- the stem's BatchNorm + ReLU
+int pw_fwd_affst(PwGemmArgs& a, int dtype, int vec, int ovec, hipStream_t st) {
+  return dtype == X3D_F16 ? pw_bf16_launch_vec<f16, PRO_AFFST, EPI_STATS>(a, vec, ovec, st)
+                          : pw_bf16_launch_vec<bf16, PRO_AFFST, EPI_STATS>(a, vec, ovec, st);
+}

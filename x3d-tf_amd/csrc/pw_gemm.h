@@ -18,7 +18,10 @@
 //   v = relu(s_c * x + t_c + (s_r * x2 + t_r | x2)),  x = that block's raw `c` output, x2 = its shortcut (raw shortcut-conv
 //   output or its input) -- and stored to `ystore` as the block's output y: no separate x3d_tail_fwd pass.  Same two-tensor
 //   staging as PRO_BNBWD (v = A*x + B*x2 + C per row) + ReLU + the side store.
-enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_BNBWD = 2, PRO_TAIL = 3 };
+// PRO_AFFST (forward, 16-bit storage): PRO_AFFINE whose activated input v = act(s * x + t) is also stored to `ystore` -- the
+//   stem's BatchNorm + ReLU (x = the raw temporal-conv output, reference model.py:202-210) built by its first reader, the
+//   `a` conv of the first residual block, instead of by a pass of its own.
+enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_BNBWD = 2, PRO_TAIL = 3, PRO_AFFST = 4 };
 
 enum { EPI_STATS = 100,     // forward epilogue (training): store raw + per-channel statistics
        EPI_BNADD = 101 };   // forward epilogue (inference): y = act(s_o*acc + t_o [+ s_r*add + t_r]) -- folded BN, residual Add + ReLU
@@ -29,7 +32,7 @@ struct PwGemmArgs {
   const void* x2;      // PRO_BNBWD: raw conv output
   const float* coef;   // PRO_AFFINE: [K][2] ; PRO_BNBWD: [K][4] ; PRO_TAIL: [K][2] (scale, shift of x)
   const float* coef2;  // PRO_TAIL: [K][2] (scale, shift of x2) or null (x2 taken as it is)
-  void* ystore;        // PRO_TAIL: [N][K][Pin] the activated input, written by the first row-block slice
+  void* ystore;        // PRO_TAIL / PRO_AFFST: [N][K][Pin] the activated input, written by the first row-block slice
   const float* gate;   // PRO_AFFINE: [N][K] or null
   int act;
   // weights, element (k, m) at w[k*wsk + m*wsm]

@@ -117,15 +117,16 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
   }
 
   // AFFINE rows are 2 floats (table always in LDS), BNBWD rows 4 floats (in LDS unless it costs a resident workgroup: K >= 320)
-  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;   // (BNBWD, TAIL: three coefficients per row)
-  const bool use_cs = (PRO == PRO_AFFINE) || a.K < 320;
+  constexpr bool AFF = (PRO == PRO_AFFINE) || (PRO == PRO_AFFST);   // one-tensor affine prologue (AFFST: + the side store)
+  constexpr int CSW = AFF ? 2 : 4;   // (BNBWD, TAIL: three coefficients per row)
+  const bool use_cs = AFF || a.K < 320;
   auto fill_coef = [&](int n) {
     if (!use_cs) return;
     if constexpr (PRO != PRO_NONE) {
       for (int k = tid; k < Kp; k += 256) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         if (k < a.K) {
-          if constexpr (PRO == PRO_AFFINE) {
+          if constexpr (AFF) {
             const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
             c[0] = a.coef[k * 2] * g;       // (s*x + t) * g
             c[1] = a.coef[k * 2 + 1] * g;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
         } else {   // wide-K layers: the table would cost the third resident workgroup (48 -> 55 KB of LDS)
           const bool inb = gk < a.K;
           cf[3] = 0.f;
-          if constexpr (PRO == PRO_AFFINE) {
+          if constexpr (AFF) {
             const float g = (inb && a.gate) ? a.gate[(long long)n * a.K + gk] : 1.0f;
             cf[0] = inb ? a.coef[gk * 2] * g : 0.f; cf[1] = inb ? a.coef[gk * 2 + 1] * g : 0.f; cf[2] = 0.f;
           } else if constexpr (PRO == PRO_TAIL) {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
             cf[0] = inb ? a.coef[gk * 4] : 0.f; cf[1] = inb ? a.coef[gk * 4 + 1] : 0.f; cf[2] = inb ? a.coef[gk * 4 + 2] : 0.f;
           }
         }
-        if constexpr (PRO == PRO_AFFINE) {
+        if constexpr (AFF) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) val[e] = cf[0] * val[e] + cf[1];
           act_vec<VEC>(val, a.act);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
           }
         }
         VecIO<H, VEC>::store(dst, val);
-        if constexpr (PRO == PRO_TAIL) {   // the activated input IS the output y of the block below: kept for its other readers
+        if constexpr (PRO == PRO_TAIL || PRO == PRO_AFFST) {   // the activated input IS the output y of the block below (the stem): kept for its other readers
           const int n_ = tile / tiles_per_n;
           const long long p_ = (long long)(tile - n_ * tiles_per_n) * BN + (long long)pv * VEC;
           if (blockIdx.y == 0 && gk < a.K && p_ < a.P) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
     if constexpr (EPI == X3D_EPI_SWISH_BWD) {
       if (n != n_prev) flush_sums(n_prev);     // the sums are per (sample, channel)
     }
-    if constexpr (PRO == PRO_AFFINE) {
+    if constexpr (AFF) {
       if (n != n_prev && a.gate) fill_coef(n);  // the SE gate is per sample; every reader of the old table is past its last barrier
     }
     n_prev = n;

@@ -729,13 +729,15 @@ class X3D:
             pl.rec(F, "x3d_tail_fwd_bn", pl.t_raw, bn_fold(pl.bn1, n * t * h1 * w1), None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
         else:
             bn_finish(pl.bn1, n * t * h1 * w1)
-            pl.rec(F, "x3d_tail_fwd", pl.t_raw, pl.bn1.ss, None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
+            stem_tail = (pl.t_raw, pl.bn1.ss, None, None, pl.y0, a.c1, t * h1 * w1)   # deferred to its first reader (below)
 
         # ---- residual stages -------------------------------------------------------------------
         # The residual tail of a block (y = relu(bn_c(c) + shortcut), reference model.py:381-392) is DEFERRED to the first
         # reader of y: the next block's `a` conv (or conv5) builds y on load and stores it (x3d_pw_fwd in_add / in_store) where
         # that form exists and does not cost the layer its weights-stationary kernel; otherwise x3d_tail_fwd runs first.
-        pending = {"tail": None}
+        pending = {"tail": None if fold_on or not training else stem_tail}
+        if not training and not fold_on:
+            pl.rec(F, "x3d_tail_fwd", pl.t_raw, pl.bn1.ss, None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
         fold_fwd = training and not fold_on and os.environ.get("X3D_NO_TAIL_FWD_FOLD") != "1"
 
         def fold_pending_tail(st):
@@ -748,7 +750,10 @@ class X3D:
                                1, st.dtype, st.w_panel, in_add=_p(shortcut), in_add_scale_shift=_p(r_ss), in_store=_p(y))
             if (fold_fwd and st.stride == 1 and pl.lib.x3d_pw_fwd_tail_supported(C.byref(ft))
                     and not hip.pw_kernel_name(st).startswith("pw_gemm_wst")):
-                pl.blocks[-1].tail_fwd_folded = True
+                if pl.blocks:
+                    pl.blocks[-1].tail_fwd_folded = True
+                else:
+                    pl.stem_tail_folded = True      # the stem's BatchNorm + ReLU (no Add)
                 return ft
             pl.rec(F, "x3d_tail_fwd", c_raw, c_ss, shortcut, r_ss, y, n, cout_, p_out_, dt)
             return st
@@ -1054,10 +1059,22 @@ class X3D:
                                    _p(prev.c_raw), _p(prev.r_raw), None, None)
                 if not pl.lib.x3d_pw_bwd_supported(C.byref(ft)):
                     ft = None
+            stem_ft = None
+            if fold_tail and prev is None and os.environ.get("X3D_NO_STEM_BWD_FOLD") != "1":
+                # B.x is the stem output y0 = relu(bn(t_raw)): the same epilogue masks dx with [y0 > 0] and takes the stem
+                # BatchNorm's backward sums (sum dx, sum dx * t_raw) -- the x3d_relu_bn_bwd_reduce pass over dy0 / t_raw goes
+                stem_ft = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
+                                        _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt,
+                                        _p(pl.t_raw), None, None, None)
+                if not pl.lib.x3d_pw_bwd_supported(C.byref(stem_ft)):
+                    stem_ft = None
+            pl.stem_bwd_folded = stem_ft is not None
             if ft is not None:
                 prev.tail_folded = True
                 pl.rec(Bk, "x3d_pw_bwd", ("field", ft, {"tail_sums_c": prev.bn_c.bsums,
                                                          "tail_sums_r": prev.bn_r.bsums if prev.bn_r else None}))
+            elif stem_ft is not None:
+                pl.rec(Bk, "x3d_pw_bwd", ("field", stem_ft, {"tail_sums_c": pl.bn1.bsums}))
             elif self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
                 pl.rec(Bk, "x3d_pw_bwd", fa)
             else:
@@ -1075,7 +1092,8 @@ class X3D:
         P1 = t * pl.y0.shape[3] * pl.y0.shape[4]
         # sums only (g = NULL): x3d_dwt_bwd applies the ReLU mask itself on the t_raw values it loads anyway, so the masked
         # gradient of the widest tensor of the network is neither written nor read back
-        pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
+        if not getattr(pl, "stem_bwd_folded", False):
+            pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
         pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b1.bsums), float(n * P1), b1.mi, p["conv1/bn/gamma"], b1.coef,
                g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
         pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
