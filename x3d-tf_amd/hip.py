@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx3d_hip.so")
+LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
 ABI_VERSION = 121   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
