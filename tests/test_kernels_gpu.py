@@ -39,6 +39,14 @@ def _stol(dtype):
     return 1e-5 if dtype == torch.float32 else (3e-3 if dtype == torch.bfloat16 else 5e-4)
 
 
+def _dw_on_matrix_cores(st):
+    """does x3d_dw3d_fwd / _bwd dispatch this launch to a matrix-core kernel (dw_mx.hip)?  Those round their operands
+    to the storage type (the vector kernels multiply in fp32), so the reference is the fp64 convolution of the rounded
+    operands, at the pointwise kernels' tolerance."""
+    from x3d_tf_amd import hip
+    return "_mx" in hip.dw3d_kernel_name(st)
+
+
 def _stats_ref(y, dtype):
     yr = y.to(dtype).double()
     return torch.stack([yr.sum((0, 2, 3, 4)), (yr * yr).sum((0, 2, 3, 4))], 1)
@@ -483,6 +491,10 @@ def test_dw3d_fwd(gpu, dtype, shape):
     torch.cuda.synchronize()
     assert tuple(y.shape) == tuple(ref.shape)
     rt, at = tol_store(dtype)   # inputs pre-rounded, fp32 arithmetic: only the output rounding differs
+    mx = _dw_on_matrix_cores(S.dw_fwd_struct(shape, dtype))
+    if mx:   # matrix-core kernel (dw_mx.hip): the fp32 prologue's output and the weights are rounded to the storage type first
+        ref = O.depthwise3x3x3(round_to(_affine(xd, ss.double(), None, 1).float(), dtype), round_to(wt, dtype), stride)
+        rt, at = tol_gemm(dtype)
     report("y", y, ref, rt, at * ref.abs().max().item())
     ys = y.float().cpu()
     sref = _stats_ref(ys, dtype)
@@ -490,7 +502,7 @@ def test_dw3d_fwd(gpu, dtype, shape):
     report("pool", pool, ys.double().sum((2, 3, 4)), _stol(dtype), 10 * _stol(dtype) * max(1.0, float(ys[0, 0].numel()) ** 0.5))
     # no prologue
     y2 = ops.dw3d_fwd(x.to(gpu), wt.to(gpu), stride)
-    report("y_noprologue", y2, O.depthwise3x3x3(xd, wt.double(), stride), rt, at * ref.abs().max().item())
+    report("y_noprologue", y2, O.depthwise3x3x3(xd, round_to(wt, dtype) if mx else wt.double(), stride), rt, at * ref.abs().max().item())
 
 
 @pytest.mark.parametrize("panel", [False, True])
@@ -590,8 +602,14 @@ def test_dw3d_bwd(gpu, dtype, shape):
     cd = coef.double()
     dB = cd[:, :, 0, None, None, None] * dvd + cd[:, :, 1, None, None, None] * bd + cd[:, :, 2, None, None, None]
     z = _affine(ad, ss.double())
-    act = F.relu(z).requires_grad_(True)
-    wref = wt.double().requires_grad_(True)
+    mx = _dw_on_matrix_cores(S.dw_bwd_struct(shape, dtype))
+    if mx:   # matrix-core kernel (dw_mx.hip): dB, A = relu(z) and the weights enter the products rounded to the storage type
+        dB = round_to(dB.float(), dtype)
+        act = round_to(F.relu(z).float(), dtype).requires_grad_(True)
+        wref = round_to(wt, dtype).requires_grad_(True)
+    else:
+        act = F.relu(z).requires_grad_(True)
+        wref = wt.double().requires_grad_(True)
     out = O.depthwise3x3x3(act, wref, stride)
     dA, dWr = torch.autograd.grad((out * dB).sum(), [act, wref])
     ga_ref = dA * (z > 0)
@@ -601,9 +619,10 @@ def test_dw3d_bwd(gpu, dtype, shape):
     ops.dw3d_bwd(dv.to(gpu), braw.to(gpu), coef.to(gpu), araw.to(gpu), ss.to(gpu), wt.to(gpu).view(c, 27), ga,
                  a_sums, dw, stride)
     torch.cuda.synchronize()
-    rt, at = tol_store(dtype)
+    rt, at = tol_gemm(dtype) if mx else tol_store(dtype)
     report("ga", ga, ga_ref, rt, at * ga_ref.abs().max().item())
-    report("dw", dw, dWr.view(c, 27) + 0.25, 2e-4, 2e-4 * dWr.abs().max().item())
+    wtol = _wtol(dtype) if mx else 2e-4
+    report("dw", dw, dWr.view(c, 27) + 0.25, wtol, wtol * dWr.abs().max().item())
     gs = ga.float().cpu().double()
     sref = torch.stack([gs.sum((0, 2, 3, 4)), (gs * ad).sum((0, 2, 3, 4))], 1)
     report("a_sums", a_sums, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
@@ -990,7 +1009,12 @@ def test_bn_fold_dw3d_fwd(gpu, dtype, shape):
     mm0, mv0, ss0, mi0 = fresh()
     ops.bn_finalize(stats, count, gamma, beta, mm0, mv0, 1e-5, 0.9, 1, ss0, mi0)
     st0 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
-    y0 = ops.dw3d_fwd(x, wt, stride, in_ss=ss0, in_act=1, stats=st0)
+    import os
+    os.environ["X3D_DW_MX"] = "0"      # the folded form runs the vector kernels: compare bits with the same kernel class
+    try:
+        y0 = ops.dw3d_fwd(x, wt, stride, in_ss=ss0, in_act=1, stats=st0)
+    finally:
+        del os.environ["X3D_DW_MX"]
     mm1, mv1, ss1, mi1 = fresh()
     fold = ops.bn_fold(stats, count, gamma, beta, mm1, mv1, 1e-5, 0.9, 1, ss1, mi1)
     st1 = torch.zeros((c, 2), dtype=torch.float64, device=gpu)

@@ -76,6 +76,9 @@ bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int 
 // packed variant for small stride-1 planes (dw_pk.hip): several samples of one channel per 512-thread workgroup
 bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW, hipStream_t st);
 bool dw_fwd_pk_launch(const DwFwdArgs& a, int dtype, int S, int SW, hipStream_t st);
+// matrix-core variant for 14x14 stride-1 planes in 16-bit storage (dw_mx.hip): the tap sums as Toeplitz products on MFMA
+bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st);
+bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);
 
 // ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
 // resource's num_records) loads zeros / drops the store WITHOUT touching memory, so the instruction itself can be

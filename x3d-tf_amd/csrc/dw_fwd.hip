@@ -207,6 +207,11 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   int cv = strips_ok ? a.g.vec : 0;
   // small planes: deep-prefetch variant (dw_pd.hip) when one staging vector per thread covers the tile
   const int pd = dw_pick_pd(SW);
+  if (dw_fwd_mx_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, 16-bit storage: the tap sums on the matrix cores (dw_mx.hip)
+    if (x3d_describe.out) return X3D_OK;
+    X3D_LAUNCH_CHECK("dw3d_fwd");
+    return X3D_OK;
+  }
   if (cv > 0 && dw_fwd_pk_launch(a, f->dtype, S, SW, st)) {   // 10..18-wide and 7x7 stride-1 planes: packed kernel (dw_pk.hip)
     if (x3d_describe.out) return X3D_OK;
     X3D_LAUNCH_CHECK("dw3d_fwd");

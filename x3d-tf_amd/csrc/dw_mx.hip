@@ -1,0 +1,432 @@
+// Channelwise 3x3x3 convolution on the MATRIX CORES, 14x14 stride-1 planes, 16-bit storage (X3D-M stage 4).
+//
+// Why.  The stride-1 depthwise kernels are bound by VALU issue, not by HBM: 27 (forward) / 54 (fused
+// backward) multiply-adds per output plus the staging / window / emit instructions -- ~150 / ~350 vector instructions per
+// thread and plane of four outputs, at 3-5 clocks each (tools/micro/vgpr_banks.hip).  The matrix cores take the multiply-adds
+// off the vector pipe.  Along one image row the convolution is a product with a banded Toeplitz matrix: for a fixed tap row
+// (kt, kh)
+//     out[h][w] += sum_k  Wt[w][k] * in[t + kt - 1][h + kh - 1][k],     Wt[w][k] = w[kt][kh][k - w + 1]  (0 <= k - w + 1 <= 2)
+// which is v_mfma_f32_16x16x32_{bf16,f16} with  A = Wt (M = output column w, K = input column k),  B[k][n] = the input row
+// of output row n = h,  D[w][h] = out^T.  A 14-wide row has 16 window columns (k = w: the left zero pad is the missing k = -1,
+// the right one the zero columns 14, 15), so the K = 32 of one MFMA holds TWO tap rows (lane groups 0-1 and 2-3 read
+// different rows): the 9 tap rows (kt, kh) of an output plane are 6 MFMAs (per kt: rows kh = 0 | 1 together, kh = 2 with a
+// zero half) = 96 matrix-core clocks per (n, c, t) plane against ~500 vector clocks of the tap loop they replace.
+//   * A (the weights) depends on the channel only: six operands (24 VGPRs) built once per wave.
+//   * B is read from an LDS image of the plane in the storage type (BN_a + ReLU applied in fp32 at staging, then rounded --
+//     what the pointwise matrix-core kernels do with their operands, and what the reference's mixed-precision policy does with
+//     the whole convolution): rows -1 .. 16 at a pitch of 48 bytes -- the 16 lanes of a ds_read_b128 quarter cover 64 distinct
+//     banks -- three planes in a ring.  Lane (h = lane & 15, g = lane >> 4) reads 8 columns 8 (g & 1) .. of row h + kh.
+//   * D: lane (h, g) holds out[h][4 g .. 4 g + 3] -- the strip of four outputs it also LOADED (one 8-byte load per lane and
+//     plane, one LDS write) and stores (two 4-byte halves: the last strip of a 14-wide row is half empty).
+//   * ONE wave per workgroup, one (n, c) channel per wave (dw_pk.hip: waves that share barriers take turns on the pipes; here
+//     there is no barrier at all -- a wave's LDS accesses execute in order), ~60 VGPRs: eight waves per SIMD.
+// Sums are fp32 in the matrix cores' own order: results agree with the vector kernels to the operand rounding (tests:
+// test_dw3d_fwd compares 16-bit storage with the fp64 convolution of the ROUNDED operands).
+#include "dw_common.h"
+
+#define MX_PITCH 48                     // bytes per LDS row: 16 columns + 8 of padding (conflict-free b128 rows)
+#define MX_ROWS 18                      // image rows -1 .. 16 (outputs rows 14, 15 of the 16-row tile are never stored)
+#define MX_TILE (MX_PITCH * MX_ROWS)    // 864 bytes per plane
+
+struct DwMxFwdArgs {
+  DwFwdArgs f;
+  unsigned bytes;    // whole-tensor size (buffer num_records)
+};
+
+template <typename T> struct MxOp;
+template <> struct MxOp<bf16> {
+  typedef bf16x8 x8;
+  static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MxOp<f16> {
+  typedef f16x8 x8;
+  static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// The six weight operands of one channel.  Operand i (0..5): kt = i / 2; even i: lane groups 0-1 hold tap row kh = 0, groups
+// 2-3 tap row kh = 1; odd i: groups 0-1 hold kh = 2, groups 2-3 zeros.  FLIP (data gradient): the transposed / reversed
+// kernel, A[w][k] = w[2 - kt][2 - kh][w - k + 1].
+template <typename T, bool FLIP>
+__device__ __forceinline__ void mx_weight_operands(const float* __restrict__ wc, int lane, typename MxOp<T>::x8 (&A)[6]) {
+  const int w = lane & 15, g = lane >> 4;
+  float wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) wr[k] = wc[k];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int kt = i >> 1;
+    // the tap row of this lane group: kh = 0 | 1 (even i), 2 | none (odd i)
+    float t3[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+      float lo, hi;
+      if (!FLIP) {
+        lo = (i & 1) ? wr[kt * 9 + 6 + kw] : wr[kt * 9 + kw];
+        hi = (i & 1) ? 0.f : wr[kt * 9 + 3 + kw];
+      } else {   // tap (kt, kh, kw) of the flipped kernel = w[2 - kt][2 - kh][2 - kw]
+        lo = (i & 1) ? wr[(2 - kt) * 9 + 0 + (2 - kw)] : wr[(2 - kt) * 9 + 6 + (2 - kw)];
+        hi = (i & 1) ? 0.f : wr[(2 - kt) * 9 + 3 + (2 - kw)];
+      }
+      t3[kw] = (g >> 1) ? hi : lo;
+    }
+    typename MxOp<T>::x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int kw = 8 * (g & 1) + j - w + 1;     // k - w + 1
+      const float v = kw == 0 ? t3[0] : (kw == 1 ? t3[1] : (kw == 2 ? t3[2] : 0.f));
+      a[j] = (T)v;
+    }
+    A[i] = a;
+  }
+}
+
+// RB: planes of the LDS ring (3, or 4 where T % 4 == 0 lets the unrolled loop go without an exit test: UN = 4);
+// EXACT: T % UN == 0 -- no `break` inside the unrolled body (with it the compiler's counts of outstanding accesses merge
+// over the exit paths and some waits of the loop fall back to small vmcnt values: the stores' latency shows)
+template <typename T, int UN, int RB, int PD, bool EXACT>
+__global__ __launch_bounds__(64, 6) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs pa) {
+  static_assert(UN % RB == 0 && UN % PD == 0, "ring period RB, slots period PD");
+  constexpr int H = 14, W = 14;
+  typedef typename MxOp<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RB * MX_TILE];
+  const DwFwdArgs& a = pa.f;
+  const DwGeom& g = a.g;
+  const int lane = threadIdx.x;
+  const int h = lane & 15, s = lane >> 4;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x % g.C);
+  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x / g.C);
+
+  for (int i = lane; i < RB * MX_TILE / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);   // pads, halo rows, plane -1
+
+  x8 A[6];
+  mx_weight_operands<T, false>(a.w + c * 27, lane, A);
+  float sc = 1.f, sh = 0.f;
+  if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
+  const float lo = a.act == X3D_ACT_RELU ? 0.f : -__builtin_inff();
+
+  const bool row_ok = h < H;
+  const int ncol = s < 3 ? 4 : 2;                                   // valid outputs of this strip
+  const int planeB = H * W * 2;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((T*)a.x, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((T*)a.y, 0, pa.bytes, 0x00020000);
+  const int voff = row_ok ? (int)((((long long)n * g.C + c) * g.T * H * W + h * W + 4 * s) * 2) : DW_OOB;
+  const int voff1 = (row_ok && s < 3) ? voff + 4 : DW_OOB;           // second half of the strip (columns 14, 15 do not exist)
+  // LDS: the own strip is staged at row h + 1, columns 4 s ..; operand reads start at row h (+ kh), columns 8 (s & 1)
+  unsigned char* stg = lds + (h + 1) * MX_PITCH + s * 8;
+  const unsigned char* rd01 = lds + (h + (s >> 1)) * MX_PITCH + (s & 1) * 16;   // kh = 0 | 1
+  const unsigned char* rd2 = lds + (h + 2) * MX_PITCH + (s & 1) * 16;           // kh = 2 | (zero weights: any finite row)
+
+  Raw slot[PD];             // planes in flight; plane p travels in slot p % PD
+  auto issue = [&](int t, Raw& r) { raw_bload<8>(r, rsX, voff, t < g.T ? t * planeB : DW_OOB); };
+  const unsigned mk0 = row_ok ? 0xffffffffu : 0u, mk1 = (row_ok && s < 3) ? 0xffffffffu : 0u;   // valid halves of the strip
+  auto stage = [&](const Raw& r, int q, bool plane_ok) {   // plane -> ring slot q (a plane past T: zeros)
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(r, e), sh), lo);
+    const unsigned pm = plane_ok ? 0xffffffffu : 0u;        // (uniform)
+    *(uint2*)(stg + q * MX_TILE) = make_uint2(Dot2<T>::pk(v[0], v[1]) & (mk0 & pm), Dot2<T>::pk(v[2], v[3]) & (mk1 & pm));
+  };
+  float s1 = 0.f, s2 = 0.f;
+
+  auto dummy_stores = [&]() {       // (the prologue issues the access sequence of a steady-state iteration: see the backward kernel)
+    Raw z; z.w[0] = 0u;
+    raw_bstore<4>(z, rsY, voff, DW_OOB);
+    raw_bstore<4>(z, rsY, voff1, DW_OOB);
+  };
+#pragma unroll
+  for (int p = 0; p < PD; p++) { issue(p, slot[p]); dummy_stores(); }
+  stage(slot[0], 1, true);          // plane p lives in ring slot (p + 1) % RB
+  issue(PD, slot[0]);
+  dummy_stores();
+
+  for (int t0 = 0; t0 < g.T; t0 += UN) {
+#pragma unroll
+    for (int d = 0; d < UN; d++) {
+      const int t = t0 + d;
+      if (!EXACT && t >= g.T) break;
+      const int qm = d % RB, q0 = (d + 1) % RB, qp = (d + 2) % RB;   // ring slots of planes t-1, t, t+1 (t0 % RB == 0)
+      stage(slot[(d + 1) % PD], qp, t + 1 < g.T);
+      issue(t + 1 + PD, slot[(d + 1) % PD]);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains of three dependent MFMAs
+      const int qs[3] = {qm, q0, qp};
+#pragma unroll
+      for (int kt = 0; kt < 3; kt++) {
+        const x8 b01 = *(const x8*)(rd01 + qs[kt] * MX_TILE);
+        const x8 b2 = *(const x8*)(rd2 + qs[kt] * MX_TILE);
+        acc = MxOp<T>::mfma(A[2 * kt], b01, acc);
+        acc2 = MxOp<T>::mfma(A[2 * kt + 1], b2, acc2);
+      }
+      acc += acc2;
+      // acc[j] = out[h][4 s + j]
+      float o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        o4[e] = (e < 2 ? mk0 : mk1) ? acc[e] : 0.f;
+        s1 += o4[e];
+        s2 += o4[e] * o4[e];
+      }
+      Raw o, o1;
+      o.w[0] = Dot2<T>::pk(o4[0], o4[1]);
+      o1.w[0] = Dot2<T>::pk(o4[2], o4[3]);
+      raw_bstore<4>(o, rsY, voff, t * planeB);
+      raw_bstore<4>(o1, rsY, voff1, t * planeB);
+    }
+  }
+  if (a.stats || a.pool) {
+    const float q1 = wave_sum(s1), q2 = wave_sum(s2);
+    if (lane == 0) {
+      if (a.stats) {
+        double* sp = stats_replica(a.stats, g.C, (unsigned)n);
+        atomic_add_d(&sp[c * 2], (double)q1);
+        atomic_add_d(&sp[c * 2 + 1], (double)q2);
+      }
+      if (a.pool) atomic_add_d(&a.pool[(long long)n * g.C + c], (double)q1);
+    }
+  }
+}
+
+// X3D_DW_MX=0: never (A/B hook)
+bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st) {
+  const DwGeom& g = a.g;
+  const char* e = getenv("X3D_DW_MX");   // (per launch: tools/ab_mx.py switches it inside one process)
+  if ((e && atoi(e) == 0) || dtype == X3D_F32 || S != 1 || g.H != 14 || g.W != 14 || a.bn.stats) return false;
+  const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
+  if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
+  if (((uintptr_t)a.x & 3) || ((uintptr_t)a.y & 3)) return false;
+  const bool exact = g.T % 4 == 0;
+  if (x3d_describe.out) {
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_mx14_kernel<%s, %s>", dtype == X3D_BF16 ? "bf16" : "f16",
+             exact ? "4, 4, 4, 1" : "6, 3, 3, 0");
+    return true;
+  }
+  DwMxFwdArgs pa;
+  pa.f = a;
+  pa.bytes = (unsigned)bytes;
+  const dim3 grid((unsigned)(g.C * g.N));
+  if (dtype == X3D_BF16) {
+    if (exact) hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<bf16, 4, 4, 4, true>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  } else {
+    if (exact) hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<f16, 4, 4, 4, true>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<f16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  }
+  return true;
+}
+
+// ================================================================================================
+// FUSED BACKWARD on the matrix cores (same planes, same organisation: one wave per (n, c) channel).
+//   dB = cA * dv + cB * braw + cC   (BN_b / SE backward folded per (n, c): coef_nc),   A = relu(s * araw + t)
+//   dA[t][h][w] = sum w[kt][kh][kw] * dB[t - kt + 1][h - kh + 1][w - kw + 1]   -- the forward product with the reversed
+//       kernel: six MFMAs per plane against the dB image (ring of three planes), weight operands built once;
+//   dW[kt][kh][kw] = sum_{t,h,w} dB[t][h][w] * A[t + kt - 1][h + kh - 1][w + kw - 1]:  for a fixed (kt, kw)
+//       C[h][h'] = sum_w dB[t][h][w] * A[t + kt - 1][h'][w + kw - 1]   is one MFMA (M = h, N = h', K = w: both operands are
+//       rows of the LDS images, 8 consecutive columns per lane) and dW[kt][kh][kw] is the diagonal h' = h + kh - 1 of C summed
+//       over the planes -- nine accumulators (36 VGPRs) kept over the whole channel, the diagonals taken once at the end.
+//       The column shift kw - 1 of the A rows is made in registers: one aligned ds_read_b128 + the dwords either side, five
+//       v_alignbit for the three shifted operands (the A image has 8 zero columns left of column 0, pitch 80 bytes).
+//       The upper half of K (lane groups 2, 3) is zero: those lanes read the dB operand from a zero row.
+// Per plane and lane: three 8-byte loads, two LDS writes, 6 + 9 MFMAs, ~80 vector instructions (the vector kernel: ~350).
+// ================================================================================================
+#define MXA_PITCH 80                       // A image: 8 zero columns | 16 columns | 8 columns of padding, 64 + 16 bytes
+#define MXA_TILE (MXA_PITCH * MX_ROWS)     // 1440 bytes per plane
+
+struct DwMxBwdArgs {
+  DwBwdArgs b;
+  unsigned bytes;
+};
+
+template <typename T, int UN, int RB, int PD, bool EXACT>
+__global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs pa) {
+  static_assert(UN % RB == 0 && UN % 2 == 0 && UN % PD == 0, "ring periods RB (dB planes), 2 (A planes) and PD (planes in flight)");
+  constexpr int H = 14, W = 14;
+  typedef typename MxOp<T>::x8 x8;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+  // dB ring (RB planes) | A ring (2 planes) | one zero row
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RB * MX_TILE + 2 * MXA_TILE + 64];
+  unsigned char* ldsA = lds + RB * MX_TILE;
+  const DwBwdArgs& a = pa.b;
+  const DwGeom& g = a.g;
+  const int lane = threadIdx.x;
+  const int h = lane & 15, s = lane >> 4;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x % g.C);
+  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x / g.C);
+
+  for (int i = lane; i < (RB * MX_TILE + 2 * MXA_TILE + 64) / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  x8 Wt[6];
+  mx_weight_operands<T, true>(a.w + c * 27, lane, Wt);
+  const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
+  const float* cf = a.coef_nc + ((long long)n * g.C + c) * 4;
+  const float cA = cf[0], cB = cf[1], cC = cf[2];
+
+  const bool row_ok = h < H;
+  const int ncol = s < 3 ? 4 : 2;
+  const int planeB = H * W * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((T*)a.araw, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((T*)a.dv, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((T*)a.braw, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((T*)a.ga, 0, pa.bytes, 0x00020000);
+  const int voff = row_ok ? (int)((((long long)n * g.C + c) * g.T * H * W + h * W + 4 * s) * 2) : DW_OOB;
+  const int voff1 = (row_ok && s < 3) ? voff + 4 : DW_OOB;
+  // dB image: as the forward's plane image.  dA operand reads: row h (+ kh), columns 8 (s & 1)
+  unsigned char* stgB = lds + (h + 1) * MX_PITCH + s * 8;
+  const unsigned char* rd01 = lds + (h + (s >> 1)) * MX_PITCH + (s & 1) * 16;
+  const unsigned char* rd2 = lds + (h + 2) * MX_PITCH + (s & 1) * 16;
+  // dW: M-operand = the dB row of output row h (image row h = LDS row h + 1), lane groups 2, 3 a zero row (K = 16 .. 31 unused)
+  const bool lowk = s < 2;
+  const unsigned char* rdM = lowk ? lds + (h + 1) * MX_PITCH + (s & 1) * 16 : lds + RB * MX_TILE + 2 * MXA_TILE;
+  const int rdM_tile = lowk ? MX_TILE : 0;
+  // A image: image column c at byte 16 + 2 c of the row.  Own strip at row h + 1; N-operand = the A row h' = lane & 15 (LDS row
+  // h' + 1), columns 8 (s & 1) - 1 .. + 8 (one aligned b128, the dword before and the dword after)
+  unsigned char* stgA = ldsA + (h + 1) * MXA_PITCH + 16 + s * 8;
+  const unsigned char* rdN = ldsA + (h + 1) * MXA_PITCH + 16 + (s & 1) * 16;
+
+  struct Slot { Raw A, D, R; };
+  Slot slot[PD];        // plane p travels in slot p % PD
+  auto issue = [&](int t, Slot& q) {
+    const int soff = t < g.T ? t * planeB : DW_OOB;
+    raw_bload<8>(q.A, rsA, voff, soff);
+    raw_bload<8>(q.D, rsD, voff, soff);
+    raw_bload<8>(q.R, rsR, voff, soff);
+  };
+  // validity of the strip's halves as AND masks on the packed pairs (rows 14, 15 and columns 14, 15 hold zeros)
+  const unsigned mk0 = row_ok ? 0xffffffffu : 0u, mk1 = (row_ok && s < 3) ? 0xffffffffu : 0u;
+  auto stage = [&](const Slot& q, int qb, int qa, bool plane_ok) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      av[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(q.A, e), sh), 0.f);
+      bv[e] = __builtin_fmaf(cA, raw_get<T>(q.D, e), __builtin_fmaf(cB, raw_get<T>(q.R, e), cC));
+    }
+    const unsigned pm = plane_ok ? 0xffffffffu : 0u;        // (uniform; false once: the zero plane behind the last one)
+    const unsigned m0 = mk0 & pm, m1 = mk1 & pm;
+    *(uint2*)(stgA + qa * MXA_TILE) = make_uint2(Dot2<T>::pk(av[0], av[1]) & m0, Dot2<T>::pk(av[2], av[3]) & m1);
+    *(uint2*)(stgB + qb * MX_TILE) = make_uint2(Dot2<T>::pk(bv[0], bv[1]) & m0, Dot2<T>::pk(bv[2], bv[3]) & m1);
+  };
+
+  f32x4 Cw[9];        // Cw[kt * 3 + kw][r] = C[h = 4 s + r][h' = lane & 15]
+#pragma unroll
+  for (int k = 0; k < 9; k++) Cw[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  Raw own;            // araw strip of the plane whose dA is emitted next
+
+  // the prologue issues the load / store sequence of a steady-state iteration (its stores dropped: out of range): the loop
+  // header merges the prologue's and the back edge's counts of outstanding accesses, and with fewer in the prologue every
+  // iteration's wait for a prefetched plane would also wait for the previous iteration's stores (vmcnt retires in order)
+  auto dummy_stores = [&]() {
+    Raw z; z.w[0] = 0u;
+    raw_bstore<4>(z, rsG, voff, DW_OOB);
+    raw_bstore<4>(z, rsG, voff1, DW_OOB);
+  };
+#pragma unroll
+  for (int p = 0; p < PD; p++) { issue(p, slot[p]); dummy_stores(); }
+  stage(slot[0], 1, 0, true);        // plane p: dB ring slot (p + 1) % RB, A ring slot p & 1
+  own = slot[0].A;
+  issue(PD, slot[0]);
+  dummy_stores();
+
+  for (int t0 = 0; t0 < g.T; t0 += UN) {
+#pragma unroll
+    for (int d = 0; d < UN; d++) {
+      const int t = t0 + d;
+      if (!EXACT && t >= g.T) break;
+      const int qs[3] = {d % RB, (d + 1) % RB, (d + 2) % RB};   // dB ring slots of planes t-1, t, t+1
+      const int sl = (d + 1) % PD;
+      stage(slot[sl], qs[2], (d + 1) & 1, t + 1 < g.T);
+      const Raw own_next = slot[sl].A;
+      issue(t + 1 + PD, slot[sl]);
+      // ---- data gradient of plane t
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 3; kt++) {
+        const x8 b01 = *(const x8*)(rd01 + qs[kt] * MX_TILE);
+        const x8 b2 = *(const x8*)(rd2 + qs[kt] * MX_TILE);
+        acc = MxOp<T>::mfma(Wt[2 * kt], b01, acc);
+        acc2 = MxOp<T>::mfma(Wt[2 * kt + 1], b2, acc2);
+      }
+      // ---- weight gradient: the A rows of plane t (three column shifts) against the dB rows of planes t+1, t, t-1 (kt = 0, 1, 2)
+      {
+        const unsigned char* pn = rdN + (d & 1) * MXA_TILE;
+        const u32x4_ mid = *(const u32x4_*)pn;
+        const unsigned prv = *(const unsigned*)(pn - 4), nxt = *(const unsigned*)(pn + 16);
+        const unsigned m01 = __builtin_amdgcn_alignbit(mid[1], mid[0], 16), m12 = __builtin_amdgcn_alignbit(mid[2], mid[1], 16),
+                       m23 = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
+        const u32x4_ lft = {__builtin_amdgcn_alignbit(mid[0], prv, 16), m01, m12, m23};     // columns 8 g' - 1 .. (kw = 0)
+        const u32x4_ rgt = {m01, m12, m23, __builtin_amdgcn_alignbit(nxt, mid[3], 16)};     // columns 8 g' + 1 .. (kw = 2)
+        const x8 n0 = __builtin_bit_cast(x8, lft), n1 = __builtin_bit_cast(x8, mid), n2 = __builtin_bit_cast(x8, rgt);
+#pragma unroll
+        for (int kt = 0; kt < 3; kt++) {
+          const x8 m = *(const x8*)(rdM + qs[2 - kt] * rdM_tile);
+          Cw[kt * 3 + 0] = MxOp<T>::mfma(m, n0, Cw[kt * 3 + 0]);
+          Cw[kt * 3 + 1] = MxOp<T>::mfma(m, n1, Cw[kt * 3 + 1]);
+          Cw[kt * 3 + 2] = MxOp<T>::mfma(m, n2, Cw[kt * 3 + 2]);
+        }
+      }
+      // ---- emit dA[t]: ReLU mask of BN_a, the BN_a backward sums of the stored gradient
+      acc += acc2;
+      float o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float av = raw_get<T>(own, e);                       // (rows / columns outside the image load zeros: the
+        o4[e] = (__builtin_fmaf(sc, av, sh) > 0.f && (e < 2 ? mk0 : mk1)) ? acc[e] : 0.f;   //  lane masks close them)
+        s1 += o4[e];
+        s2 += o4[e] * av;
+      }
+      Raw o, o1;
+      o.w[0] = Dot2<T>::pk(o4[0], o4[1]);
+      o1.w[0] = Dot2<T>::pk(o4[2], o4[3]);
+      raw_bstore<4>(o, rsG, voff, t * planeB);
+      raw_bstore<4>(o1, rsG, voff1, t * planeB);
+      own = own_next;
+    }
+  }
+
+  // ---- dW[kt][kh][kw] = sum over lanes / registers with h' - h + 1 == kh of Cw[kt][kw]
+  float red[29];
+#pragma unroll
+  for (int kt = 0; kt < 3; kt++)
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+      float p[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int kh = h - (4 * s + r) + 1;      // h' = lane & 15 = h here (the N index), row index 4 s + r
+        const float v = Cw[kt * 3 + kw][r];
+        p[0] += kh == 0 ? v : 0.f;
+        p[1] += kh == 1 ? v : 0.f;
+        p[2] += kh == 2 ? v : 0.f;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) red[kt * 9 + kh * 3 + kw] = wave_sum_lane63(p[kh]);
+    }
+  red[27] = wave_sum_lane63(s1);
+  red[28] = wave_sum_lane63(s2);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
+    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
+    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
+  }
+}
+
+bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
+  const DwGeom& g = a.g;
+  const char* e = getenv("X3D_DW_MX");
+  // fp16: the forward only (dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back)
+  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || g.H != 14 || g.W != 14) return false;
+  const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
+  if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
+  if (((uintptr_t)a.araw & 3) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 3) || ((uintptr_t)a.braw & 3)) return false;
+  const bool exact = g.T % 4 == 0;
+  if (x3d_describe.out) {
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mx14_kernel<bf16, %s>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
+    return true;
+  }
+  DwMxBwdArgs pa;
+  pa.b = a;
+  pa.bytes = (unsigned)bytes;
+  const dim3 grid((unsigned)(g.C * g.N));
+  if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
+  else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  return true;
+}
