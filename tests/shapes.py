@@ -149,6 +149,8 @@ DW = [
     (9, 3, 5, 7, 7, 1),                                                   #   7x7: four planes per wave (4 + 4 + 1), strips 4 + 3
     (3, 4, 8, 14, 14, 1), (2, 3, 1, 14, 14, 1), (2, 2, 2, 14, 14, 1),     # matrix-core kernels (dw_mx.hip, 16-bit storage): T % 4 == 0 runs the
     (2, 3, 13, 14, 14, 1),                                                #   exit-free loop (ring of 4), else ring of 3; T below the prefetch depth
+    (5, 3, 4, 7, 7, 1), (2, 2, 8, 7, 7, 1), (4, 2, 16, 7, 7, 1),          #   7x7 planes four to a tile (partial last group), T % 4 == 0
+    (2, 2, 4, 12, 14, 1), (1, 2, 5, 14, 12, 1),                           #   12 / 14 rows and columns
     # ragged rows (flat staging, CV < 0): X3D-S 182-pixel test crops (91 / 46 / 23), vectors that cross rows and H-tiles,
     # rows shorter than a 16-byte vector (13 -> 7: 8-byte vectors), short planes
     (1, 2, 3, 91, 91, 1), (1, 2, 3, 91, 91, 2), (1, 2, 4, 46, 46, 1), (1, 2, 3, 23, 23, 1), (1, 2, 3, 23, 23, 2),

@@ -80,21 +80,87 @@ __device__ __forceinline__ void mx_weight_operands(const float* __restrict__ wc,
   }
 }
 
+// Which image strip a lane owns.  Lane (h = lane & 15, s = lane >> 4) is row h, columns 4 s .. 4 s + 3 of the 16 x 16 tile.
+//   P7 = false: ONE plane of H x W <= 14 x 14 (even W) -- tile row / column = image row / column, rows >= H and columns >= W
+//     hold zeros (the bottom / right TF-SAME pad).
+//   P7 = true: FOUR 7 x 7 planes (samples n0 .. n0 + 3 of one channel) in one tile: rows 0-6 | zero row 7 | rows 8-14, columns
+//     0-6 | zero column 7 | columns 8-14 -- the separators are the planes' zero pads, so the products are those of the single
+//     plane.  Rows of 7 elements start at any 2-byte address: the second strip of a row (columns 4, 5, 6) is loaded one
+//     element early (columns 3 .. 6: it never leaves its row, so never the tensor) and shifted down; its third element is
+//     stored alone.
+template <bool P7>
+struct MxMap {
+  int voffL, shift;          // load offset (bytes from the tensor base; DW_OOB: nothing), elements to shift the loaded vector down
+  int vst0, vst1, vst1e;     // stores: pair 0, pair 1 (4 bytes each), element 2 alone (2 bytes)
+  unsigned mk0, mk1;         // valid elements of the two pairs as AND masks
+  int n;                     // sample of this lane
+  int planeB;
+  __device__ __forceinline__ void build(int lane, int blk, int N, int C, int T, int H, int W, int& c) {
+    const int h = lane & 15, s = lane >> 4;
+    if constexpr (!P7) {
+      c = __builtin_amdgcn_readfirstlane(blk % C);
+      n = __builtin_amdgcn_readfirstlane(blk / C);
+      const bool ok0 = h < H && 4 * s < W, ok1 = h < H && 4 * s + 2 < W;
+      const long long e = (((long long)n * C + c) * T * H + h) * W + 4 * s;
+      voffL = ok0 ? (int)(e * 2) : DW_OOB;
+      shift = 0;
+      vst0 = voffL;
+      vst1 = ok1 ? (int)(e * 2) + 4 : DW_OOB;
+      vst1e = DW_OOB;
+      mk0 = ok0 ? 0xffffffffu : 0u;
+      mk1 = ok1 ? 0xffffffffu : 0u;
+      planeB = H * W * 2;
+    } else {
+      c = __builtin_amdgcn_readfirstlane(blk % C);
+      const int n0 = __builtin_amdgcn_readfirstlane(blk / C) * 4;
+      n = n0 + 2 * (h >> 3) + (s >> 1);
+      const int r = h & 7, second = s & 1;                 // in-plane row, second strip of the row (columns 4, 5, 6)
+      const bool ok = r < 7 && n < N;
+      const long long e = (((long long)n * C + c) * T * 7 + r) * 7 + 4 * second;
+      voffL = ok ? (int)((e - second) * 2) : DW_OOB;
+      shift = second;
+      vst0 = ok ? (int)(e * 2) : DW_OOB;
+      vst1 = (ok && !second) ? (int)(e * 2) + 4 : DW_OOB;
+      vst1e = (ok && second) ? (int)(e * 2) + 4 : DW_OOB;
+      mk0 = ok ? 0xffffffffu : 0u;
+      mk1 = ok ? (second ? 0x0000ffffu : 0xffffffffu) : 0u;
+      planeB = 49 * 2;
+    }
+  }
+  // the loaded vector with the strip's first element in element 0
+  __device__ __forceinline__ Raw aligned(const Raw& r) const {
+    if constexpr (P7) {
+      const unsigned long long v = (((unsigned long long)r.w[1] << 32) | r.w[0]) >> (16 * shift);
+      Raw o; o.w[0] = (unsigned)v; o.w[1] = (unsigned)(v >> 32); o.w[2] = o.w[3] = 0u;
+      return o;
+    } else {
+      return r;
+    }
+  }
+  __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned p0, unsigned p1, int soff) const {
+    Raw o, o1;
+    o.w[0] = p0; o1.w[0] = p1;
+    raw_bstore<4>(o, rs, vst0, soff);
+    raw_bstore<4>(o1, rs, vst1, soff);
+    if constexpr (P7) raw_bstore<2>(o1, rs, vst1e, soff);
+  }
+};
+
 // RB: planes of the LDS ring (3, or 4 where T % 4 == 0 lets the unrolled loop go without an exit test: UN = 4);
 // EXACT: T % UN == 0 -- no `break` inside the unrolled body (with it the compiler's counts of outstanding accesses merge
 // over the exit paths and some waits of the loop fall back to small vmcnt values: the stores' latency shows)
-template <typename T, int UN, int RB, int PD, bool EXACT>
-__global__ __launch_bounds__(64, 6) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs pa) {
+template <typename T, int UN, int RB, int PD, bool EXACT, bool P7>
+__global__ __launch_bounds__(64, 7) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs pa) {
   static_assert(UN % RB == 0 && UN % PD == 0, "ring period RB, slots period PD");
-  constexpr int H = 14, W = 14;
   typedef typename MxOp<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RB * MX_TILE];
   const DwFwdArgs& a = pa.f;
   const DwGeom& g = a.g;
   const int lane = threadIdx.x;
   const int h = lane & 15, s = lane >> 4;
-  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x % g.C);
-  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x / g.C);
+  int c;
+  MxMap<P7> mp;
+  mp.build(lane, blockIdx.x, g.N, g.C, g.T, g.H, g.W, c);
 
   for (int i = lane; i < RB * MX_TILE / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);   // pads, halo rows, plane -1
 
@@ -104,22 +170,19 @@ __global__ __launch_bounds__(64, 6) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs 
   if (a.ss) { sc = a.ss[c * 2]; sh = a.ss[c * 2 + 1]; }
   const float lo = a.act == X3D_ACT_RELU ? 0.f : -__builtin_inff();
 
-  const bool row_ok = h < H;
-  const int ncol = s < 3 ? 4 : 2;                                   // valid outputs of this strip
-  const int planeB = H * W * 2;
+  const int planeB = mp.planeB;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((T*)a.x, 0, pa.bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((T*)a.y, 0, pa.bytes, 0x00020000);
-  const int voff = row_ok ? (int)((((long long)n * g.C + c) * g.T * H * W + h * W + 4 * s) * 2) : DW_OOB;
-  const int voff1 = (row_ok && s < 3) ? voff + 4 : DW_OOB;           // second half of the strip (columns 14, 15 do not exist)
   // LDS: the own strip is staged at row h + 1, columns 4 s ..; operand reads start at row h (+ kh), columns 8 (s & 1)
   unsigned char* stg = lds + (h + 1) * MX_PITCH + s * 8;
   const unsigned char* rd01 = lds + (h + (s >> 1)) * MX_PITCH + (s & 1) * 16;   // kh = 0 | 1
   const unsigned char* rd2 = lds + (h + 2) * MX_PITCH + (s & 1) * 16;           // kh = 2 | (zero weights: any finite row)
 
   Raw slot[PD];             // planes in flight; plane p travels in slot p % PD
-  auto issue = [&](int t, Raw& r) { raw_bload<8>(r, rsX, voff, t < g.T ? t * planeB : DW_OOB); };
-  const unsigned mk0 = row_ok ? 0xffffffffu : 0u, mk1 = (row_ok && s < 3) ? 0xffffffffu : 0u;   // valid halves of the strip
-  auto stage = [&](const Raw& r, int q, bool plane_ok) {   // plane -> ring slot q (a plane past T: zeros)
+  auto issue = [&](int t, Raw& r) { raw_bload<8>(r, rsX, mp.voffL, t < g.T ? t * planeB : DW_OOB); };
+  const unsigned mk0 = mp.mk0, mk1 = mp.mk1;   // valid elements of the strip's two pairs
+  auto stage = [&](const Raw& r0, int q, bool plane_ok) {   // plane -> ring slot q (a plane past T: zeros)
+    const Raw r = mp.aligned(r0);
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) v[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(r, e), sh), lo);
@@ -128,11 +191,8 @@ __global__ __launch_bounds__(64, 6) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs 
   };
   float s1 = 0.f, s2 = 0.f;
 
-  auto dummy_stores = [&]() {       // (the prologue issues the access sequence of a steady-state iteration: see the backward kernel)
-    Raw z; z.w[0] = 0u;
-    raw_bstore<4>(z, rsY, voff, DW_OOB);
-    raw_bstore<4>(z, rsY, voff1, DW_OOB);
-  };
+  auto dummy_stores = [&]() { mp.store(rsY, 0u, 0u, DW_OOB); };   // (the prologue issues the access sequence of a steady-state
+                                                                   //  iteration: see the backward kernel)
 #pragma unroll
   for (int p = 0; p < PD; p++) { issue(p, slot[p]); dummy_stores(); }
   stage(slot[0], 1, true);          // plane p lives in ring slot (p + 1) % RB
@@ -161,55 +221,75 @@ __global__ __launch_bounds__(64, 6) void dw3d_fwd_mx14_kernel(const DwMxFwdArgs 
       float o4[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        o4[e] = (e < 2 ? mk0 : mk1) ? acc[e] : 0.f;
+        const unsigned m = e < 2 ? mk0 : mk1;
+        o4[e] = (m >> (16 * (e & 1)) & 1u) ? acc[e] : 0.f;
         s1 += o4[e];
         s2 += o4[e] * o4[e];
       }
-      Raw o, o1;
-      o.w[0] = Dot2<T>::pk(o4[0], o4[1]);
-      o1.w[0] = Dot2<T>::pk(o4[2], o4[3]);
-      raw_bstore<4>(o, rsY, voff, t * planeB);
-      raw_bstore<4>(o1, rsY, voff1, t * planeB);
+      mp.store(rsY, Dot2<T>::pk(o4[0], o4[1]), Dot2<T>::pk(o4[2], o4[3]), t * planeB);
     }
   }
   if (a.stats || a.pool) {
     const float q1 = wave_sum(s1), q2 = wave_sum(s2);
+    float qp[P7 ? 4 : 1];
+    if constexpr (P7) {     // the squeeze-excite pool is per sample: the four planes' sums separately
+#pragma unroll
+      for (int k = 0; k < 4; k++) qp[k] = wave_sum((2 * (h >> 3) + (s >> 1)) == k ? s1 : 0.f);
+    }
     if (lane == 0) {
       if (a.stats) {
-        double* sp = stats_replica(a.stats, g.C, (unsigned)n);
+        double* sp = stats_replica(a.stats, g.C, (unsigned)blockIdx.x);
         atomic_add_d(&sp[c * 2], (double)q1);
         atomic_add_d(&sp[c * 2 + 1], (double)q2);
       }
-      if (a.pool) atomic_add_d(&a.pool[(long long)n * g.C + c], (double)q1);
+      if (a.pool) {
+        if constexpr (P7) {
+          const int n0 = (int)(blockIdx.x / g.C) * 4;
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (n0 + k < g.N) atomic_add_d(&a.pool[(long long)(n0 + k) * g.C + c], (double)qp[k]);
+        } else {
+          atomic_add_d(&a.pool[(long long)mp.n * g.C + c], (double)q1);
+        }
+      }
     }
   }
+}
+
+// planes the tile covers: one plane of 12 .. 14 rows and 12 / 14 columns (even: strips start at 4-byte addresses), or 7 x 7
+// planes four to a tile
+static bool mx_plane_ok(const DwGeom& g, bool* p7) {
+  *p7 = g.H == 7 && g.W == 7;
+  // (a 10 x 10 plane fills 39 % of the tile: measured 85 -> 87 us forward, 185 -> 240 us backward against the vector kernels)
+  return *p7 || (g.H >= 12 && g.H <= 14 && g.W >= 12 && g.W <= 14 && (g.W & 1) == 0);
 }
 
 // X3D_DW_MX=0: never (A/B hook)
 bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
   const char* e = getenv("X3D_DW_MX");   // (per launch: tools/ab_mx.py switches it inside one process)
-  if ((e && atoi(e) == 0) || dtype == X3D_F32 || S != 1 || g.H != 14 || g.W != 14 || a.bn.stats) return false;
+  bool p7;
+  if ((e && atoi(e) == 0) || dtype == X3D_F32 || S != 1 || !mx_plane_ok(g, &p7) || a.bn.stats) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.x & 3) || ((uintptr_t)a.y & 3)) return false;
   const bool exact = g.T % 4 == 0;
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_mx14_kernel<%s, %s>", dtype == X3D_BF16 ? "bf16" : "f16",
-             exact ? "4, 4, 4, 1" : "6, 3, 3, 0");
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_mx14_kernel<%s, %s, %d>", dtype == X3D_BF16 ? "bf16" : "f16",
+             exact ? "4, 4, 4, 1" : "6, 3, 3, 0", (int)p7);
     return true;
   }
   DwMxFwdArgs pa;
   pa.f = a;
   pa.bytes = (unsigned)bytes;
-  const dim3 grid((unsigned)(g.C * g.N));
-  if (dtype == X3D_BF16) {
-    if (exact) hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<bf16, 4, 4, 4, true>), grid, dim3(64), 0, st, pa);
-    else hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
-  } else {
-    if (exact) hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<f16, 4, 4, 4, true>), grid, dim3(64), 0, st, pa);
-    else hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<f16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
-  }
+  const dim3 grid((unsigned)(g.C * (p7 ? ceil_div(g.N, 4) : g.N)));
+#define MX_FWD(TT, P7_)                                                                                             \
+  do {                                                                                                              \
+    if (exact) hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<TT, 4, 4, 4, true, P7_>), grid, dim3(64), 0, st, pa);       \
+    else hipLaunchKernelGGL((dw3d_fwd_mx14_kernel<TT, 6, 3, 3, false, P7_>), grid, dim3(64), 0, st, pa);            \
+  } while (0)
+  if (dtype == X3D_BF16) { if (p7) MX_FWD(bf16, true); else MX_FWD(bf16, false); }
+  else { if (p7) MX_FWD(f16, true); else MX_FWD(f16, false); }
+#undef MX_FWD
   return true;
 }
 
@@ -235,10 +315,9 @@ struct DwMxBwdArgs {
   unsigned bytes;
 };
 
-template <typename T, int UN, int RB, int PD, bool EXACT>
+template <typename T, int UN, int RB, int PD, bool EXACT, bool P7>
 __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs pa) {
   static_assert(UN % RB == 0 && UN % 2 == 0 && UN % PD == 0, "ring periods RB (dB planes), 2 (A planes) and PD (planes in flight)");
-  constexpr int H = 14, W = 14;
   typedef typename MxOp<T>::x8 x8;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
   // dB ring (RB planes) | A ring (2 planes) | one zero row
@@ -248,26 +327,25 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
   const DwGeom& g = a.g;
   const int lane = threadIdx.x;
   const int h = lane & 15, s = lane >> 4;
-  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x % g.C);
-  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x / g.C);
+  int c;
+  MxMap<P7> mp;
+  mp.build(lane, blockIdx.x, g.N, g.C, g.T, g.H, g.W, c);
 
   for (int i = lane; i < (RB * MX_TILE + 2 * MXA_TILE + 64) / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   x8 Wt[6];
   mx_weight_operands<T, true>(a.w + c * 27, lane, Wt);
   const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
-  const float* cf = a.coef_nc + ((long long)n * g.C + c) * 4;
-  const float cA = cf[0], cB = cf[1], cC = cf[2];
-
-  const bool row_ok = h < H;
-  const int ncol = s < 3 ? 4 : 2;
-  const int planeB = H * W * 2;
+  float cA = 0.f, cB = 0.f, cC = 0.f;          // per (sample, channel): uniform for one plane per wave, per lane for four
+  if (mp.n < g.N) {
+    const float* cf = a.coef_nc + ((long long)mp.n * g.C + c) * 4;
+    cA = cf[0]; cB = cf[1]; cC = cf[2];
+  }
+  const int planeB = mp.planeB;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((T*)a.araw, 0, pa.bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((T*)a.dv, 0, pa.bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((T*)a.braw, 0, pa.bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((T*)a.ga, 0, pa.bytes, 0x00020000);
-  const int voff = row_ok ? (int)((((long long)n * g.C + c) * g.T * H * W + h * W + 4 * s) * 2) : DW_OOB;
-  const int voff1 = (row_ok && s < 3) ? voff + 4 : DW_OOB;
   // dB image: as the forward's plane image.  dA operand reads: row h (+ kh), columns 8 (s & 1)
   unsigned char* stgB = lds + (h + 1) * MX_PITCH + s * 8;
   const unsigned char* rd01 = lds + (h + (s >> 1)) * MX_PITCH + (s & 1) * 16;
@@ -285,18 +363,19 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
   Slot slot[PD];        // plane p travels in slot p % PD
   auto issue = [&](int t, Slot& q) {
     const int soff = t < g.T ? t * planeB : DW_OOB;
-    raw_bload<8>(q.A, rsA, voff, soff);
-    raw_bload<8>(q.D, rsD, voff, soff);
-    raw_bload<8>(q.R, rsR, voff, soff);
+    raw_bload<8>(q.A, rsA, mp.voffL, soff);
+    raw_bload<8>(q.D, rsD, mp.voffL, soff);
+    raw_bload<8>(q.R, rsR, mp.voffL, soff);
   };
   // validity of the strip's halves as AND masks on the packed pairs (rows 14, 15 and columns 14, 15 hold zeros)
-  const unsigned mk0 = row_ok ? 0xffffffffu : 0u, mk1 = (row_ok && s < 3) ? 0xffffffffu : 0u;
+  const unsigned mk0 = mp.mk0, mk1 = mp.mk1;
   auto stage = [&](const Slot& q, int qb, int qa, bool plane_ok) {
+    const Raw rA = mp.aligned(q.A), rD = mp.aligned(q.D), rR = mp.aligned(q.R);
     float av[4], bv[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      av[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(q.A, e), sh), 0.f);
-      bv[e] = __builtin_fmaf(cA, raw_get<T>(q.D, e), __builtin_fmaf(cB, raw_get<T>(q.R, e), cC));
+      av[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(rA, e), sh), 0.f);
+      bv[e] = __builtin_fmaf(cA, raw_get<T>(rD, e), __builtin_fmaf(cB, raw_get<T>(rR, e), cC));
     }
     const unsigned pm = plane_ok ? 0xffffffffu : 0u;        // (uniform; false once: the zero plane behind the last one)
     const unsigned m0 = mk0 & pm, m1 = mk1 & pm;
@@ -313,15 +392,11 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
   // the prologue issues the load / store sequence of a steady-state iteration (its stores dropped: out of range): the loop
   // header merges the prologue's and the back edge's counts of outstanding accesses, and with fewer in the prologue every
   // iteration's wait for a prefetched plane would also wait for the previous iteration's stores (vmcnt retires in order)
-  auto dummy_stores = [&]() {
-    Raw z; z.w[0] = 0u;
-    raw_bstore<4>(z, rsG, voff, DW_OOB);
-    raw_bstore<4>(z, rsG, voff1, DW_OOB);
-  };
+  auto dummy_stores = [&]() { mp.store(rsG, 0u, 0u, DW_OOB); };
 #pragma unroll
   for (int p = 0; p < PD; p++) { issue(p, slot[p]); dummy_stores(); }
   stage(slot[0], 1, 0, true);        // plane p: dB ring slot (p + 1) % RB, A ring slot p & 1
-  own = slot[0].A;
+  own = mp.aligned(slot[0].A);
   issue(PD, slot[0]);
   dummy_stores();
 
@@ -333,7 +408,7 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
       const int qs[3] = {d % RB, (d + 1) % RB, (d + 2) % RB};   // dB ring slots of planes t-1, t, t+1
       const int sl = (d + 1) % PD;
       stage(slot[sl], qs[2], (d + 1) & 1, t + 1 < g.T);
-      const Raw own_next = slot[sl].A;
+      const Raw own_next = mp.aligned(slot[sl].A);
       issue(t + 1 + PD, slot[sl]);
       // ---- data gradient of plane t
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -360,7 +435,7 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
           Cw[kt * 3 + 0] = MxOp<T>::mfma(m, n0, Cw[kt * 3 + 0]);
           Cw[kt * 3 + 1] = MxOp<T>::mfma(m, n1, Cw[kt * 3 + 1]);
           Cw[kt * 3 + 2] = MxOp<T>::mfma(m, n2, Cw[kt * 3 + 2]);
-        }
+          }
       }
       // ---- emit dA[t]: ReLU mask of BN_a, the BN_a backward sums of the stored gradient
       acc += acc2;
@@ -368,15 +443,11 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const float av = raw_get<T>(own, e);                       // (rows / columns outside the image load zeros: the
-        o4[e] = (__builtin_fmaf(sc, av, sh) > 0.f && (e < 2 ? mk0 : mk1)) ? acc[e] : 0.f;   //  lane masks close them)
+        o4[e] = (__builtin_fmaf(sc, av, sh) > 0.f && ((e < 2 ? mk0 : mk1) >> (16 * (e & 1)) & 1u)) ? acc[e] : 0.f;   //  lane masks close them)
         s1 += o4[e];
         s2 += o4[e] * av;
       }
-      Raw o, o1;
-      o.w[0] = Dot2<T>::pk(o4[0], o4[1]);
-      o1.w[0] = Dot2<T>::pk(o4[2], o4[3]);
-      raw_bstore<4>(o, rsG, voff, t * planeB);
-      raw_bstore<4>(o1, rsG, voff1, t * planeB);
+      mp.store(rsG, Dot2<T>::pk(o4[0], o4[1]), Dot2<T>::pk(o4[2], o4[3]), t * planeB);
       own = own_next;
     }
   }
@@ -412,21 +483,27 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
 bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
   const char* e = getenv("X3D_DW_MX");
+  bool p7;
   // fp16: the forward only (dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back)
-  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || g.H != 14 || g.W != 14) return false;
+  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || !mx_plane_ok(g, &p7)) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 3) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 3) || ((uintptr_t)a.braw & 3)) return false;
   const bool exact = g.T % 4 == 0;
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mx14_kernel<bf16, %s>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mx14_kernel<bf16, %s, %d>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0", (int)p7);
     return true;
   }
   DwMxBwdArgs pa;
   pa.b = a;
   pa.bytes = (unsigned)bytes;
-  const dim3 grid((unsigned)(g.C * g.N));
-  if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
-  else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  const dim3 grid((unsigned)(g.C * (p7 ? ceil_div(g.N, 4) : g.N)));
+  if (p7) {
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, true>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, true>), grid, dim3(64), 0, st, pa);
+  } else {
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, false>), grid, dim3(64), 0, st, pa);
+  }
   return true;
 }
