@@ -151,6 +151,7 @@ DW = [
     (2, 3, 13, 14, 14, 1),                                                #   exit-free loop (ring of 4), else ring of 3; T below the prefetch depth
     (5, 3, 4, 7, 7, 1), (2, 2, 8, 7, 7, 1), (4, 2, 16, 7, 7, 1),          #   7x7 planes four to a tile (partial last group), T % 4 == 0
     (2, 2, 4, 12, 14, 1), (1, 2, 5, 14, 12, 1),                           #   12 / 14 rows and columns
+    (2, 3, 5, 28, 28, 1), (1, 2, 4, 26, 30, 1), (2, 2, 8, 28, 26, 1),     #   H-tiled backward for rows of 26 .. 30 elements (dw3d_bwd_mxw_kernel)
     # ragged rows (flat staging, CV < 0): X3D-S 182-pixel test crops (91 / 46 / 23), vectors that cross rows and H-tiles,
     # rows shorter than a 16-byte vector (13 -> 7: 8-byte vectors), short planes
     (1, 2, 3, 91, 91, 1), (1, 2, 3, 91, 91, 2), (1, 2, 4, 46, 46, 1), (1, 2, 3, 23, 23, 1), (1, 2, 3, 23, 23, 2),

@@ -46,7 +46,7 @@ def main():
             res = {}
             for rnd in range(5):
                 for mode in ("0", "1"):
-                    os.environ["X3D_DW_MX"] = mode
+                    os.environ["X3D_DW_MX"] = mode; os.environ["X3D_DW_MXW"] = mode
                     stats = ops.stats_buffer(c, dev)
                     pool = torch.zeros((n, c), dtype=torch.float64, device=dev)
                     f = lambda: ops.dw3d_fwd(x, wt, 1, y=y, in_ss=ss, in_act=1, stats=stats, pool=pool)

@@ -375,7 +375,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   // 160-190 VGPRs and slower.  X3D_DW_PD_S2=1 / X3D_DW_PD=1 switch back to the one-plane-ahead kernel (A/B hooks).
   static const char* pd_s2 = getenv("X3D_DW_PD_S2");
   const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : (pd_s2 ? atoi(pd_s2) : 2));
-  if (dw_bwd_mx_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, bf16: both gradients on the matrix cores (dw_mx.hip)
+  if (dw_bwd_mx_launch(a, f->dtype, S, st) || dw_bwd_mxw_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, bf16: both gradients on the matrix cores (dw_mx.hip)
     if (x3d_describe.out) return X3D_OK;
     X3D_LAUNCH_CHECK("dw3d_bwd");
     return X3D_OK;

@@ -79,6 +79,7 @@ bool dw_fwd_pk_launch(const DwFwdArgs& a, int dtype, int S, int SW, hipStream_t 
 // matrix-core variant for 14x14 stride-1 planes in 16-bit storage (dw_mx.hip): the tap sums as Toeplitz products on MFMA
 bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st);
 bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);
+bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);   // rows of 18 .. 30 elements (28 x 28, 20 x 20), H-tiled
 
 // ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
 // resource's num_records) loads zeros / drops the store WITHOUT touching memory, so the instruction itself can be

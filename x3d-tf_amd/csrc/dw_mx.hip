@@ -486,6 +486,9 @@ bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   bool p7;
   // fp16: the forward only (dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back)
   if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || !mx_plane_ok(g, &p7)) return false;
+  // 7 x 7 planes: 64.3 -> 60.3 us per launch in isolation, but 66.8 -> 73.2 us inside the X3D-M step (operands in the infinity
+  // cache: the packed vector kernel gains more from that): the forward only, unless X3D_DW_MX=7
+  if (p7 && !(e && atoi(e) == 7)) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 3) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 3) || ((uintptr_t)a.braw & 3)) return false;
@@ -505,5 +508,259 @@ bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
     if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);
     else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, false>), grid, dim3(64), 0, st, pa);
   }
+  return true;
+}
+
+
+// ================================================================================================
+// FUSED BACKWARD, wider planes (stride 1, rows of 26 .. 30 elements: X3D-M stage 3 at 28 x 28), H-tiled.
+// One wave per (n, c, H-tile of 14 rows).  A whole image row fits ONE K = 32 window, so
+//   * the LDS images hold the tile's 16 window rows (image rows r0 - 1 .. r0 + 14: the rows r0 - 1 and r0 + 14 belong to the
+//     neighbour tiles, or are the zero pad), image column c at column c + 8 (eight zero columns left and right), one guard row
+//     above and below; lane (n = lane & 15, g = lane >> 4) loads the strips g and g + 4 of window row n and emits the same
+//     strips of the SAME row (outputs of the window rows 1 .. 14);
+//   * dA: column tile j (outputs 16 j .. 16 j + 15) takes the K window at image column 16 j - 8 -- 16-byte aligned in LDS --
+//     with ONE tap row per MFMA: A[w][k] = w'[kt][kh][k - w - 7] (w' the reversed kernel), the same nine operands for both
+//     tiles, B = the dB row n + kh - 1: 18 MFMAs per plane;
+//   * dW: C[m][n] = sum_k dB[m][k] * A[n][k + kw - 1] with K = the whole row: M-operand = dB row m for the tile's OWN rows
+//     (1 .. 14; the halo rows and rows below the image read a zero row: they are the neighbour tiles' terms), N-operand = A row
+//     n (all 16 window rows) in three column shifts; dW[kt][kh][kw] = the diagonal n = m + kh - 1.
+// ================================================================================================
+#define MXW_PITCH 112                       // 8 + 32 + 8 columns = 96 bytes of row + 16: conflict-free b128 rows
+#define MXW_TILE (MXW_PITCH * MX_ROWS)      // guard row | 16 window rows | guard row
+
+struct DwMxwBwdArgs {
+  DwBwdArgs b;
+  unsigned bytes;
+  int HT;            // H-tiles (of 14 rows) per plane
+};
+
+template <typename T, int UN, int RB, int PD, bool EXACT>
+__global__ __launch_bounds__(64, 2) void dw3d_bwd_mxw_kernel(const DwMxwBwdArgs pa) {
+  static_assert(UN % RB == 0 && UN % 2 == 0 && UN % PD == 0, "ring periods RB (dB planes), 2 (A planes) and PD (planes in flight)");
+  typedef typename MxOp<T>::x8 x8;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+  // dB ring (RB planes) | A ring (2 planes) | one zero row
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(RB + 2) * MXW_TILE + 128];
+  unsigned char* ldsA = lds + RB * MXW_TILE;
+  const DwBwdArgs& a = pa.b;
+  const DwGeom& g = a.g;
+  const int lane = threadIdx.x;
+  const int n16 = lane & 15, s = lane >> 4;
+  const int ht = __builtin_amdgcn_readfirstlane(blockIdx.x % pa.HT);
+  const int nc = __builtin_amdgcn_readfirstlane(blockIdx.x / pa.HT);
+  const int c = nc % g.C, n = nc / g.C;
+  const int H = g.H, W = g.W;
+  const int r0 = ht * 14;
+
+  for (int i = lane; i < ((RB + 2) * MXW_TILE + 128) / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // nine operands of the reversed kernel: A[w = lane & 15][k = 8 s + j] = w[2 - kt][2 - kh][2 - kw], kw = k - w - 7
+  x8 Wt[9];
+  {
+    const float* wc = a.w + c * 27;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int kt = i / 3, kh = i % 3;
+      const float* w3 = wc + (2 - kt) * 9 + (2 - kh) * 3;
+      const float w0 = w3[2], w1 = w3[1], w2 = w3[0];
+      x8 op;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int kw = 8 * s + j - n16 - 7;
+        op[j] = (T)(kw == 0 ? w0 : (kw == 1 ? w1 : (kw == 2 ? w2 : 0.f)));
+      }
+      Wt[i] = op;
+    }
+  }
+  const float sc = a.ss_a[c * 2], sh = a.ss_a[c * 2 + 1];
+  const float* cf = a.coef_nc + ((long long)n * g.C + c) * 4;
+  const float cA = cf[0], cB = cf[1], cC = cf[2];
+
+  const int planeB = H * W * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((T*)a.araw, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((T*)a.dv, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((T*)a.braw, 0, pa.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((T*)a.ga, 0, pa.bytes, 0x00020000);
+  const int row = r0 - 1 + n16;                                     // image row of window row n16
+  const bool row_in = row >= 0 && row < H;                          // loaded (else the zero pad)
+  const bool row_own = n16 >= 1 && n16 <= 14 && row < H;            // emitted by this tile
+  const long long base = ((long long)n * g.C + c) * g.T * H * W + (long long)row * W;
+  int vld[2], vs0[2], vs1[2];
+  unsigned mk0[2], mk1[2], eo0[2], eo1[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = 16 * j + 4 * s;
+    const bool c0 = col < W, c1 = col + 2 < W;
+    vld[j] = (row_in && c0) ? (int)((base + col) * 2) : DW_OOB;
+    mk0[j] = (row_in && c0) ? 0xffffffffu : 0u;
+    mk1[j] = (row_in && c1) ? 0xffffffffu : 0u;
+    eo0[j] = (row_own && c0) ? 1u : 0u;
+    eo1[j] = (row_own && c1) ? 1u : 0u;
+    vs0[j] = eo0[j] ? (int)((base + col) * 2) : DW_OOB;
+    vs1[j] = eo1[j] ? (int)((base + col + 2) * 2) : DW_OOB;
+  }
+  // window row n16 lives in LDS row n16 + 1; image column c at byte 16 + 2 c
+  unsigned char* stgB = lds + (n16 + 1) * MXW_PITCH + 16 + s * 8;            // (+ 32 j)
+  unsigned char* stgA = ldsA + (n16 + 1) * MXW_PITCH + 16 + s * 8;
+  const unsigned char* rdB = lds + n16 * MXW_PITCH + s * 16;                 // dA: row n16 + kh - 1 (+ kh * PITCH), K window (+ 32 j)
+  const unsigned char* rdM = row_own ? lds + (n16 + 1) * MXW_PITCH + 16 + s * 16 : lds + (RB + 2) * MXW_TILE;
+  const int rdM_tile = row_own ? MXW_TILE : 0;
+  const unsigned char* rdN = ldsA + (n16 + 1) * MXW_PITCH + 16 + s * 16;
+
+  struct Slot { Raw A[2], D[2], R[2]; };
+  Slot slot[PD];
+  auto issue = [&](int t, Slot& q) {
+    const int soff = t < g.T ? t * planeB : DW_OOB;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      raw_bload<8>(q.A[j], rsA, vld[j], soff);
+      raw_bload<8>(q.D[j], rsD, vld[j], soff);
+      raw_bload<8>(q.R[j], rsR, vld[j], soff);
+    }
+  };
+  auto stage = [&](const Slot& q, int qb, int qa, bool plane_ok) {
+    const unsigned pm = plane_ok ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        av[e] = fmaxf(__builtin_fmaf(sc, raw_get<T>(q.A[j], e), sh), 0.f);
+        bv[e] = __builtin_fmaf(cA, raw_get<T>(q.D[j], e), __builtin_fmaf(cB, raw_get<T>(q.R[j], e), cC));
+      }
+      const unsigned m0 = mk0[j] & pm, m1 = mk1[j] & pm;
+      *(uint2*)(stgA + qa * MXW_TILE + 32 * j) = make_uint2(Dot2<T>::pk(av[0], av[1]) & m0, Dot2<T>::pk(av[2], av[3]) & m1);
+      *(uint2*)(stgB + qb * MXW_TILE + 32 * j) = make_uint2(Dot2<T>::pk(bv[0], bv[1]) & m0, Dot2<T>::pk(bv[2], bv[3]) & m1);
+    }
+  };
+  auto store4 = [&](int j, unsigned p0, unsigned p1, int soff) {
+    Raw o, o1;
+    o.w[0] = p0; o1.w[0] = p1;
+    raw_bstore<4>(o, rsG, vs0[j], soff);
+    raw_bstore<4>(o1, rsG, vs1[j], soff);
+  };
+  auto dummy_stores = [&]() { store4(0, 0u, 0u, DW_OOB); store4(1, 0u, 0u, DW_OOB); };
+
+  f32x4 Cw[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Cw[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  Raw own[2];
+
+#pragma unroll
+  for (int p = 0; p < PD; p++) { issue(p, slot[p]); dummy_stores(); }
+  stage(slot[0], 1, 0, true);        // plane p: dB ring slot (p + 1) % RB, A ring slot p & 1
+  own[0] = slot[0].A[0]; own[1] = slot[0].A[1];
+  issue(PD, slot[0]);
+  dummy_stores();
+
+  for (int t0 = 0; t0 < g.T; t0 += UN) {
+#pragma unroll
+    for (int d = 0; d < UN; d++) {
+      const int t = t0 + d;
+      if (!EXACT && t >= g.T) break;
+      const int qs[3] = {d % RB, (d + 1) % RB, (d + 2) % RB};
+      const int sl = (d + 1) % PD;
+      stage(slot[sl], qs[2], (d + 1) & 1, t + 1 < g.T);
+      const Raw on0 = slot[sl].A[0], on1 = slot[sl].A[1];
+      issue(t + 1 + PD, slot[sl]);
+      // ---- weight gradient
+      {
+        const unsigned char* pn = rdN + (d & 1) * MXW_TILE;
+        const u32x4_ mid = *(const u32x4_*)pn;
+        const unsigned prv = *(const unsigned*)(pn - 4), nxt = *(const unsigned*)(pn + 16);
+        const unsigned m01 = __builtin_amdgcn_alignbit(mid[1], mid[0], 16), m12 = __builtin_amdgcn_alignbit(mid[2], mid[1], 16),
+                       m23 = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
+        const u32x4_ lft = {__builtin_amdgcn_alignbit(mid[0], prv, 16), m01, m12, m23};
+        const u32x4_ rgt = {m01, m12, m23, __builtin_amdgcn_alignbit(nxt, mid[3], 16)};
+        const x8 n0 = __builtin_bit_cast(x8, lft), n1 = __builtin_bit_cast(x8, mid), n2 = __builtin_bit_cast(x8, rgt);
+#pragma unroll
+        for (int kt = 0; kt < 3; kt++) {
+          const x8 m = *(const x8*)(rdM + qs[2 - kt] * rdM_tile);
+          Cw[kt * 3 + 0] = MxOp<T>::mfma(m, n0, Cw[kt * 3 + 0]);
+          Cw[kt * 3 + 1] = MxOp<T>::mfma(m, n1, Cw[kt * 3 + 1]);
+          Cw[kt * 3 + 2] = MxOp<T>::mfma(m, n2, Cw[kt * 3 + 2]);
+        }
+      }
+      // ---- data gradient of plane t, the two column tiles, and its emit
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 3; kt++) {
+          const unsigned char* pb = rdB + qs[kt] * MXW_TILE + 32 * j;
+          acc = MxOp<T>::mfma(Wt[kt * 3 + 0], *(const x8*)(pb), acc);
+          acc2 = MxOp<T>::mfma(Wt[kt * 3 + 1], *(const x8*)(pb + MXW_PITCH), acc2);
+          acc3 = MxOp<T>::mfma(Wt[kt * 3 + 2], *(const x8*)(pb + 2 * MXW_PITCH), acc3);
+        }
+        acc += acc2 + acc3;
+        float o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float av = raw_get<T>(own[j], e);
+          o4[e] = (__builtin_fmaf(sc, av, sh) > 0.f && (e < 2 ? eo0[j] : eo1[j])) ? acc[e] : 0.f;
+          s1 += o4[e];
+          s2 += o4[e] * av;
+        }
+        store4(j, Dot2<T>::pk(o4[0], o4[1]), Dot2<T>::pk(o4[2], o4[3]), t * planeB);
+      }
+      own[0] = on0; own[1] = on1;
+    }
+  }
+
+  // ---- dW[kt][kh][kw]: the diagonal n = m + kh - 1 of Cw[kt][kw] (n = lane & 15, m = 4 s + r)
+  float red[29];
+#pragma unroll
+  for (int kt = 0; kt < 3; kt++)
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+      float p[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int kh = n16 - (4 * s + r) + 1;
+        const float v = Cw[kt * 3 + kw][r];
+        p[0] += kh == 0 ? v : 0.f;
+        p[1] += kh == 1 ? v : 0.f;
+        p[2] += kh == 2 ? v : 0.f;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) red[kt * 9 + kh * 3 + kw] = wave_sum_lane63(p[kh]);
+    }
+  red[27] = wave_sum_lane63(s1);
+  red[28] = wave_sum_lane63(s2);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
+    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
+    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
+  }
+}
+
+// X3D_DW_MXW=0: never (A/B hook)
+bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
+  const DwGeom& g = a.g;
+  const char* e = getenv("X3D_DW_MXW");
+  // measured (108 ch x 64 clips of 16 x 28 x 28): 240 -> 226 us per launch, 235 -> 222 us inside the X3D-M step, at two waves
+  // per SIMD (188 VGPRs: nine weight operands + nine dW accumulators + two strips of three tensors in flight).  Rows of 20
+  // elements in tiles of 14 + 6 rows (X3D-XL stage 4) lose (341 -> 564 us): only planes that fill the tiles
+  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || (g.W & 1) || g.W < 26 || g.W > 30 || g.H < 12 ||
+      (g.H % 14 != 0 && g.H % 14 < 10)) return false;
+  const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
+  const int HT = ceil_div(g.H, 14);
+  if (bytes >= (1ll << 30) || (long long)g.C * g.N * HT >= (1ll << 31)) return false;
+  if (((uintptr_t)a.araw & 7) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 7) || ((uintptr_t)a.braw & 7)) return false;
+  const bool exact = g.T % 4 == 0;
+  if (x3d_describe.out) {
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mxw_kernel<bf16, %s>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
+    return true;
+  }
+  DwMxwBwdArgs pa;
+  pa.b = a;
+  pa.bytes = (unsigned)bytes;
+  pa.HT = HT;
+  const dim3 grid((unsigned)((long long)g.C * g.N * HT));
+  if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
+  else hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
   return true;
 }
