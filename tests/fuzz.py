@@ -12,13 +12,19 @@ CHANS = [24, 48, 54, 96, 108, 192, 216, 432, 40, 72, 200]
 
 
 def case_calls(rng: random.Random):
-    """One fuzz case = 7 kernel-test calls: [(test function name, positional args after `gpu`)]."""
+    """One fuzz case = 9 kernel-test calls: [(test function name, positional args after `gpu`)]."""
     dt = rng.choice(DTYPES)
     out = []
     shp = (rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 5, 8]), rng.choice(WIDTHS), rng.choice(WIDTHS),
            rng.choice([1, 2]))
     out.append(("test_dw3d_fwd", (dt, shp)))
     out.append(("test_dw3d_bwd", (dt, shp)))
+    # the planes the matrix-core depthwise kernels take (dw_mx.hip): 12 / 14 rows and columns, 7 x 7 four to a tile (any sample
+    # count), rows of 26 .. 30 elements in H-tiles of 14 rows; T around the prefetch depth and the exit-free loop (T % 4 == 0)
+    hm, wm = rng.choice([(14, 14), (12, 14), (14, 12), (12, 12), (7, 7), (7, 7), (28, 28), (26, 28), (28, 30), (14, 26), (24, 28)])
+    shm = (rng.choice([1, 2, 3, 4, 5, 6]), rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4, 5, 8, 9]), hm, wm, 1)
+    out.append(("test_dw3d_fwd", (dt, shm)))
+    out.append(("test_dw3d_bwd", (dt, shm)))
     t, h, w = rng.choice([1, 2, 3, 5, 13]), rng.choice([3, 5, 7, 8, 10, 12, 14]), rng.choice([3, 5, 7, 8, 10, 12, 14])
     cin, cout = rng.choice(CHANS), rng.choice(CHANS)
     n = rng.choice([1, 2])
@@ -49,5 +55,5 @@ def run_cases(gpu, cases: int, seed: int, log=None):
                 if log:
                     log(f"FAIL {name} {args}\n{traceback.format_exc(limit=2)}")
         if log and (i + 1) % 10 == 0:
-            log(f"{i + 1} cases ({7 * (i + 1)} kernel checks), {len(fails)} failures")
+            log(f"{i + 1} cases ({9 * (i + 1)} kernel checks), {len(fails)} failures")
     return fails
