@@ -204,6 +204,61 @@ __global__ __launch_bounds__(ELEM_BLOCK) void tail_bwd_kernel(T* __restrict__ dy
   }
 }
 
+// ... small planes (P / VEC < 256: the 7 x 7 stage): one workgroup takes NB samples of ONE channel -- with a workgroup per (n, c)
+// 98 of 256 threads had a vector and N workgroups per channel met in the fp64 atomics (192 ch x 64 clips of 16x7x7: 28 us for
+// 77 MB).  grid = (C, ceil(N / NB)); the flat index runs over (sample in the group, vector of the plane).
+template <typename T, int VEC>
+__global__ __launch_bounds__(ELEM_BLOCK) void tail_bwd_small_kernel(T* __restrict__ dyg, const T* __restrict__ y,
+                                                                   const T* __restrict__ craw, const T* __restrict__ rraw,
+                                                                   double* sums_c, double* sums_r, int N, int C, int P, int NB) {
+  __shared__ float scratch[3 * (ELEM_BLOCK / 64)];
+  const int c = blockIdx.x, n0 = blockIdx.y * NB;
+  const int nb = min(NB, N - n0);
+  const int vpp = P / VEC, total = nb * vpp;
+  float red[3] = {0.f, 0.f, 0.f};
+  for (int i0 = threadIdx.x; i0 < total; i0 += 2 * ELEM_BLOCK) {
+    // two vectors per thread and round, their loads issued together
+    float d[2][VEC], yy[2][VEC], cr[2][VEC], rr[2][VEC];
+    long long off[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int i = i0 + u * ELEM_BLOCK;
+      ok[u] = i < total;
+      const int nl = ok[u] ? i / vpp : 0, pv = ok[u] ? i - nl * vpp : 0;
+      off[u] = ((long long)(n0 + nl) * C + c) * P + (long long)pv * VEC;
+      if (ok[u]) {
+        VecIO<T, VEC>::load(dyg + off[u], d[u]);
+        VecIO<T, VEC>::load(y + off[u], yy[u]);
+        VecIO<T, VEC>::load(craw + off[u], cr[u]);
+        if (rraw) VecIO<T, VEC>::load(rraw + off[u], rr[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!ok[u]) continue;
+      float g[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        g[e] = yy[u][e] > 0.f ? d[u][e] : 0.f;
+        red[0] += g[e];
+        red[1] += g[e] * cr[u][e];
+        if (rraw) red[2] += g[e] * rr[u][e];
+      }
+      VecIO<T, VEC>::store(dyg + off[u], g);
+    }
+  }
+  block_sum<3>(red, scratch);
+  if (threadIdx.x == 0) {
+    atomic_add_d(&sums_c[c * 2], (double)red[0]);
+    atomic_add_d(&sums_c[c * 2 + 1], (double)red[1]);
+    if (rraw) {
+      atomic_add_d(&sums_r[c * 2], (double)red[0]);
+      atomic_add_d(&sums_r[c * 2 + 1], (double)red[2]);
+    }
+  }
+}
+
 // z = s*yraw + t ; g = (dy ? dy : dpool[n][c]/P) * [z > 0]; sums += (sum g, sum g*yraw)
 template <typename T, int VEC>
 __global__ __launch_bounds__(ELEM_BLOCK) void relu_bn_bwd_reduce_kernel(const T* __restrict__ dy,
@@ -337,6 +392,22 @@ extern "C" int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const 
   const int vec = norm_vec(dtype, pick_vec(eb, P, dy_g, y, c_raw, r_raw));
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = elem_grid(P, vec, N * C);
+  // small planes in 16-bit storage: NB samples of one channel per workgroup (X3D_TAIL_SMALL=0: A/B hook)
+  static const char* small_env = getenv("X3D_TAIL_SMALL");
+  if (dtype != X3D_F32 && vec == 8 && P / 8 < ELEM_BLOCK && !(small_env && atoi(small_env) == 0)) {
+    int nb = (int)(4 * ELEM_BLOCK / (P / 8));
+    if (nb > N) nb = N;
+    if (nb > 16) nb = 16;
+    const dim3 g2((unsigned)C, (unsigned)ceil_div(N, nb));
+    if (dtype == X3D_F16)
+      hipLaunchKernelGGL((tail_bwd_small_kernel<f16, 8>), g2, dim3(ELEM_BLOCK), 0, st, (f16*)dy_g, (const f16*)y, (const f16*)c_raw,
+                         (const f16*)r_raw, sums_c, sums_r, N, C, (int)P, nb);
+    else
+      hipLaunchKernelGGL((tail_bwd_small_kernel<bf16, 8>), g2, dim3(ELEM_BLOCK), 0, st, (bf16*)dy_g, (const bf16*)y, (const bf16*)c_raw,
+                         (const bf16*)r_raw, sums_c, sums_r, N, C, (int)P, nb);
+    X3D_LAUNCH_CHECK("tail_bwd");
+    return X3D_OK;
+  }
 #define ARGS(T) (T*)dy_g, (const T*)y, (const T*)c_raw, (const T*)r_raw, sums_c, sums_r, C, P
   if (dtype == X3D_F32) {
     if (vec == 4) hipLaunchKernelGGL((tail_bwd_kernel<float, 4>), grid, dim3(ELEM_BLOCK), 0, st, ARGS(float));
