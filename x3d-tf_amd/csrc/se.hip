@@ -18,20 +18,46 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const double* __restrict__ 
   for (int c = tid; c < C; c += 256)
     pooled[c] = ssb[c * 2] * (float)(pool_sums[(long long)n * C + c] / P) + ssb[c * 2 + 1];
   __syncthreads();
-  for (int j = wid; j < Wd; j += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += w1[j * C + c] * pooled[c];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float h = fmaxf(acc + b1[j], 0.f);
-      hid[j] = h;
-      hidden[(long long)n * Wd + j] = h;
+  // (loops with a run-time trip count are not unrolled: every load waited for the previous one -- 32 L2 latencies per thread in
+  //  the fc2 loop were most of the 28 us this kernel took on the 432-channel layers; batches of 8 loads in flight)
+  // fc1: a wave takes the rows j = wid, wid + 4, ... EIGHT at a time (one row after the other every row's loads waited for the
+  // previous row's reduction: 8 x ~1.5 us on the 432-channel layers)
+  for (int j0 = wid; j0 < Wd; j0 += 32) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc[u] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float pv = pooled[c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + 4 * u;
+        acc[u] += (j < Wd ? w1[j * C + c] : 0.f) * pv;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + 4 * u;
+      const float t = wave_sum(acc[u]);
+      if (lane == 0 && j < Wd) {
+        const float h = fmaxf(t + b1[j], 0.f);
+        hid[j] = h;
+        hidden[(long long)n * Wd + j] = h;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float acc = b2[c];
-    for (int j = 0; j < Wd; j++) acc += w2[c * Wd + j] * hid[j];
+    const float* wr = w2 + c * Wd;
+    int j = 0;
+    for (; j + 8 <= Wd; j += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) wv[u] = wr[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += wv[u] * hid[j + u];
+    }
+    for (; j < Wd; j++) acc += wr[j] * hid[j];
     gate[(long long)n * C + c] = sigmoidf_(acc);
   }
 }
@@ -68,20 +94,41 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a
     dz2_out[i] = d;
   }
   __syncthreads();
-  for (int j = wid; j < Wd; j += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += a.w2[c * Wd + j] * dz2[c];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float d = a.hidden[(long long)n * Wd + j] > 0.f ? acc : 0.f;
-      dz1[j] = d;
-      dz1_out[(long long)n * Wd + j] = d;
+  for (int j0 = wid; j0 < Wd; j0 += 32) {      // eight rows of fc2^T at a time (see se_fwd_kernel)
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc[u] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float dv = dz2[c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + 4 * u;
+        acc[u] += (j < Wd ? a.w2[c * Wd + j] : 0.f) * dv;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + 4 * u;
+      const float t = wave_sum(acc[u]);
+      if (lane == 0 && j < Wd) {
+        const float d = a.hidden[(long long)n * Wd + j] > 0.f ? t : 0.f;
+        dz1[j] = d;
+        dz1_out[(long long)n * Wd + j] = d;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dp = 0.f;
-    for (int j = 0; j < Wd; j++) dp += a.w1[j * C + c] * dz1[j];
+    int j = 0;
+    for (; j + 8 <= Wd; j += 8) {     // eight loads in flight (see se_fwd_kernel)
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) wv[u] = a.w1[(j + u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) dp += wv[u] * dz1[j + u];
+    }
+    for (; j < Wd; j++) dp += a.w1[j * C + c] * dz1[j];
     a.scratch[(long long)n * C + c] = dp;  // d loss / d pooled[n][c]
   }
 }
@@ -91,53 +138,60 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a
 //   dw2[c][j] += sum_n dz2[n][c]*hidden[n][j]    db2[c] += sum_n dz2[n][c]
 //   dw1[j][c] += sum_n dz1[n][j]*pooled[n][c]    db1[j]  += sum_n dz1[n][j]   (workgroup 0)
 // Each gradient element has exactly one writer, so the += are plain read-modify-writes.
-__global__ __launch_bounds__(64) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+// With SE the workgroup has FOUR waves: wave 0 does the BatchNorm part, and all four split the sequential pass over the samples
+// of the SE weight gradients (64 dependent rounds of loads in one wave were ~12 of the kernel's ~16 us on the 432-channel layers)
+__global__ __launch_bounds__(256) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
+  __shared__ float part[4][3][64];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int C = a.C, N = a.N;
-  double sdu = 0.0, sdub = 0.0;
-  for (int n = lane; n < N; n += 64) {
-    const long long i = (long long)n * C + c;
-    const double g = has_se ? (double)a.gate[i] : 1.0;
-    const double dp = has_se ? (double)a.scratch[i] : 0.0;
-    sdu += g * a.nc_sums[i * 2] + dp;
-    sdub += g * a.nc_sums[i * 2 + 1] + (has_se ? dp / a.P * a.pool_sums[i] : 0.0);
-  }
-  sdu = wave_sum_d(sdu);
-  sdub = wave_sum_d(sdub);
-  const double count = (double)N * a.P;
-  const double mean = a.b_mean_invstd[c * 2], invstd = a.b_mean_invstd[c * 2 + 1];
-  const double dga = (sdub - mean * sdu) * invstd;
-  const double k1 = (double)a.gamma_b[c] * invstd;
-  const double B = -k1 * invstd * dga / count;
-  const double Cc = -k1 * sdu / count - B * mean;
-  if (lane == 0) {
-    a.dgamma_b[c] += (float)dga;
-    a.dbeta_b[c] += (float)sdu;
-  }
-  for (int n = lane; n < N; n += 64) {
-    const long long i = (long long)n * C + c;
-    const double g = has_se ? (double)a.gate[i] : 1.0;
-    const double dp = has_se ? (double)a.scratch[i] : 0.0;
-    float* o = a.coef_nc + i * 4;
-    o[0] = (float)(k1 * g);
-    o[1] = (float)B;
-    o[2] = (float)(Cc + k1 * dp / a.P);
-    o[3] = 0.f;
+  if (wid == 0) {
+    double sdu = 0.0, sdub = 0.0;
+    for (int n = lane; n < N; n += 64) {
+      const long long i = (long long)n * C + c;
+      const double g = has_se ? (double)a.gate[i] : 1.0;
+      const double dp = has_se ? (double)a.scratch[i] : 0.0;
+      sdu += g * a.nc_sums[i * 2] + dp;
+      sdub += g * a.nc_sums[i * 2 + 1] + (has_se ? dp / a.P * a.pool_sums[i] : 0.0);
+    }
+    sdu = wave_sum_d(sdu);
+    sdub = wave_sum_d(sdub);
+    const double count = (double)N * a.P;
+    const double mean = a.b_mean_invstd[c * 2], invstd = a.b_mean_invstd[c * 2 + 1];
+    const double dga = (sdub - mean * sdu) * invstd;
+    const double k1 = (double)a.gamma_b[c] * invstd;
+    const double B = -k1 * invstd * dga / count;
+    const double Cc = -k1 * sdu / count - B * mean;
+    if (lane == 0) {
+      a.dgamma_b[c] += (float)dga;
+      a.dbeta_b[c] += (float)sdu;
+    }
+    for (int n = lane; n < N; n += 64) {
+      const long long i = (long long)n * C + c;
+      const double g = has_se ? (double)a.gate[i] : 1.0;
+      const double dp = has_se ? (double)a.scratch[i] : 0.0;
+      float* o = a.coef_nc + i * 4;
+      o[0] = (float)(k1 * g);
+      o[1] = (float)B;
+      o[2] = (float)(Cc + k1 * dp / a.P);
+      o[3] = 0.f;
+    }
   }
   if (!has_se) return;
   const int Wd = a.Wd;
   const float* dz2 = a.scratch + (long long)N * C;
   const float* dz1 = a.scratch + 2ll * N * C;
   const float sb = a.b_scale_shift[c * 2], tb = a.b_scale_shift[c * 2 + 1];
-  float sb2 = 0.f;
-  for (int n = lane; n < N; n += 64) sb2 += dz2[(long long)n * C + c];
-  sb2 = wave_sum(sb2);
-  if (lane == 0) a.db2[c] += sb2;
-  // lanes = hidden units: a sequential pass over the samples, no cross-lane traffic
+  if (wid == 0) {
+    float sb2 = 0.f;
+    for (int n = lane; n < N; n += 64) sb2 += dz2[(long long)n * C + c];
+    sb2 = wave_sum(sb2);
+    if (lane == 0) a.db2[c] += sb2;
+  }
+  // lanes = hidden units; the four waves take the samples n = wid, wid + 4, ... -- no cross-lane traffic, partial sums meet in LDS
+  float s2 = 0.f, s1 = 0.f, sj = 0.f;
   if (lane < Wd) {
-    float s2 = 0.f, s1 = 0.f, sj = 0.f;
-#pragma unroll 8
-    for (int n = 0; n < N; n++) {
+#pragma unroll 4
+    for (int n = wid; n < N; n += 4) {
       const long long i = (long long)n * C + c;
       const float d2 = dz2[i];
       const float pooled = sb * (float)(a.pool_sums[i] / a.P) + tb;
@@ -146,9 +200,17 @@ __global__ __launch_bounds__(64) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a
       s1 += d1 * pooled;
       sj += d1;
     }
-    a.dw2[c * Wd + lane] += s2;
-    a.dw1[lane * C + c] += s1;
-    if (c == 0) a.db1[lane] += sj;
+  }
+  part[wid][0][lane] = s2; part[wid][1][lane] = s1; part[wid][2][lane] = sj;
+  __syncthreads();
+  if (wid == 0 && lane < Wd) {
+    // (the four partial sums are added in a fixed order: the result does not depend on the waves' timing)
+    const float t2 = (part[0][0][lane] + part[1][0][lane]) + (part[2][0][lane] + part[3][0][lane]);
+    const float t1 = (part[0][1][lane] + part[1][1][lane]) + (part[2][1][lane] + part[3][1][lane]);
+    const float tj = (part[0][2][lane] + part[1][2][lane]) + (part[2][2][lane] + part[3][2][lane]);
+    a.dw2[c * Wd + lane] += t2;
+    a.dw1[lane * C + c] += t1;
+    if (c == 0) a.db1[lane] += tj;
   }
 }
 
@@ -165,7 +227,7 @@ extern "C" int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(se_bwd_kernel, dim3(a->N), dim3(256), 0, st, *a);
     X3D_LAUNCH_CHECK("se_bwd");
   }
-  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(a->C), dim3(64), 0, st, *a, has_se);
+  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(a->C), dim3(has_se ? 256 : 64), 0, st, *a, has_se);
   X3D_LAUNCH_CHECK("bnb_bwd");
   return X3D_OK;
 }
