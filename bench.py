@@ -6,7 +6,8 @@ RCCL).  W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + syn
 max over ranks; rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[2], the one `metric` is quoted on): X3D-M, clips of 16x224x224, batch
-64 per GPU, bf16 activation storage with fp32 arithmetic, synthetic N(0,1) clips (NTHWC at the module
+64 per GPU, bf16 activation storage (fp32 accumulation; matrix-core operands -- the pointwise convs and the depthwise
+planes dw_mx.hip covers -- rounded to bf16), synthetic N(0,1) clips (NTHWC at the module
 boundary, already resident in HBM), random-init weights; weak scaling (per-GPU batch fixed).
 
 Extra objects on the JSON line:
@@ -132,6 +133,8 @@ def mfma_utilisation(model, pl, trainer, clips, labels, lr, steps=3):
         for i, item in enumerate(lst):
             if item is None or item[0] not in PW_ENTRIES:
                 continue
+            if (id(lst), i) in pl.side_entries:   # forked onto the side stream (X3D_SIDE_WGRAD=1): events on this stream
+                continue                          # would bracket nothing and count the FLOPs against ~zero time
             st = pl.structs[(id(lst), i)]
             s_ = getattr(st, "stride", 1) or 1
             ho, wo = -(-st.H // s_), -(-st.W // s_)
@@ -267,6 +270,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         pl = trainer.step(clips, labels, lr)
     torch.cuda.synchronize()
+    trainer.reducer.exposed_ms()      # (drop the warm-up steps' measurements)
     timer = KernelTimer(model, pl, 2 if dtype == torch.bfloat16 else 4)
     timer.wrap(pl)
     timer.enabled = True
@@ -279,7 +283,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = xdist.max_over_ranks(elapsed, device)
+    per_rank = xdist.gather_over_ranks(elapsed, device)      # every rank's own clock around the same K steps
+    elapsed = max(per_rank)
     loss = float(trainer.loss(pl).item())
     mfma = mfma_utilisation(model, pl, trainer, clips, labels, lr) if (world == 1 and rank == 0) else None
 
@@ -303,10 +308,15 @@ def main():
         out = {
             "metric": "clips/sec (fwd+bwd) X3D-%s %dx%d^2; depthwise HBM GB/s" % (args.variant, t, s),
             "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            # each rank's own wall clock over the K steps (the barriers around the region equalise them unless a rank is slow
+            # OUTSIDE the collectives): a scaling loss with min ~ max is exchange / launch overhead, min << max a slow rank
+            "ms_per_step_ranks": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,
+                                  "all": [round(1e3 * v / args.steps, 4) for v in per_rank]},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"X3D-{args.variant} train step (fwd + bwd + Nesterov SGD), clips {t}x{s}x{s}x3, "
-                                   f"{args.dtype} activation storage / fp32 arithmetic, random-init weights",
+                                   f"{args.dtype} activation storage / fp32 accumulation (matrix-core operands in {args.dtype}), random-init weights",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": loss,
             "collectives": trainer.collective_stats(),

@@ -121,6 +121,29 @@ class _RoundBwd(torch.autograd.Function):
         return g.to(ctx.dt).to(g.dtype), None
 
 
+class _DwOperands(torch.autograd.Function):
+    """depthwise3x3x3 whose forward and backward products each see their operands rounded to `dt_f` / `dt_b` (None: fp32)."""
+
+    @staticmethod
+    def forward(ctx, a, w, stride, dt_f, dt_b):
+        ctx.save_for_backward(a, w)
+        ctx.stride, ctx.dt_b = stride, dt_b
+        r = (lambda v: v.to(dt_f).to(v.dtype)) if dt_f is not None else (lambda v: v)
+        return depthwise3x3x3(r(a), r(w), stride)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        dt = ctx.dt_b
+        r = (lambda v: v.to(dt).to(v.dtype)) if dt is not None else (lambda v: v)
+        with torch.enable_grad():
+            a_ = r(a.detach()).requires_grad_(True)
+            w_ = r(w.detach()).requires_grad_(True)
+            y = depthwise3x3x3(a_, w_, ctx.stride)
+            da, dw = torch.autograd.grad(y, [a_, w_], r(g))
+        return da, dw, None, None, None
+
+
 class Storage:
     """Emulates a reduced-precision HBM storage type on top of the fp32 graph.
 
@@ -133,14 +156,26 @@ class Storage:
     1e-7 -> 7e-5 gradient error), so bf16 parity can only be stated against this storage-faithful variant.
     """
 
-    def __init__(self, dtype=None):
+    def __init__(self, dtype=None, dw_operands=None):
         self.dtype = None if dtype in (None, torch.float32) else dtype
+        # site (block prefix) -> (forward on the matrix cores?, backward on the matrix cores?): the depthwise kernels of
+        # dw_mx.hip multiply operands ROUNDED to the storage type (relu(bn_a(a)), dB, the 27 weights), the vector kernels
+        # multiply in fp32 -- and the two directions of one layer may run different kernels.  Tests fill this from the
+        # library's own dispatch (x3d_dw3d_kernel_name); empty = fp32 operands everywhere.
+        self.dw_operands = dw_operands or {}
 
     def act(self, x):
         return x if self.dtype is None else _RoundFwd.apply(x, self.dtype)
 
     def grad(self, x):
         return x if self.dtype is None else _RoundBwd.apply(x, self.dtype)
+
+    def depthwise(self, a_act, w, stride, site):
+        """the 3x3x3 channelwise conv with the operand rounding of the kernels that run it on the device"""
+        fwd_mx, bwd_mx = self.dw_operands.get(site, (False, False))
+        if self.dtype is None or not (fwd_mx or bwd_mx):
+            return depthwise3x3x3(a_act, w, stride)
+        return _DwOperands.apply(a_act, w, stride, self.dtype if fwd_mx else None, self.dtype if bwd_mx else None)
 
 
 _FP32 = Storage(None)
@@ -171,7 +206,7 @@ def res_block(x, p, b, arch, training, state, taps=None, masks=None, st=_FP32):
     a = st.act(pointwise(x, p[f"{q}/a/kernel"]))
     # st.grad: the device stores ga = d loss / d bn_a(a) (ReLU mask already applied)
     a_act = _relu(st.grad(batch_norm(a, p, f"{q}/bn_a", training, eps, mom, state)), f"{pre}/a", masks)
-    bb = st.act(depthwise3x3x3(a_act, p[f"{q}/b/kernel"], b.stride))
+    bb = st.act(st.depthwise(a_act, p[f"{q}/b/kernel"], b.stride, pre))
     u = batch_norm(bb, p, f"{q}/bn_b", training, eps, mom, state)
     if b.has_se:
         # SE (model.py:274-290,311-315): global mean -> fc1(+bias, ReLU) -> fc2(+bias, sigmoid) -> scale,

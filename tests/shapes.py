@@ -171,6 +171,8 @@ MODEL_TRAIN_HALF = [     # teacher-forced block by block, bf16 and fp16 storage
     ("XL", 2, 4, 64),     # XL widths (72/162/306/630...: off the 32-grid, K > 432), 55 blocks, SE parity across stages
     ("L", 1, 2, 312),     # BASELINE config 4's real planes: 156 / 78 / 39 / 20 / 10 (odd 39 -> 20)
     ("S", 1, 13, 91),     # 13 frames on half a 182-pixel test crop: ragged planes (46 / 23 / 12 / 6 / 3) and rows of P % 8 != 0 points at every stage
+    ("M", 1, 4, 224),     # BASELINE config 3's own planes (112 / 56 / 28 / 14 / 7) with T % 4 == 0: the exact dw_mx variants, the
+                          #   stage-2/3 forward tail fold on real rows, the stem fold at 112^2 -- what bench.py times
 ]
 MODEL_INFER = [           # variant, views, crops, T, S, dtype
     ("XS", 10, 1, 4, 160, F32), ("S", 2, 1, 13, 96, F32),

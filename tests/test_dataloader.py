@@ -159,16 +159,24 @@ def test_rank_shards_are_disjoint_and_cover_the_dataset(tmp_path):
     for k in range(0, 14, 4):
         DL.write_tfrecords(str(tmp_path / f"part-{k // 4}.tfrecord"), recs[k:k + 4])
     pattern = str(tmp_path / "part-*.tfrecord")
+    one = list(DL.InputReader(cfg, False, True, device="cpu", rank=0, world=1)._records(pattern, 8))
+    assert sorted(one) == sorted(recs)
     for training in (False, True):
         shards = []
         for r in range(2):
             rd = DL.InputReader(cfg, training, True, device="cpu", seed=9, rank=r, world=2)
             assert rd.local_batch(8) == 4 and rd.local_batch(None) is None
             shards.append(list(rd._records(pattern, rd.local_batch(8))))
-        assert not set(shards[0]) & set(shards[1])
-        assert sorted(shards[0] + shards[1]) == sorted(recs) and abs(len(shards[0]) - len(shards[1])) <= 1
-    one = list(DL.InputReader(cfg, False, True, device="cpu", rank=0, world=1)._records(pattern, 8))
-    assert sorted(one) == sorted(recs)
+        assert not set(shards[0]) & set(shards[1]) and len(shards[0]) == len(shards[1])     # equal shards: no rank runs ahead
+        if training:    # complete groups of `world` records: all 14 here (15 would drop one per pass)
+            assert sorted(shards[0] + shards[1]) == sorted(recs)
+        else:           # evaluation: rank r's quarter-batches of each COMPLETE global batch of 8; the partial one (6) is dropped
+            assert shards[0] == one[0:4] and shards[1] == one[4:8]
+    # an odd record count in training: the pass's last record is dropped on both ranks (equal shards), every pass
+    DL.write_tfrecords(str(tmp_path / "part-9.tfrecord"), [b"\xff" * 40])
+    odd = [list(DL.InputReader(cfg, True, True, device="cpu", seed=9, rank=r, world=2)._records(pattern, 4)) for r in range(2)]
+    assert len(odd[0]) == len(odd[1]) == 7 and not set(odd[0]) & set(odd[1])
+    os.remove(str(tmp_path / "part-9.tfrecord"))
     with pytest.raises(ValueError):
         DL.InputReader(cfg, True, True, device="cpu", rank=0, world=3).local_batch(8)
     with pytest.raises(ValueError):
@@ -177,7 +185,72 @@ def test_rank_shards_are_disjoint_and_cover_the_dataset(tmp_path):
     (tmp_path / "list.txt").write_text("".join(f"v{i}.mp4 {i}\n" for i in range(7)))
     a = list(DL.InputReader(cfg, False, False, device="cpu", rank=0, world=2)._records(str(tmp_path / "list.txt"), None))
     b = list(DL.InputReader(cfg, False, False, device="cpu", rank=1, world=2)._records(str(tmp_path / "list.txt"), None))
-    assert a == [f"v{i}.mp4 {i}" for i in (0, 2, 4, 6)] and b == [f"v{i}.mp4 {i}" for i in (1, 3, 5)]
+    assert a == [f"v{i}.mp4 {i}" for i in (0, 2, 4)] and b == [f"v{i}.mp4 {i}" for i in (1, 3, 5)]     # (v6: incomplete group)
+    # training: the WHOLE list is re-permuted every pass by the rank-independent generator before the split, so a rank's
+    # shard changes from pass to pass (reference: .shuffle(DATASET_SIZE) of the one dataset, then the replica split)
+    ra = DL.InputReader(cfg, True, False, device="cpu", seed=4, rank=0, world=2)
+    rb = DL.InputReader(cfg, True, False, device="cpu", seed=4, rank=1, world=2)
+    passes = [(list(ra._records(str(tmp_path / "list.txt"), 2)), list(rb._records(str(tmp_path / "list.txt"), 2))) for _ in range(4)]
+    for pa, pb in passes:
+        assert len(pa) == len(pb) == 3 and not set(pa) & set(pb)
+    assert len({tuple(sorted(pa)) for pa, _ in passes}) > 1
+
+
+def _eval_rank(rank, world, port, pattern, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import x3d_tf_amd as x
+    from x3d_tf_amd.evaluate import evaluate_dataset
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = x.get_config("XS")
+    res = evaluate_dataset(_FakeModel(), cfg, _fake_batches(DL.InputReader(cfg, False, True, device="cpu"), pattern, 4))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _FakeModel:
+    """probabilities that depend on the record only (evaluate_dataset's arithmetic and exchange are under test, not X3D)"""
+    table = torch.softmax(torch.randn(64, 10, generator=torch.Generator().manual_seed(3)) * 3, 1)
+
+    def __call__(self, clips, training=False):
+        return self.table[clips.view(-1).long()]
+
+
+def _fake_batches(rd, pattern, global_batch):
+    """(record ids, labels) batches from the reader's own record stream and batch arithmetic (the GPU view kernels are not
+    available on the CPU: the record's first byte stands for the clip)"""
+    b = rd.local_batch(global_batch)
+    recs = [r[0] for r in rd._records(pattern, b)]
+    for k in range(0, len(recs) - b + 1, b):        # drop_remainder
+        ids = torch.tensor(recs[k:k + b])
+        yield ids.view(-1, 1), ids % 10
+
+
+def test_two_rank_evaluation_reports_the_single_process_metric(tmp_path):
+    """under torchrun every rank evaluated 1/world of the videos and reported a metric over its shard only.
+    evaluate_dataset sums the counters over the ranks: both ranks of a gloo world-2 run return what one process computes
+    over the whole stream -- the same videos, the same trailing partial batch dropped (reference eval.py:83-89 under
+    MirroredStrategy reports ONE global metric)."""
+    import torch.multiprocessing as mp
+    import x3d_tf_amd as x
+    from x3d_tf_amd.evaluate import evaluate_dataset
+    from tests.test_dist import _free_port
+    recs = [bytes([i]) * (3 + i) for i in range(15)]          # 15 videos, global batch 4: three batches, 3 videos dropped
+    for k in range(0, 15, 4):
+        DL.write_tfrecords(str(tmp_path / f"part-{k // 4}.tfrecord"), recs[k:k + 4])
+    pattern = str(tmp_path / "part-*.tfrecord")
+    cfg = x.get_config("XS")
+    want = evaluate_dataset(_FakeModel(), cfg, _fake_batches(DL.InputReader(cfg, False, True, device="cpu", rank=0, world=1), pattern, 4))
+    assert want["videos"] == 12
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_eval_rank, args=(2, _free_port(), pattern, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["videos"] == 12
+    for k in ("loss", "acc", "top_5_acc"):
+        assert abs(got[k] - want[k]) < 1e-12, (k, got[k], want[k])
 
 
 # ---- the pipeline end to end on the GPU ------------------------------------------------------------

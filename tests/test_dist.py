@@ -69,14 +69,20 @@ def _worker(rank, world, port, out):
     groups = _flat_layout(arch, params)
     buckets = [torch.cat([res["grads"][k].reshape(-1) for k in g]) / world for g in groups]
     red = xd.BucketReducer(buckets)
+    assert red.exposed_ms() is None        # nothing measured yet
     for i in range(len(buckets)):          # launched in the order the backward pass finishes them
         red.launch(i)
+    red.mark_backward_done()
     red.finish()
+    exposed = red.exposed_ms()             # bench.py's collectives.exposed_ms (host clock on gloo)
+    assert exposed is not None and exposed >= 0.0 and red.exposed_ms() is None     # (read once: the average resets)
+    per_rank = xd.gather_over_ranks(float(10 * (rank + 1)), device="cpu")
+    assert per_rank == [10.0, 20.0]
     moving = torch.cat([v.reshape(-1) for k, v in sorted(res["state"].new_moving.items())])
     xd.mean_(moving)
     t = xd.max_over_ranks(float(rank + 1), device="cpu")
     if rank == 0:
-        torch.save(dict(buckets=buckets, moving=moving, tmax=t, w0=params["fc2/bias"].clone()), out)
+        torch.save(dict(buckets=buckets, moving=moving, tmax=t, w0=params["fc2/bias"].clone(), exposed=exposed), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,6 +108,7 @@ def test_two_replicas_match_per_shard_average(tmp_path):
     mref = sum(torch.cat([v.reshape(-1) for k, v in sorted(r["state"].new_moving.items())]) for r in per) / 2
     assert torch.allclose(got["moving"], mref, rtol=1e-6, atol=1e-7)
     assert got["tmax"] == 2.0
+    assert got["exposed"] >= 0.0
     assert torch.equal(got["w0"], params["fc2/bias"])          # broadcast restored rank 0's values
     # per-replica BN: the average of shard gradients is NOT the gradient of the concatenated batch
     whole = O.train_step({k: v.clone() for k, v in params.items()}, clips, labels, arch, lr=None, dropout_mask=mask,
@@ -154,6 +161,8 @@ def _gpu_worker(rank, world, port, outdir):
     tr.reducer.launch = lambda i: (hooks.append(i), orig(i))[1]
     tr.step(clips[lo:hi].to(dev), labels[lo:hi].to(dev), lr=0.05)
     torch.cuda.synchronize()
+    cs = tr.collective_stats()
+    assert cs["exposed_ms"] is not None and cs["exposed_ms"] >= 0.0 and cs["exposed_clock"] == "host"
     torch.save(dict(grads=m.flat_grads.cpu(), params=m.flat_params.cpu(), hooks=hooks), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

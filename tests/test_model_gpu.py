@@ -182,7 +182,8 @@ def test_train_matches_committed_golden_vector(gpu):
 @pytest.mark.parametrize("dtype", S.HALF_DTYPES)
 @pytest.mark.parametrize("name,n,t,s", S.MODEL_TRAIN_HALF)
 def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
-    """bf16 activation storage (fp32 arithmetic), checked with TEACHER FORCING: every residual block of the
+    """16-bit activation storage (fp32 accumulation; the operands of the matrix-core products -- pointwise convs, and the
+    depthwise planes dw_mx.hip covers -- rounded to the storage type), checked with TEACHER FORCING: every residual block of the
     device run is replayed on the oracle from the device's own stored block input (forward) and the device's
     own stored upstream gradient (backward), with the oracle rounding to bf16 at the tensors the device
     stores (oracle Storage).  End-to-end comparison is meaningless in bf16: a random-init BN network amplifies
@@ -205,7 +206,11 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     torch.cuda.synchronize()
     assert torch.isfinite(pl.loss_rows).all() and torch.isfinite(m.flat_grads).all()
     masks = hip_relu_masks(pl)
-    st = O.Storage(dtype)
+    # which depthwise launches run on the matrix cores (operands rounded to the storage type): the library's own dispatch
+    from x3d_tf_amd import hip as _hip
+    dw_ops = {O.block_prefix(B.spec): ("_mx" in _hip.dw3d_kernel_name(B.sb), "_mx" in _hip.dw3d_kernel_name(B.db))
+              for B in pl.blocks}
+    st = O.Storage(dtype, dw_operands=dw_ops)
     # replay the backward block by block, capturing each block's upstream gradient before it is overwritten
     m.flat_grads.zero_()
     pl.zero_buf.zero_()
@@ -255,7 +260,7 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
             e = num / (den + 1e-30)
             worst["dw"] = max(worst["dw"], e)
             errs[k] = e
-    print("bf16 teacher-forced worst:", worst, sorted(errs.items(), key=lambda kv: -kv[1])[:4], "tail folded in", folded, "blocks")
+    print("teacher-forced worst:", name, n, t, s, dtype, "mx (fwd, bwd) blocks:", sum(v[0] for v in dw_ops.values()), sum(v[1] for v in dw_ops.values()), worst, sorted(errs.items(), key=lambda kv: -kv[1])[:4], "tail folded in", folded, "blocks")
     lim, med = (6e-2, 1.5e-2) if dtype == torch.bfloat16 else (1e-2, 2.5e-3)
     bad = {k: e for k, e in errs.items() if e > lim}
     assert not bad, f"relative L2 error beyond {lim} (teacher-forced, {dtype}): {bad}"
@@ -398,6 +403,21 @@ def test_trainer_adam_checkpoint_resume_matches_uninterrupted_run(gpu, tmp_path)
     tr3 = Trainer(m3, cfg_s)
     assert tr3.resume(str(tmp_path / "run")) == 1 and tr3.opt_step == 0
     assert float(m3.flat_velocity.abs().max()) == 0.0
+    # ... and WITHOUT a Trainer: a bare model.load_weights() of the Adam bundle installs Adam's moments, an SGD
+    # update then starts from zero momentum instead of using Adam's first moment as velocity -- and vice versa
+    m4 = X3D(cfg_s, dtype=torch.float32, device=gpu, seed=8)
+    m4.load_weights(str(tmp_path / "run"))
+    assert m4.slot_kind == "adam" and float(m4.flat_velocity.abs().max()) > 0.0
+    m4.flat_grads.zero_()
+    w_before = m4.flat_params[:m4.n_trainable_flat].clone()
+    m4.apply_sgd(0.1, 0.9)                    # zero gradient + zero (re-initialised) momentum: only the L2 term moves weights
+    torch.cuda.synchronize()
+    assert m4.slot_kind == "sgd"
+    l2 = m4.l2_mask.bool()
+    assert torch.equal(m4.flat_params[:m4.n_trainable_flat][~l2], w_before[~l2])
+    m5 = X3D(cfg_s, dtype=torch.float32, device=gpu, seed=8)
+    m5.load_weights(str(tmp_path / "run"), optimizer="sgd")      # the caller names its branch: nothing of Adam's is installed
+    assert m5.slot_kind is None and float(m5.flat_velocity.abs().max()) == 0.0
 
 
 FULL_SIZE_TRAIN = [          # BASELINE configs at FULL size: variant, clips, T, S, storage, clips per inference sub-plan

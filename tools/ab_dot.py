@@ -1,4 +1,5 @@
-"""In-process A/B of the depthwise backward with the tap loops on two-element dot products (X3D_DW_DOT) against the
+"""(needs a library built with X3D_EXPERIMENTS=1 -- the product build reads its A/B switches once)
+In-process A/B of the depthwise backward with the tap loops on two-element dot products (X3D_DW_DOT) against the
 scalar-FMA form: the variants alternate inside one process on the same tensors (box-to-box and run-to-run spread of
 single runs is +-5 %), medians over rounds.
 

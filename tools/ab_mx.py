@@ -1,4 +1,5 @@
-"""In-process A/B of the matrix-core depthwise kernels (dw_mx.hip, X3D_DW_MX) against the vector kernels on the 14x14
+"""(needs a library built with X3D_EXPERIMENTS=1 -- the product build reads its A/B switches once)
+In-process A/B of the matrix-core depthwise kernels (dw_mx.hip, X3D_DW_MX) against the vector kernels on the 14x14
 stride-1 layer of X3D-M stage 4: time per launch (variants alternating) and the difference of the outputs.
 
     python tools/ab_mx.py [C,T,H,W ...]

@@ -615,23 +615,34 @@ def _flat_slot(model, flat, k):
     return flat[o:o + model.params[k].numel()].view(model.params[k].shape)
 
 
-def load_tf_checkpoint(model, path, expect_partial=True):
+def load_tf_checkpoint(model, path, expect_partial=True, optimizer=None):
     """Variables + optimizer state (reference train.py:131-136 `model.load_weights(latest)`): SGD `momentum` slots or
     Adam `m` / `v` slots into the model's flat slot buffers; the optimizer's hyper-parameter variables (`iter`, ...) are
-    left in `model.optimizer_state` for the trainer (Trainer.resume restores its step counter from `iter`)."""
+    left in `model.optimizer_state` for the trainer (Trainer.resume restores its step counter from `iter`).
+
+    optimizer: the optimizer branch that will USE the slots ("sgd" | "adam" | None = whatever the bundle holds).  Slots of
+    the other branch are not installed (Keras restores the variables and leaves a new optimizer's slots at zero): Adam's first
+    moment is never SGD momentum or vice versa.  Whatever is installed is recorded in `model.slot_kind`, which
+    `apply_sgd` / `apply_adam` check before their first use of the buffers."""
     sd, slots, hyper = read_checkpoint(path, model.specs, expect_partial=expect_partial, with_slots=("momentum", "m", "v"))
     model.load_state_dict(sd)
-    first = slots["m"] or slots["momentum"]
-    for k, v in first.items():
-        if k in model.grads:
-            _flat_slot(model, model.flat_velocity, k).copy_(v)
-    if slots["v"]:
-        if getattr(model, "flat_second", None) is None:
-            model.flat_second = torch.zeros_like(model.flat_velocity)
-        for k, v in slots["v"].items():
+    kind = "adam" if slots["m"] or slots["v"] else "sgd" if slots["momentum"] else None
+    model.flat_velocity.zero_()
+    if getattr(model, "flat_second", None) is not None:
+        model.flat_second.zero_()
+    install = kind is not None and optimizer in (None, kind)
+    if install:
+        for k, v in (slots["m"] or slots["momentum"]).items():
             if k in model.grads:
-                _flat_slot(model, model.flat_second, k).copy_(v)
-    model.optimizer_state = dict(hyper=hyper, kind=("adam" if slots["m"] or slots["v"] else "sgd" if slots["momentum"] else None))
+                _flat_slot(model, model.flat_velocity, k).copy_(v)
+        if slots["v"]:
+            if getattr(model, "flat_second", None) is None:
+                model.flat_second = torch.zeros_like(model.flat_velocity)
+            for k, v in slots["v"].items():
+                if k in model.grads:
+                    _flat_slot(model, model.flat_second, k).copy_(v)
+    model.slot_kind = kind if install else None
+    model.optimizer_state = dict(hyper=hyper, kind=kind)
     return model
 
 

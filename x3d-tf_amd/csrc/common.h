@@ -19,6 +19,25 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
+// A/B switches (X3D_* environment variables): the product library reads each ONCE (first use, cached by name); a build
+// made with -DX3D_EXPERIMENTS re-reads them on every launch, which is what the in-process A/B tools (tools/ab_mx.py,
+// tools/ab_dot.py) need.  `name` must be a string literal (the cache is keyed by its address).
+static inline int x3d_env_int(const char* name, int dflt) {
+#ifdef X3D_EXPERIMENTS
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  struct Slot { const char* name; int val; };
+  static Slot slots[64];
+  static int nslots = 0;
+  for (int i = 0; i < nslots; i++) if (slots[i].name == name) return slots[i].val;
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : dflt;
+  if (nslots < 64) { slots[nslots].name = name; slots[nslots].val = v; nslots++; }
+  return v;
+#endif
+}
+
 // 16-bit storage types (X3D_BF16 / X3D_F16): vector types, the matrix-core instruction and the name used in kernel
 // descriptions.  Every 16-bit kernel is a template over H; arithmetic around the matrix cores is fp32 either way.
 // 16-bit storage, point counts that are not a multiple of 8 (X3D-S: 13 frames -> 1300 / 325 points per sample in stages

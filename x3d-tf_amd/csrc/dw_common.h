@@ -342,9 +342,8 @@ template <> struct Dot2<float> {
 // v_pk_fma_f32, v_cvt_pk_bf16_f32, v_max_f32, v_lshlrev_b32 and every DPP form take ~4.9: a dot2 (2 MACs, 4.9 clocks) is no
 // cheaper than two all-VGPR FMAs, and the pair conversions come on top.
 static bool dw_use_dot(int dtype) {
-  const char* e = getenv("X3D_DW_DOT");   // (read per launch: tools/ab_dot.py switches it inside one process)
-  if (!e) return false;
-  return atoi(e) != 0 && dtype != X3D_F32 && (atoi(e) == 2 || dtype == X3D_BF16);
+  const int e = x3d_env_int("X3D_DW_DOT", 0);   // (tools/ab_dot.py switches it inside one process: X3D_EXPERIMENTS build)
+  return e != 0 && dtype != X3D_F32 && (e == 2 || dtype == X3D_BF16);
 }
 
 // tile geometry shared by forward and backward

@@ -266,9 +266,9 @@ static bool mx_plane_ok(const DwGeom& g, bool* p7) {
 // X3D_DW_MX=0: never (A/B hook)
 bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
-  const char* e = getenv("X3D_DW_MX");   // (per launch: tools/ab_mx.py switches it inside one process)
+  const int e = x3d_env_int("X3D_DW_MX", 1);   // (tools/ab_mx.py switches it inside one process: X3D_EXPERIMENTS build)
   bool p7;
-  if ((e && atoi(e) == 0) || dtype == X3D_F32 || S != 1 || !mx_plane_ok(g, &p7) || a.bn.stats) return false;
+  if (e == 0 || dtype == X3D_F32 || S != 1 || !mx_plane_ok(g, &p7) || a.bn.stats) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.x & 3) || ((uintptr_t)a.y & 3)) return false;
@@ -482,13 +482,13 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
 
 bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
-  const char* e = getenv("X3D_DW_MX");
+  const int e = x3d_env_int("X3D_DW_MX", 1);
   bool p7;
   // fp16: the forward only (dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back)
-  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || !mx_plane_ok(g, &p7)) return false;
+  if (e == 0 || dtype != X3D_BF16 || S != 1 || !mx_plane_ok(g, &p7)) return false;
   // 7 x 7 planes: 64.3 -> 60.3 us per launch in isolation, but 66.8 -> 73.2 us inside the X3D-M step (operands in the infinity
   // cache: the packed vector kernel gains more from that): the forward only, unless X3D_DW_MX=7
-  if (p7 && !(e && atoi(e) == 7)) return false;
+  if (p7 && e != 7) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 3) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 3) || ((uintptr_t)a.braw & 3)) return false;
@@ -740,11 +740,11 @@ __global__ __launch_bounds__(64, 2) void dw3d_bwd_mxw_kernel(const DwMxwBwdArgs 
 // X3D_DW_MXW=0: never (A/B hook)
 bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
-  const char* e = getenv("X3D_DW_MXW");
+  const int e = x3d_env_int("X3D_DW_MXW", 1);
   // measured (108 ch x 64 clips of 16 x 28 x 28): 240 -> 226 us per launch, 235 -> 222 us inside the X3D-M step, at two waves
   // per SIMD (188 VGPRs: nine weight operands + nine dW accumulators + two strips of three tensors in flight).  Rows of 20
   // elements in tiles of 14 + 6 rows (X3D-XL stage 4) lose (341 -> 564 us): only planes that fill the tiles
-  if ((e && atoi(e) == 0) || dtype != X3D_BF16 || S != 1 || (g.W & 1) || g.W < 26 || g.W > 30 || g.H < 12 ||
+  if (e == 0 || dtype != X3D_BF16 || S != 1 || (g.W & 1) || g.W < 26 || g.W > 30 || g.H < 12 ||
       (g.H % 14 != 0 && g.H % 14 < 10)) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   const int HT = ceil_div(g.H, 14);

@@ -341,10 +341,7 @@ __global__ __launch_bounds__(PK_MAX_THREADS, 4) void dw3d_bwd_pk_kernel(const Dw
 }
 
 // A/B switches: X3D_DW_PK=0 never use the packed kernel; X3D_DW_PK_SW=2|4 force the strip width (default: 4 from 12-wide rows)
-static int pk_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
+static int pk_env(const char* name, int dflt) { return x3d_env_int(name, dflt); }
 
 template <typename T, int SW>
 static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
@@ -377,8 +374,9 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
   // two-element dot products (16-bit storage, strips of 4, compile-time geometry)
   const bool dot = SW == 4 && (fixed || odd7) && dw_use_dot(sizeof(T) == 4 ? X3D_F32 : (TypeName<T>::v[0] == 'b' ? X3D_BF16 : X3D_F16));
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d, %d%s>", TypeName<T>::v, SW,
-             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7, dot ? ", 1" : "");
+    // (all eight template arguments, as the symbol carries them: tools/dw_gbs.py joins this string with the rocprofv3 table)
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pk_kernel<%s, %d, 2, 6, %d, %d, %d, %d>", TypeName<T>::v, SW,
+             (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7, dot ? (odd7 ? 3 : pk_env("X3D_DW_DOTMASK", 3)) : 0);
     return true;
   }
 #ifdef X3D_EXPERIMENTS   // result-changing timing hook: only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)

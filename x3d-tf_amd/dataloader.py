@@ -262,20 +262,41 @@ class InputReader:
                             yield next(it)
                         except StopIteration:
                             live.remove(it)
-            recs = self._shard(interleave())
+            recs = self._shard(interleave(), batch_size)
             if self._is_training:
                 recs = self._shuffle(recs, batch_size * 16 if batch_size else 1024)
             return recs
         lines = [ln for f in files for ln in open(f).read().splitlines() if ln.strip()]   # TextLineDataset(...).cache()
         if self._is_training:
-            return self._shuffle(self._shard(iter(lines)), max(int(self._cfg.TRAIN.DATASET_SIZE) // self._world, 1))
-        return self._shard(iter(lines))
+            # .shuffle(DATASET_SIZE, reshuffle_each_iteration): a fresh permutation of the WHOLE list every pass, drawn from
+            # the rank-independent generator BEFORE the split -- every rank sees every video over the epochs, as the
+            # replicas of the reference's one shuffled dataset do (a per-rank shuffle of a fixed shard would not)
+            lines = [lines[i] for i in self._rng_files.permutation(len(lines))]
+        return self._shard(iter(lines), batch_size)
 
-    def _shard(self, it: Iterator) -> Iterator:
-        """this rank's records of the (rank-independent) record stream: r, r + world, ... (tf.data's `shard`)"""
+    def _shard(self, it: Iterator, local_batch: Optional[int] = None) -> Iterator:
+        """this rank's records of the (rank-independent) record stream, cut so that every rank gets the SAME number:
+        training -- records r, r + world, ... of the complete groups of `world` records (tf.data's `shard`; the
+        pass's last N % world records are dropped, so all ranks cross pass boundaries at the same step and keep drawing the
+        same per-pass permutations); evaluation -- the stream is cut into GLOBAL batches of world * local_batch records,
+        rank r takes records [r * b, (r + 1) * b) of each complete one and the trailing partial global batch is dropped:
+        exactly the videos `batch(drop_remainder=True)` of the reference's single dataset evaluates."""
         if self._world == 1:
             return it
-        return (x for i, x in enumerate(it) if i % self._world == self._rank)
+        group = self._world if self._is_training or not local_batch else self._world * local_batch
+        per = group // self._world
+
+        def gen():
+            buf = []
+            for x in it:
+                buf.append(x)
+                if len(buf) == group:
+                    if self._is_training:
+                        yield buf[self._rank]
+                    else:
+                        yield from buf[self._rank * per:(self._rank + 1) * per]
+                    buf = []
+        return gen()
 
     def local_batch(self, batch_size: Optional[int]) -> Optional[int]:
         """clips (videos in evaluation) per step on this rank for the reference's global `batch_size`"""

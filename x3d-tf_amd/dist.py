@@ -11,6 +11,7 @@ depthwise/pointwise kernels.  ``backend="nccl"`` is RCCL on ROCm; the same code 
 tensors for the multi-process tests.
 """
 import os
+import time
 from typing import List, Optional, Sequence, Tuple
 
 # the host driver only supports dmabuf IPC; the HSA runtime reads this when HIP initialises, i.e. it has to be in the
@@ -127,6 +128,8 @@ class BucketReducer:
         self._work: List = []
         self.launched = 0          # all-reduces enqueued so far (bench.py reports them)
         self.launched_bytes = 0
+        self._t_mark, self._ev_mark = None, None
+        self._pairs, self._host_s, self._host_n = [], 0.0, 0
 
     def launch(self, i: int):
         if not self.active:
@@ -135,10 +138,50 @@ class BucketReducer:
         self.launched_bytes += self.buckets[i].numel() * self.buckets[i].element_size()
         self._work.append(dist.all_reduce(self.buckets[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def mark_backward_done(self):
+        """Call once the last backward launch of the step is on the current stream: records an event there (no
+        synchronisation).  finish() measures from it how long the exchange stays EXPOSED, i.e. the part of the collectives
+        that did not hide behind the backward pass."""
+        if not self.active:
+            return
+        self._t_mark = time.perf_counter()
+        self._ev_mark = None
+        if self._device_events():
+            self._ev_mark = torch.cuda.Event(enable_timing=True)
+            self._ev_mark.record()
+
+    def _device_events(self) -> bool:
+        # RCCL: work.wait() makes the compute STREAM wait, so stream events bracket the exposed time without a host sync;
+        # host-side backends (gloo) block the host in wait(): wall time then
+        return bool(self.buckets) and self.buckets[0].is_cuda and dist.get_backend(self.group) == "nccl"
+
     def finish(self):
         for w in self._work:
             w.wait()
         self._work = []
+        if not self.active or self._t_mark is None:
+            return
+        if self._ev_mark is not None:
+            done = torch.cuda.Event(enable_timing=True)
+            done.record()
+            self._pairs.append((self._ev_mark, done))      # read later (exposed_ms), after the caller's own synchronisation
+        else:
+            self._host_s += time.perf_counter() - self._t_mark
+            self._host_n += 1
+        self._t_mark, self._ev_mark = None, None
+
+    def exposed_ms(self, reset: bool = True) -> Optional[float]:
+        """Average over the steps since the last call of (every bucket landed) - (last backward kernel finished), in ms:
+        HIP-event time on the compute stream with RCCL, host wall time of the waits with a host-side backend (there it
+        also contains whatever backward work was still queued on the device).  ~0 when the exchange hid behind the backward
+        pass; None when no multi-rank step was measured.  Call after a device synchronisation."""
+        n = len(self._pairs) + self._host_n
+        if n == 0:
+            return None
+        total = sum(a.elapsed_time(b) for a, b in self._pairs) + 1e3 * self._host_s
+        if reset:
+            self._pairs, self._host_s, self._host_n = [], 0.0, 0
+        return max(total / n, 0.0)
 
 
 def broadcast_(tensors: Sequence[torch.Tensor], src: int = 0, group=None):
@@ -154,6 +197,17 @@ def mean_(t: torch.Tensor, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(dist.get_world_size(group))
     return t
+
+
+def gather_over_ranks(value: float, device=None) -> List[float]:
+    """`value` of every rank, in rank order (one entry without a process group)."""
+    if not _active():
+        return [value]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() else "cpu"))
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
 
 
 def max_over_ranks(value: float, device=None) -> float:

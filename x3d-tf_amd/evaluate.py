@@ -31,6 +31,21 @@ class Metrics:
         self.top5 += int((top5 == labels[:, None]).any(dim=1).sum())
         self.n += int(labels.numel())
 
+    def all_reduce_(self, group=None, device=None):
+        """Sum the numerators and the video count over the replicas (no-op without a multi-rank process group): under
+        MirroredStrategy `model.evaluate` reports ONE metric over the whole dataset (reference eval.py:83-89,
+        utils.py:160-167); here every rank evaluates its shard of the videos and only these four counters are exchanged
+        ("eval -- replicas only ... only metric counters are reduced")."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        if device is None:
+            device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([self.loss, float(self.top1), float(self.top5), float(self.n)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, group=group)
+        self.loss, self.top1, self.top5, self.n = float(t[0]), int(round(float(t[1]))), int(round(float(t[2]))), int(round(float(t[3])))
+        return self
+
     def result(self) -> Dict[str, float]:
         n = max(self.n, 1)
         return {"loss": self.loss / n + self.reg_loss, "acc": self.top1 / n, "top_5_acc": self.top5 / n, "videos": self.n}
@@ -65,13 +80,18 @@ def evaluate(model, cfg, videos: Iterable[Tuple[torch.Tensor, int]], batch_video
     return m.result()
 
 
-def evaluate_dataset(model, cfg, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]]) -> Dict[str, float]:
+def evaluate_dataset(model, cfg, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], group=None) -> Dict[str, float]:
     """reference eval.py:83-89 `model.evaluate(InputReader(cfg, False, use_tfrecord)(pattern, cfg.TEST.BATCH_SIZE))`:
     `batches` yields (clips [B * views * crops, T, S, S, 3], labels [B]) as `dataloader.InputReader` does in evaluation
-    mode (the views were built on the GPU while the batch was assembled)."""
+    mode (the views were built on the GPU while the batch was assembled).  Under torchrun the reader hands every rank its
+    share of each global batch; the counters are summed over the ranks ONCE at the end, so every rank returns the metric of
+    the whole dataset (the same videos the single-process run evaluates: the reader drops the same trailing partial batch)."""
     m = Metrics(float(model.regularization_loss().item()) if hasattr(model, "regularization_loss") else 0.0)
+    dev = None
     for clips, labels in batches:
         m.update(model(clips, training=False).float(), labels)
+        dev = clips.device
     if hasattr(model, "release_plans"):
         model.release_plans(keep=1)
+    m.all_reduce_(group, dev)
     return m.result()

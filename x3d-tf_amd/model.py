@@ -476,11 +476,22 @@ class X3D:
             elif strict:
                 raise KeyError(f"unexpected parameter {k}")
 
-    def load_weights(self, path, expect_partial=True):
+    def load_weights(self, path, expect_partial=True, optimizer=None):
         """Keras-style ``load_weights`` on a TF tensor-bundle checkpoint prefix or directory
-        (reference train.py:131-143, eval.py:78-81)."""
+        (reference train.py:131-143, eval.py:78-81).  optimizer: "sgd" | "adam" -- the branch that will use the
+        optimizer slots (slots written by the other branch are left at zero); None installs what the bundle holds."""
         from .checkpoint import load_tf_checkpoint
-        return load_tf_checkpoint(self, path, expect_partial=expect_partial)
+        return load_tf_checkpoint(self, path, expect_partial=expect_partial, optimizer=optimizer)
+
+    def _claim_slots(self, kind):
+        """The slot buffers hold state of ONE optimizer branch (`slot_kind`: set by load_weights, then by the first update).
+        An update of the other branch starts from zero slots, as a freshly built Keras optimizer does."""
+        have = getattr(self, "slot_kind", None)
+        if have is not None and have != kind:
+            self.flat_velocity.zero_()
+            if getattr(self, "flat_second", None) is not None:
+                self.flat_second.zero_()
+        self.slot_kind = kind
 
     def save_weights(self, prefix, optimizer_hyper=None, optimizer="sgd"):
         from .checkpoint import save_tf_checkpoint
@@ -749,7 +760,7 @@ class X3D:
             ft = hip.PwFwdArgs(_p(c_raw), st.w, st.y, None, _p(c_ss), None, ACT_RELU, st.N, st.Cin, st.Cout, st.T, st.H, st.W,
                                1, st.dtype, st.w_panel, in_add=_p(shortcut), in_add_scale_shift=_p(r_ss), in_store=_p(y))
             if (fold_fwd and st.stride == 1 and pl.lib.x3d_pw_fwd_tail_supported(C.byref(ft))
-                    and not hip.pw_kernel_name(st).startswith("pw_gemm_wst")):
+                    and not hip.pw_kernel_name(st).startswith(("pw_gemm_wst", "pw_gemm_ws_kernel"))):
                 if pl.blocks:
                     pl.blocks[-1].tail_fwd_folded = True
                 else:
@@ -1024,6 +1035,7 @@ class X3D:
             db = hip.Dw3dBwdArgs(_p(dvv), _p(B.b_raw), _p(pl.coef_nc), _p(B.a_raw), _p(B.bn_a.ss),
                                  _p(p[f"{q}/b/kernel"]), _p(gaa), None, _p(g[f"{q}/b/kernel"]), n, b.inner, t, B.hh,
                                  B.ww, b.stride, dt)
+            B.db = db
             pl.rec_join(Bk)
             pl.rec(Bk, "x3d_dw3d_bwd", ("field", db, {"a_sums": B.bn_a.bsums}))
             pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_a.bsums), float(n * P_in), B.bn_a.mi, p[f"{q}/bn_a/gamma"],
@@ -1204,6 +1216,7 @@ class X3D:
 
     def apply_sgd(self, lr, momentum=0.9, grad_scale=1.0):
         """SGD(momentum, nesterov=True) + L2 (reference train.py:89-92, model.py:47), one launch."""
+        self._claim_slots("sgd")
         hip.call("x3d_sgd_nesterov", self.flat_params.data_ptr(), self.flat_velocity.data_ptr(),
                  self.flat_grads.data_ptr(), self.l2_mask.data_ptr(), float(lr), float(momentum),
                  float(self.arch.weight_decay), float(grad_scale), self.n_trainable_flat)
@@ -1211,6 +1224,7 @@ class X3D:
     def apply_adam(self, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         """Adam + L2 (reference train.py:93-95: tf.optimizers.Adam(learning_rate), Keras defaults), one launch.  The first
         moment lives in `flat_velocity` (the slot the SGD branch uses for momentum), the second in `flat_second`."""
+        self._claim_slots("adam")
         if getattr(self, "flat_second", None) is None:
             self.flat_second = torch.zeros_like(self.flat_velocity)
         hip.call("x3d_adam", self.flat_params.data_ptr(), self.flat_velocity.data_ptr(), self.flat_second.data_ptr(),

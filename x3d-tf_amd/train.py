@@ -70,6 +70,7 @@ class Trainer:
         pl = m.forward_backward(clips, labels, global_batch=n * self.world,
                                 on_stage_done=self._on_stage_done if self.collectives else None,
                                 loss_scale=self.loss_scale)
+        self.reducer.mark_backward_done()     # (an event on the compute stream: finish() measures the exposed exchange from it)
         self.reducer.finish()
         if self._stats_work is not None:      # mirrored-variable MEAN aggregation of the BN moving statistics [TF-3p]
             self._stats_work.wait()
@@ -134,7 +135,11 @@ class Trainer:
                 "bytes_per_step": sum(b.numel() * b.element_size() for b in r.buckets),
                 "allreduces_launched": r.launched, "allreduce_bytes": r.launched_bytes,
                 "launched_from_backward_hooks": bool(self.collectives and r.launched > 0),
-                "moving_stats_mean": bool(self.sync_moving_stats)}
+                "moving_stats_mean": bool(self.sync_moving_stats),
+                # time between the end of the backward pass and the last bucket landing, averaged over the steps since the
+                # last call (0 = fully hidden; None = single rank); "device" = HIP events on the compute stream (RCCL)
+                "exposed_ms": r.exposed_ms(),
+                "exposed_clock": ("device" if (r.active and r._device_events()) else ("host" if r.active else None))}
 
     def _on_stage_done(self, stage):
         """backward hook (model.forward_backward): 'fwd' = forward finished (the moving statistics are final: their
@@ -175,7 +180,7 @@ class Trainer:
         if not path:
             return 0
         m = self.model
-        m.load_weights(path)   # weights + optimizer slots; unknown keys tolerated as Keras does (warning only)
+        m.load_weights(path, optimizer=self.optimizer)   # weights + this branch's optimizer slots; unknown keys tolerated as Keras does
         st = getattr(m, "optimizer_state", None) or {}
         kind = st.get("kind")
         if kind is not None and kind != self.optimizer:
