@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 121
+#define X3D_ABI_VERSION 122
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -230,9 +230,25 @@ typedef struct {
   const void* tail_r;
   double* tail_sums_c;
   double* tail_sums_r;
+  /* RECOMPUTED conv output (ADD epilogues; rc_panel == NULL: off).  The conv is followed by a training-mode BatchNorm, so
+   * dYraw = A*g + B*yraw + C with yraw = W x linear in the conv input: with rc_panel set the launch streams g and x ONLY
+   * (yraw / coef / dw / w_panel are not read and may be NULL) -- the caller need not keep the conv's raw output at all:
+   *   dx = [W1 | M] [g ; x] + c0 (+ add, + tail)    W1 = W^T diag(A), M = W^T diag(B) W, c0 = W^T C   (x3d_pw_bwd_rc_prepare)
+   *   rc_sums [Cout + 1 + Cin][Cin] += [g ; 1 ; x] x^T  over all points (zero it before the launch); x3d_pw_bwd_rc_finish turns
+   *   the sums into dw = diag(A) (g x^T) + diag(B) W (x x^T) + C (sum x)^T   (reference model.py:246-257 `a` -> `bn_a`). */
+  const void* rc_panel;        /* x3d_pw_bwd_rc_panel_elems(Cout, Cin) elements of the storage type, 16-byte aligned */
+  const float* rc_c0;          /* [Cin] */
+  float* rc_sums;              /* x3d_pw_bwd_rc_sums_elems(Cout, Cin) floats */
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
+/* the per-step operands of the recomputed-output form.  panel_elems == 0: the layer shape is not covered (Cin <= 32,
+ * Cout <= 127).  prepare: after x3d_bn_bwd_finalize produced `coef` [Cout][4]; finish: after x3d_pw_bwd, dw [Cout][Cin] +=. */
+long long x3d_pw_bwd_rc_panel_elems(int Cout, int Cin);
+long long x3d_pw_bwd_rc_sums_elems(int Cout, int Cin);
+int x3d_pw_bwd_rc_prepare(const float* w /* [Cout][Cin] fp32 */, const float* coef, void* rc_panel, float* rc_c0, int Cout, int Cin,
+                          int dtype, void* stream);
+int x3d_pw_bwd_rc_finish(const float* rc_sums, const float* w, const float* coef, float* dw, int Cout, int Cin, int dtype, void* stream);
 
 /* bf16 weight panels.  The bf16 GEMMs keep their A operand (the weights) resident in LDS as bf16 rows of
  * pitch roundup(K,16)+8; without a panel every workgroup converts its rows from the fp32 master weights

@@ -117,6 +117,19 @@ PW_BWD = [
     (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
 ]
 
+# ... without the conv's raw output (pw_bwd_rc.hip: y = W x folded into the BatchNorm backward): N, Cin, Cout, T, H, W, epilogue, tail
+PW_BWD_RC = [
+    (2, 24, 54, 4, 16, 16, "add", 0), (2, 24, 54, 4, 16, 16, "add", 1), (2, 24, 54, 4, 16, 16, "add", 2),          # stage 2 (X3D-S / M / L)
+    (1, 24, 54, 2, 16, 16, "add_strided", 0), (1, 24, 54, 2, 16, 16, "add_strided", 1),                            # block 0 of stage 2 (stem fold = tail 1)
+    (2, 24, 54, 2, 28, 28, "add_strided", 0), (2, 24, 54, 2, 28, 28, "add_strided", 2),                            # rows of 28 points: element form
+    (1, 24, 108, 3, 16, 16, "add_strided", 0), (1, 24, 108, 3, 16, 16, "add_strided", 1), (1, 24, 108, 3, 16, 16, "add_strided", 2),   # stage 3 block 0
+    (1, 24, 108, 2, 12, 12, "add_strided", 2), (1, 24, 108, 2, 12, 12, "add_strided", 1), (2, 24, 54, 2, 28, 28, "add_strided", 1),   # ... X3D-L / XL rows (element form)
+    (1, 32, 72, 1, 16, 16, "add", 0), (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add_strided", 2),  # X3D-XL stage 2 (Cin = 32: no spare row)
+    (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2), (2, 8, 31, 1, 9, 8, "add", 0),               # ragged tiles, widths off the grid, Cout + 1 = 32
+    (1, 16, 95, 1, 12, 12, "add", 0), (1, 24, 127, 1, 8, 8, "add", 2),                                             # three / four row tiles of g
+    (5, 24, 54, 8, 28, 28, "add", 1),                                                                              # several tiles per workgroup, across samples
+]
+
 # ... with the residual-tail backward of the block below folded into the epilogue (the `a` convs: ADD epilogues, panels of
 # one or two row tiles): N, Cin, Cout, T, H, W, epilogue, tail (1 = identity shortcut below, 2 = shortcut conv below)
 PW_BWD_TAIL = [
@@ -249,6 +262,15 @@ def pw_bwd_struct(shape, dtype):
                          A() if sw else None, A() if sw else None, None if sw else A(), A(), n, cin, cout, t, h, w,
                          _code(dtype), A() if tail else None, A() if tail == 2 else None, A() if tail else None,
                          A() if tail == 2 else None)
+
+
+def pw_bwd_rc_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w, epi, tail = shape
+    A = _Addr.new
+    return hip.PwBwdArgs(A(), None, None, None, A(), PW_DGRAD_EPI.index(epi), A(), None, None, None, None, A(), None, n, cin,
+                         cout, t, h, w, _code(dtype), A() if tail else None, A() if tail == 2 else None, A() if tail else None,
+                         A() if tail == 2 else None, A(), A(), A())
 
 
 def dw_fwd_struct(shape, dtype):

@@ -49,6 +49,10 @@ def _kernel_case_names():
                 st = S.pw_bwd_struct(shp, dt)
                 assert hip.load().x3d_pw_bwd_supported(st), f"fused backward with the tail does not cover the registered case {shp}"
                 add(st, f"test_pw_bwd_tail[{shp}, {dt}]")
+            for shp in S.PW_BWD_RC:
+                st = S.pw_bwd_rc_struct(shp, dt)
+                assert hip.load().x3d_pw_bwd_supported(st), f"the recomputed-output fused backward does not cover the registered case {shp}"
+                add(st, f"test_pw_bwd_rc[{shp}, {dt}]")
         for shp in S.DW:
             add(S.dw_fwd_struct(shp, dt), f"test_dw3d_fwd[{shp}, {dt}]")
             add(S.dw_bwd_struct(shp, dt), f"test_dw3d_bwd[{shp}, {dt}]")

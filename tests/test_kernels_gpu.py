@@ -272,6 +272,84 @@ def test_pw_bwd_oracle(gpu, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", S.PW_BWD_RC)
+def test_pw_bwd_rc(gpu, dtype, shape):
+    """x3d_pw_bwd with rc_panel (pw_bwd_rc.hip): the `a`-conv backward that never reads the conv's raw output.  Reference:
+    the fp64 restatement of what the plain form computes -- y = Wr x (Wr: weights rounded to the storage type, as the forward
+    GEMM multiplies them), dY = A g + B y + C, dx = Wr^T dY (+ add, + folded tail), dw = dY x^T -- so the algebraic fold
+    dx = [Wr^T A | Wr^T B Wr] [g ; x] + Wr^T C,  dw = A (g x^T) + B Wr (x x^T) + C (sum x)^T is checked against the definition,
+    not against itself: dw directly (tol of the weight gradients), dx in two steps -- the device against the fold with its
+    two panel operands rounded to the storage type (tol_gemm, as every matrix-core test rounds its operands), and that
+    rounded fold against the definition (the operand-rounding bound)."""
+    ops = _ops()
+    n, cin, cout, t, h, w, epi, tail = shape
+    g_ = _gen(37)
+    gy, gyd = rnd((n, cout, t, h, w), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    x, xd = rnd((n, cin, t, h, w), dtype, g_)
+    if tail:
+        x = torch.relu(x)          # = output of the block below: about half of it positive
+        xd = x.double()
+    wr = round_to(wt, dtype)
+    yd = torch.einsum("oc,ncthw->nothw", wr, xd)
+    c = coef.double()
+    dy = c[:, 0].view(1, -1, 1, 1, 1) * gyd + c[:, 1].view(1, -1, 1, 1, 1) * yd + c[:, 2].view(1, -1, 1, 1, 1)
+    dx_def = torch.einsum("oc,nothw->ncthw", wr, dy)                  # the definition: W^T (A g + B (W x) + C)
+    # ... and the same map with the two matrix-core operands of the kernel rounded to the storage type, as every
+    # pointwise test rounds its operands (tol_gemm): W1 = Wr^T diag(A), M = Wr^T diag(B) Wr; c0 = Wr^T C stays fp32
+    w1 = round_to((wr * c[:, 0:1]).float(), dtype)                     # [co][ci]
+    mm = round_to(torch.einsum("oc,o,od->cd", wr, c[:, 1], wr).float(), dtype)
+    dx_ref = (torch.einsum("oc,nothw->ncthw", w1, gyd) + torch.einsum("cd,ndthw->ncthw", mm, xd) +
+              (wr * c[:, 2:3]).sum(0).view(1, -1, 1, 1, 1))
+    # the algebraic fold IS the definition up to that operand rounding (2^-9 relative per panel entry for bf16)
+    fold_err = (dx_ref - dx_def).abs().max().item() / dx_def.abs().max().item()
+    assert fold_err < (2e-2 if dtype == torch.bfloat16 else 3e-3), fold_err
+    if epi == "add":
+        add, addd = rnd((n, cin, t, h, w), dtype, g_)
+        dx_ref = dx_ref + addd
+        e = ops.EPI_ADD
+    else:
+        add, addd = rnd((n, cin, t, (h + 1) // 2, (w + 1) // 2), dtype, g_)
+        up = torch.zeros_like(dx_ref)
+        up[:, :, :, ::2, ::2] = addd
+        dx_ref = dx_ref + up
+        e = ops.EPI_ADD_STRIDED
+    dev = lambda v: None if v is None else v.to(gpu)
+    craw = rraw = sc = sr = None
+    if tail:
+        craw, crd = rnd((n, cin, t, h, w), dtype, g_)
+        sc = torch.zeros((cin, 2), dtype=torch.float64, device=gpu)
+        if tail == 2:
+            rraw, rrd = rnd((n, cin, t, h, w), dtype, g_)
+            sr = torch.zeros((cin, 2), dtype=torch.float64, device=gpu)
+    dx = torch.empty((n, cin, t, h, w), dtype=dtype, device=gpu)
+    dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)     # += semantics
+    ok = ops.pw_bwd_rc(dev(gy), dev(x), dev(wt), dev(coef), dx, dw, e, dev(add), tail_c=dev(craw), tail_r=dev(rraw),
+                       tail_sums_c=sc, tail_sums_r=sr)
+    torch.cuda.synchronize()
+    assert ok, "the recomputed-output form should cover this shape"
+    rt, at = tol_gemm(dtype)
+    scale = dx_ref.abs().max().item()
+    if tail:
+        # the mask is [x > 0] -- exact; the masked entries are exact zeros
+        keep = xd > 0
+        assert (dx.float().cpu()[~keep] == 0).all()
+        dx_ref = dx_ref * keep
+    report("dx", dx, dx_ref, rt, at * scale)
+    dw_ref = torch.einsum("nothw,ncthw->oc", dy, xd)
+    tol = _wtol(dtype)
+    report("dw", dw, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
+    if tail:
+        dxs = dx.float().cpu().double()      # the sums describe dx as stored
+        sref = torch.stack([dxs.sum((0, 2, 3, 4)), (dxs * crd).sum((0, 2, 3, 4))], 1)
+        report("tail_sums_c", sc, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
+        if tail == 2:
+            sref = torch.stack([dxs.sum((0, 2, 3, 4)), (dxs * rrd).sum((0, 2, 3, 4))], 1)
+            report("tail_sums_r", sr, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD_TAIL)
 def test_pw_bwd_tail(gpu, dtype, shape):
     """x3d_pw_bwd with the residual-tail backward of the block below folded into its epilogue (tail_c / tail_r): the conv

@@ -190,7 +190,7 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     perturbations ~600x (measured in fp32), and bf16 rounding re-injects any 1e-7 difference as a 4e-3 one, so
     two exact implementations decorrelate to O(30 %) on gradients.  Per block the error is one bf16 ulp class:
     stated tolerance 2 % of each tensor's max for activations/gradients; weight gradients (whose GEMM operands
-    are rounded to bf16 for the matrix cores) 6 % relative L2 worst case, 1.5 % median."""
+    are rounded to bf16 for the matrix cores) 5.5 % relative L2 worst case (8 % for the two SE biases), 1.5 % median."""
     from oracle import x3d_oracle as O
     cfg, arch, params = _setup(name)
     torch.manual_seed(2)
@@ -205,7 +205,6 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     pl = m.forward_backward(x.to(gpu), labels.to(gpu), loss_scale=ls)        # builds the plan, full step
     torch.cuda.synchronize()
     assert torch.isfinite(pl.loss_rows).all() and torch.isfinite(m.flat_grads).all()
-    masks = hip_relu_masks(pl)
     # which depthwise launches run on the matrix cores (operands rounded to the storage type): the library's own dispatch
     from x3d_tf_amd import hip as _hip
     dw_ops = {O.block_prefix(B.spec): ("_mx" in _hip.dw3d_kernel_name(B.sb), "_mx" in _hip.dw3d_kernel_name(B.db))
@@ -218,6 +217,13 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     from x3d_tf_amd import hip
     hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
              pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), ls / n, n, arch.num_classes)
+    torch.cuda.synchronize()
+    # the ReLU sign patterns of THIS forward pass (the one whose stored tensors the blocks are replayed from): two passes of
+    # the same plan agree to the last fp32 bit of their batch statistics only when their reductions run in the same order,
+    # and one ulp there re-rounds 16-bit tensors downstream -- measured (tools/debug_replay.py): first pass and replay of
+    # X3D-M 2x4x128 differ in 10-20 elements of a stage-3 tensor and in hundreds of last-stage signs when another model's
+    # buffers are alive in the process.  The backward launches do not write forward tensors.
+    masks = hip_relu_masks(pl)
     pos = 0
     worst = dict(y=0.0, dx=0.0, dw=0.0)
     errs = {}
@@ -261,9 +267,12 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
             worst["dw"] = max(worst["dw"], e)
             errs[k] = e
     print("teacher-forced worst:", name, n, t, s, dtype, "mx (fwd, bwd) blocks:", sum(v[0] for v in dw_ops.values()), sum(v[1] for v in dw_ops.values()), worst, sorted(errs.items(), key=lambda kv: -kv[1])[:4], "tail folded in", folded, "blocks")
-    lim, med = (6e-2, 1.5e-2) if dtype == torch.bfloat16 else (1e-2, 2.5e-3)
-    bad = {k: e for k, e in errs.items() if e > lim}
-    assert not bad, f"relative L2 error beyond {lim} (teacher-forced, {dtype}): {bad}"
+    # Limits (round 4, after the oracle learnt which depthwise products see rounded operands -- Storage.dw_operands): measured
+    # worst over the six cases 4.9e-2 bf16 / 6.4e-3 fp16 (the bn_a gammas: cancelling sums of 16-bit products); the two SE
+    # biases are sums that cancel to ~1e-3 of their terms (docstring above) and sit at 5.3e-2 .. 6.1e-2 / 6.2e-3
+    lim, lim_se, med = (5.5e-2, 8e-2, 1.5e-2) if dtype == torch.bfloat16 else (8e-3, 1.2e-2, 2.5e-3)
+    bad = {k: e for k, e in errs.items() if e > (lim_se if k.endswith(("/se_fc1/bias", "/se_fc2/bias")) else lim)}
+    assert not bad, f"relative L2 error beyond {lim} ({lim_se} for the SE biases) (teacher-forced, {dtype}): {bad}"
     assert sorted(errs.values())[len(errs) // 2] < med        # median
 
 

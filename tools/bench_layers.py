@@ -36,8 +36,9 @@ def describe(name, st, eb):
         return f"{f['Cout']}->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}", by
     if name == "x3d_pw_bwd":   # fused dgrad + wgrad: dY twice-read tensors once, conv input / braw once, dx written
         extra = {1: f["Cin"], 2: f["Cin"] // 4, 3: 0}[f["epi"]]
-        by = eb * n * t * h * w * (2 * f["Cout"] + 2 * f["Cin"] + extra)
-        return f"{f['Cout']}<->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}", by
+        rc = bool(getattr(st, "rc_panel", None))      # recomputed-output form: the conv's raw output is not read
+        by = eb * n * t * h * w * ((1 if rc else 2) * f["Cout"] + 2 * f["Cin"] + extra)
+        return f"{f['Cout']}<->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}" + (" rc" if rc else ""), by
     if name == "x3d_pw_wgrad":
         by = eb * n * t * ho * wo * (2 * f["Cout"] + f["Cin"])
         return f"{f['Cout']}x{f['Cin']} @{t}x{ho}x{wo}", by

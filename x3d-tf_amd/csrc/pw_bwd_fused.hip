@@ -609,8 +609,13 @@ int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st);
 bool pw_bwd_wsta_applies(const x3d_pw_bwd_args* b);
 int pw_bwd_wsta(const x3d_pw_bwd_args* b, hipStream_t st);
 
+// ... and the form that recomputes the conv output instead of reading it (pw_bwd_rc.hip; rc_panel != NULL)
+bool pw_bwd_rc_supported(const x3d_pw_bwd_args* b);
+int pw_bwd_rc(const x3d_pw_bwd_args* b, hipStream_t st);
+
 // eligibility of the fused path (the caller falls back to x3d_pw_dgrad + x3d_pw_wgrad otherwise)
 static bool fb_supported(const x3d_pw_bwd_args* b) {
+  if (b->rc_panel) return pw_bwd_rc_supported(b);
   if (pw_bwd_wst_applies(b) || pw_bwd_wsta_applies(b)) return true;
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw) return false;
   int MT = 0, KT = 0;
@@ -639,8 +644,10 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
 extern "C" int x3d_pw_bwd_supported(const x3d_pw_bwd_args* b) { return (b && fb_supported(b)) ? 1 : 0; }
 
 extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
-  X3D_REQUIRE(b && b->g && b->yraw && b->coef && b->dx && b->dw, "pw_bwd: null pointer");
+  X3D_REQUIRE(b && b->g && b->dx, "pw_bwd: null pointer");
   X3D_REQUIRE(b->N > 0 && b->Cin > 0 && b->Cout > 0 && b->T > 0 && b->H > 0 && b->W > 0, "pw_bwd: bad extents");
+  if (b->rc_panel) return pw_bwd_rc(b, (hipStream_t)stream);
+  X3D_REQUIRE(b->yraw && b->coef && b->dw, "pw_bwd: null pointer");
   X3D_REQUIRE(fb_supported(b), "pw_bwd: shape / alignment / epilogue not covered by the fused kernel "
                                "(x3d_pw_bwd_supported() == 0): use x3d_pw_dgrad + x3d_pw_wgrad");
   if (pw_bwd_wst_applies(b)) return pw_bwd_wst(b, (hipStream_t)stream);

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 121   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 122   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -43,7 +43,8 @@ class PwBwdArgs(C.Structure):
                 ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
                 ("x", _vp), ("dw", _vp),
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
-                ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp)]
+                ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp),
+                ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp)]
 
 
 class EvalViewsArgs(C.Structure):
@@ -116,6 +117,10 @@ _SIGS = {
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
     "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
+    "x3d_pw_bwd_rc_panel_elems": ([_i, _i], _ll),
+    "x3d_pw_bwd_rc_sums_elems": ([_i, _i], _ll),
+    "x3d_pw_bwd_rc_prepare": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "x3d_pw_bwd_rc_finish": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_pw_kernel_name": ([C.POINTER(PwFwdArgs), C.POINTER(PwDgradArgs), C.POINTER(PwWgradArgs), C.POINTER(PwBwdArgs),
                             C.c_char_p, _i], _i),
     "x3d_pw_panel_elems": ([_i, _i], _ll),

@@ -303,6 +303,8 @@ class X3D:
         # fused dgrad + wgrad of the pointwise convs (x3d_pw_bwd) where it applies; X3D_NO_FUSED_PW_BWD=1 records
         # the separate kernels instead (A/B measurements)
         self._fuse_pw_bwd = os.environ.get("X3D_NO_FUSED_PW_BWD", "0") != "1"
+        # ... in the form that recomputes the `a` conv's output algebraically instead of reading a_raw (X3D_PW_BWD_RC=0: A/B)
+        self._rc_pw_bwd = os.environ.get("X3D_PW_BWD_RC", "1") != "0"
         self._stats_r = int(hip.load().x3d_stats_replicas())
 
     # ---------------------------------------------------------------------------------------------
@@ -1062,36 +1064,61 @@ class X3D:
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt), EPI_ADD,
                                      _p(gten), None, None, None, None, n, b.cin, b.inner, t, B.hh, B.ww, dt)
             da.w_panel = self._wp(f"{q}/a/kernel", True)
-            fa = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
-                               _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt)
+            # The `a` conv's raw output is linear in its input, so the BatchNorm backward dY = A g + B a_raw + C folds into the
+            # GEMMs (pw_bwd_rc.hip): where that form covers the layer (stages 2-3 first blocks: Cin <= 32) the launch streams
+            # g and x only -- a_raw, 2.25x the size of x, is not read here.  Per-step operands: the panel [W^T A | W^T B W] and
+            # c0 (x3d_pw_bwd_rc_prepare, after bn_a's backward finalize) and the moment sums dW is finished from.
+            rc = None
+            pe = int(pl.lib.x3d_pw_bwd_rc_panel_elems(b.inner, b.cin)) if (self._fuse_pw_bwd and self._rc_pw_bwd and
+                                                                            self.dtype != torch.float32) else 0
+            if pe:
+                rc = (pl.act(pe), pl.f32(b.cin), pl.acc64((int(pl.lib.x3d_pw_bwd_rc_sums_elems(b.inner, b.cin)) + 1) // 2))
+
+            def a_bwd_args(tail_c=None, tail_r=None, use_rc=True):
+                if rc is not None and use_rc:
+                    return hip.PwBwdArgs(da.g, None, None, None, da.dx, da.epi, da.add, None, None, None, None, _p(B.x), None,
+                                         n, b.cin, b.inner, t, B.hh, B.ww, dt, tail_c, tail_r, None, None, _p(rc[0]), _p(rc[1]), None)
+                return hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
+                                     _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt, tail_c, tail_r, None, None)
+
+            def supported(st):
+                return st is not None and bool(pl.lib.x3d_pw_bwd_supported(C.byref(st)))
+
+            fa = a_bwd_args()
+            if rc is not None and not supported(fa):
+                rc, fa = None, a_bwd_args(use_rc=False)
             ft = None
             if fold_tail and prev is not None:   # B.x is prev.y: this launch can apply prev's Add + ReLU backward to its dx
-                ft = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
-                                   _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt,
-                                   _p(prev.c_raw), _p(prev.r_raw), None, None)
-                if not pl.lib.x3d_pw_bwd_supported(C.byref(ft)):
+                ft = a_bwd_args(_p(prev.c_raw), _p(prev.r_raw))
+                if not supported(ft):
                     ft = None
             stem_ft = None
             if fold_tail and prev is None and os.environ.get("X3D_NO_STEM_BWD_FOLD") != "1":
                 # B.x is the stem output y0 = relu(bn(t_raw)): the same epilogue masks dx with [y0 > 0] and takes the stem
                 # BatchNorm's backward sums (sum dx, sum dx * t_raw) -- the x3d_relu_bn_bwd_reduce pass over dy0 / t_raw goes
-                stem_ft = hip.PwBwdArgs(da.g, da.yraw, da.coef, da.w_panel, da.dx, da.epi, da.add, None, None, None, None,
-                                        _p(B.x), _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, dt,
-                                        _p(pl.t_raw), None, None, None)
-                if not pl.lib.x3d_pw_bwd_supported(C.byref(stem_ft)):
+                stem_ft = a_bwd_args(_p(pl.t_raw), None)
+                if not supported(stem_ft):
                     stem_ft = None
             pl.stem_bwd_folded = stem_ft is not None
+            fields = {} if rc is None else {"rc_sums": rc[2]}
+            chosen = ft if ft is not None else (stem_ft if stem_ft is not None else (fa if self._fuse_pw_bwd and supported(fa) else None))
+            B.a_bwd_rc = rc is not None and chosen is not None
+            if B.a_bwd_rc:
+                pl.rec(Bk, "x3d_pw_bwd_rc_prepare", p[f"{q}/a/kernel"], B.bn_a.coef, rc[0], rc[1], b.inner, b.cin, dt)
             if ft is not None:
                 prev.tail_folded = True
-                pl.rec(Bk, "x3d_pw_bwd", ("field", ft, {"tail_sums_c": prev.bn_c.bsums,
-                                                         "tail_sums_r": prev.bn_r.bsums if prev.bn_r else None}))
+                pl.rec(Bk, "x3d_pw_bwd", ("field", ft, dict(fields, tail_sums_c=prev.bn_c.bsums,
+                                                            tail_sums_r=prev.bn_r.bsums if prev.bn_r else None)))
             elif stem_ft is not None:
-                pl.rec(Bk, "x3d_pw_bwd", ("field", stem_ft, {"tail_sums_c": pl.bn1.bsums}))
-            elif self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fa)):
-                pl.rec(Bk, "x3d_pw_bwd", fa)
+                pl.rec(Bk, "x3d_pw_bwd", ("field", stem_ft, dict(fields, tail_sums_c=pl.bn1.bsums)))
+            elif chosen is not None:
+                pl.rec(Bk, "x3d_pw_bwd", ("field", fa, fields))
             else:
                 pl.rec_side(Bk, "x3d_pw_wgrad", wa)
                 pl.rec(Bk, "x3d_pw_dgrad", da)
+            if B.a_bwd_rc:
+                pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rc[2]), p[f"{q}/a/kernel"], B.bn_a.coef, g[f"{q}/a/kernel"],
+                       b.inner, b.cin, dt)
             cur = 1 - cur
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt
