@@ -128,6 +128,8 @@ PW_BWD_RC = [
     (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2), (2, 8, 31, 1, 9, 8, "add", 0),               # ragged tiles, widths off the grid, Cout + 1 = 32
     (1, 16, 95, 1, 12, 12, "add", 0), (1, 24, 127, 1, 8, 8, "add", 2),                                             # three / four row tiles of g
     (5, 24, 54, 8, 28, 28, "add", 1),                                                                              # several tiles per workgroup, across samples
+    (2, 48, 108, 2, 28, 28, "add", 0), (24, 48, 108, 8, 28, 28, "add", 0),                                         # stage 3: two row tiles of x (48 rows in the image)
+    (1, 40, 100, 1, 12, 12, "add", 0), (1, 48, 90, 2, 8, 16, "add_strided", 0), (3, 48, 108, 4, 20, 20, "add", 0), # ... widths off the grid, three g tiles, X3D-L planes
 ]
 
 # ... with the residual-tail backward of the block below folded into the epilogue (the `a` convs: ADD epilogues, panels of
@@ -141,6 +143,17 @@ PW_BWD_TAIL = [
     (1, 32, 72, 1, 16, 16, "add", 1), (1, 32, 72, 1, 16, 16, "add", 2), (1, 32, 72, 1, 16, 16, "add_strided", 1),  # X3D-XL stage 2
     (3, 20, 40, 1, 7, 8, "add", 1), (1, 24, 20, 2, 10, 12, "add", 2),                                              # ragged tiles, widths off the grid
     (2, 96, 216, 2, 14, 14, "add", 1), (24, 96, 216, 8, 14, 14, "add", 1), (3, 90, 210, 1, 10, 12, "add", 1),      # stage-4 `a` conv (pw_bwd_wsta.hip)
+]
+
+# ---- the `a` conv without its output tensor (ab_fused.hip): N, Cin, C, T, H, W, stride --------------------------------------
+AB = [
+    (2, 24, 54, 3, 16, 16, 2), (2, 24, 54, 3, 16, 16, 1),       # strips of 2, one H-tile, four channel groups (the last: 6 of 16)
+    (1, 24, 54, 4, 112, 112, 2),                                # X3D-M block 0: 28 H-tiles of 2 output rows, strips of 4
+    (2, 24, 54, 2, 56, 56, 1), (1, 24, 108, 3, 56, 56, 2),      # stage 2 stride 1 (left pad 1: unaligned plane writes), stage 3 block 0
+    (1, 48, 108, 2, 32, 32, 1), (1, 48, 216, 2, 24, 24, 2),     # Cin = 48: two k blocks per tile
+    (1, 32, 72, 2, 24, 24, 2), (1, 32, 72, 1, 40, 40, 1),       # X3D-XL widths (Cin = 32: every k block real)
+    (1, 24, 20, 3, 40, 40, 1), (1, 8, 9, 2, 44, 48, 2),         # partial channel groups, a short last H-tile, Cin = 8
+    (3, 24, 54, 1, 24, 32, 2), (1, 24, 54, 5, 8, 8, 1),         # T = 1, non-square, tiny planes
 ]
 
 # ---- x3d_dw3d_fwd / x3d_dw3d_bwd: N, C, T, H, W, stride --------------------------------------------------------------------

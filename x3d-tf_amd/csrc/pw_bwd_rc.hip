@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_r;
 
 struct PwBwdRcArgs {
   const void* g; const void* x;
-  const void* wp;                       // rc panel [MT*32][KT*32 + MT*32 + 8]
+  const void* wp;                       // rc panel [MT*32][ZR + 8], ZR = rows of the tile image
   const float* c0;                      // [Ci]
   void* dx;                             // [N][Ci][P]
   const void* add;
@@ -42,22 +42,25 @@ struct PwBwdRcArgs {
 #define RC_YP 160    // Z pitch (elements): 320 B
 #define RC_OP 132    // fp32 output slab pitch
 
-// MT: 32-row tiles of Ci; KT: 32-row tiles of Co + 1
+// MT: 32-row tiles of Ci; KT: 32-row tiles of Co + 1.  MT == 2 (Ci in 33..48): the image holds 48 x rows, not 64 -- with 64
+// the 48 <-> 108 layer needs 87 KB of LDS and runs one workgroup per CU; the moment-sum MFMAs then read 16 rows past the image
+// (into the panel that follows it: finite values, landing only in discarded rows / columns of the accumulators)
 template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V>
-__global__ __launch_bounds__(256, (KT <= 2 && !TAIL) ? 3 : 2) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {
+__global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
   constexpr int BN = RC_BN, YP = RC_YP, OP = RC_OP;
   constexpr bool TAILR = TAIL == 2;
-  constexpr int ZR = KT * 32 + MT * 32;             // rows of the tile image
+  constexpr int XR = MT == 1 ? 32 : 48;             // x rows of the tile image
+  constexpr int ZR = KT * 32 + XR;                  // rows of the tile image
   constexpr int XR0 = KT * 32;                      // first x row
   constexpr int WP = ZR + 8;                        // panel pitch (elements): an odd number of 16-byte units
   constexpr int RT = KT + MT;                       // row tiles of the moment sums
   constexpr int NT = RT * MT;                       // tiles of the moment sums
   constexpr int TPW = (NT + 3) / 4;
   constexpr int NKS = NT >= 4 ? 1 : 4 / NT;
-  constexpr int NVY = KT * 2, NVX = MT * 2, ROWS_PT = MT * 2;
+  constexpr int NVY = KT * 2, NVX = XR / 16, ROWS_PT = MT * 2;
   constexpr size_t ZS_B = (size_t)ZR * YP * 2;
   static_assert((size_t)32 * OP * 4 <= ZS_B, "slab must fit the tile image it aliases");
   H* Zs = (H*)smem_raw;
@@ -80,7 +83,11 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL) ? 3 : 2) void pw_bwd_rc_ker
 
   const int srow = tid >> 4, sunit = tid & 15;
   hx8 rg[NVY], rx[NVX];
-  unsigned ymask[TAIL ? NVX : 1];
+  unsigned ymask[TAIL ? ROWS_PT : 1];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PT; i++) ymask[i] = 0u;
+  }
   // every load of the tile loop is unconditional (clamped address, value selected afterwards): the waits stay countable
   auto issue = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tiles_per_n;
@@ -365,8 +372,9 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL) ? 3 : 2) void pw_bwd_rc_ker
   }
 }
 
+static inline int rc_zrows(int MT, int KT) { return KT * 32 + (MT == 1 ? 32 : 48); }
 static inline size_t rc_lds_bytes(int MT, int KT) {
-  const int ZR = KT * 32 + MT * 32;
+  const int ZR = rc_zrows(MT, KT);
   return (size_t)ZR * RC_YP * 2 + (size_t)MT * 32 * (ZR + 8) * 2;
 }
 
@@ -406,8 +414,9 @@ struct RcShape { int MT, KT, ZR, WP, Kg, Cip; };
 static inline bool rc_shape(int Cin, int Cout, RcShape* s) {
   s->MT = ceil_div(Cin, 32);
   s->KT = ceil_div(Cout + 1, 32);
-  if (s->MT != 1 || s->KT < 1 || s->KT > 4) return false;      // (wider inputs: two workgroups per CU no longer fit the image)
-  s->ZR = s->KT * 32 + s->MT * 32;
+  if (s->MT < 1 || s->MT > 2 || Cin > 48 || s->KT < 1 || s->KT > 4) return false;   // (wider inputs: two workgroups per CU no longer fit)
+  if (s->MT == 2 && s->KT < 3) return false;                    // (instantiated for the X3D stage-3 shape class only)
+  s->ZR = rc_zrows(s->MT, s->KT);
   s->WP = s->ZR + 8;
   s->Kg = (Cout + 1 + 15) & ~15;
   s->Cip = (Cin + 15) & ~15;
@@ -426,19 +435,24 @@ bool pw_bwd_rc_supported(const x3d_pw_bwd_args* b) {
   for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;
   if (!b->add || (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8))) return false;
   if (b->tail_r && !b->tail_c) return false;
+  // (two row tiles of x: the tail's extra epilogue operands spill 96-176 bytes per lane at the 256-VGPR cap -- those layers keep
+  // the separate x3d_tail_bwd pass, as they do with pw_bwd_fused.hip)
+  if (s.MT == 2 && b->tail_c) return false;
   return rc_lds_bytes(s.MT, s.KT) <= 160 * 1024;
 }
 
 template <typename H, int EPI>
-static int rc_pick(PwBwdRcArgs& a, int KT, int tail, hipStream_t st) {
-#define RC_CASE(K_)                                                          \
-  if (KT == K_) {                                                            \
-    if (tail == 2) return rc_launch<H, 1, K_, EPI, 2>(a, st);                \
-    if (tail == 1) return rc_launch<H, 1, K_, EPI, 1>(a, st);                \
-    return rc_launch<H, 1, K_, EPI, 0>(a, st);                               \
+static int rc_pick(PwBwdRcArgs& a, int MT, int KT, int tail, hipStream_t st) {
+#define RC_CASE(M_, K_)                                                      \
+  if (MT == M_ && KT == K_) {                                                \
+    if (tail == 2) return rc_launch<H, M_, K_, EPI, 2>(a, st);               \
+    if (tail == 1) return rc_launch<H, M_, K_, EPI, 1>(a, st);               \
+    return rc_launch<H, M_, K_, EPI, 0>(a, st);                              \
   }
-  RC_CASE(1) RC_CASE(2) RC_CASE(3) RC_CASE(4)
+  RC_CASE(1, 1) RC_CASE(1, 2) RC_CASE(1, 3) RC_CASE(1, 4)
 #undef RC_CASE
+  if (MT == 2 && KT == 3 && tail == 0) return rc_launch<H, 2, 3, EPI, 0>(a, st);
+  if (MT == 2 && KT == 4 && tail == 0) return rc_launch<H, 2, 4, EPI, 0>(a, st);
   x3d_set_error("pw_bwd (recomputed output): unsupported tile shape");
   return X3D_ERR_INVALID;
 }
@@ -458,8 +472,8 @@ int pw_bwd_rc(const x3d_pw_bwd_args* b, hipStream_t st) {
   a.tail_c = b->tail_c; a.tail_r = b->tail_r; a.tail_sums_c = b->tail_sums_c; a.tail_sums_r = b->tail_sums_r;
   const int tail = b->tail_c ? (b->tail_r ? 2 : 1) : 0;
   if (b->dtype == X3D_F16)
-    return b->epi == X3D_EPI_ADD ? rc_pick<f16, X3D_EPI_ADD>(a, s.KT, tail, st) : rc_pick<f16, X3D_EPI_ADD_STRIDED>(a, s.KT, tail, st);
-  return b->epi == X3D_EPI_ADD ? rc_pick<bf16, X3D_EPI_ADD>(a, s.KT, tail, st) : rc_pick<bf16, X3D_EPI_ADD_STRIDED>(a, s.KT, tail, st);
+    return b->epi == X3D_EPI_ADD ? rc_pick<f16, X3D_EPI_ADD>(a, s.MT, s.KT, tail, st) : rc_pick<f16, X3D_EPI_ADD_STRIDED>(a, s.MT, s.KT, tail, st);
+  return b->epi == X3D_EPI_ADD ? rc_pick<bf16, X3D_EPI_ADD>(a, s.MT, s.KT, tail, st) : rc_pick<bf16, X3D_EPI_ADD_STRIDED>(a, s.MT, s.KT, tail, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
