@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 123
+#define X3D_ABI_VERSION 124
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -249,6 +249,13 @@ long long x3d_pw_bwd_rc_sums_elems(int Cout, int Cin);
 int x3d_pw_bwd_rc_prepare(const float* w /* [Cout][Cin] fp32 */, const float* coef, void* rc_panel, float* rc_c0, int Cout, int Cin,
                           int dtype, void* stream);
 int x3d_pw_bwd_rc_finish(const float* rc_sums, const float* w, const float* coef, float* dw, int Cout, int Cin, int dtype, void* stream);
+/* x3d_bn_bwd_finalize (arguments up to C: the same arithmetic, the same outputs) + x3d_pw_bwd_rc_prepare for the conv this
+ * BatchNorm follows (w != NULL: its [C][Cin] weights; C <= 127) + x3d_pw_bwd_rc_finish of an EARLIER recomputed-output launch
+ * (fin_sums != NULL), in ONE launch: three ~5 us launches of the backward pass's critical path become one. */
+int x3d_bn_bwd_finalize_rc(const double* sums, double count, const float* mean_invstd, const float* gamma, float* coef,
+                           float* dgamma, float* dbeta, int C, const float* w, void* rc_panel, float* rc_c0, int Cin,
+                           const float* fin_sums, const float* fin_w, const float* fin_coef, float* fin_dw, int fin_Cout,
+                           int fin_Cin, int dtype, void* stream);
 
 /* bf16 weight panels.  The bf16 GEMMs keep their A operand (the weights) resident in LDS as bf16 rows of
  * pitch roundup(K,16)+8; without a panel every workgroup converts its rows from the fp32 master weights

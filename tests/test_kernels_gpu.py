@@ -350,6 +350,49 @@ def test_pw_bwd_rc(gpu, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("cout,cin,fco,fci", [(54, 24, 108, 24), (108, 48, 54, 24), (72, 32, 72, 32), (20, 8, 127, 24)])
+def test_bn_bwd_finalize_rc_equals_the_three_launches(gpu, dtype, cout, cin, fco, fci):
+    """x3d_bn_bwd_finalize_rc (finalize + panel of this layer + dW of an earlier layer in one launch) writes the same bits as
+    x3d_bn_bwd_finalize, x3d_pw_bwd_rc_prepare and x3d_pw_bwd_rc_finish one after the other -- with and without each job."""
+    ops = _ops()
+    from x3d_tf_amd import hip
+    lib = hip.load()
+    g_ = _gen(39)
+    dev = lambda v: v.to(gpu)
+    sums = dev(torch.randn((cout, 2), generator=g_, dtype=torch.float64) * 50)
+    mi = dev(torch.stack([torch.randn(cout, generator=g_), 0.5 + torch.rand(cout, generator=g_)], 1))
+    gamma = dev(1 + 0.2 * torch.randn(cout, generator=g_))
+    w = dev(torch.randn((cout, cin), generator=g_) * 0.2)
+    fw = dev(torch.randn((fco, fci), generator=g_) * 0.2)
+    fcoef = dev(torch.randn((fco, 4), generator=g_) * 0.5)
+    fsums = dev(torch.randn((fco + 1 + fci) * fci, generator=g_) * 30)
+    count = 12345.0
+    pe = int(lib.x3d_pw_bwd_rc_panel_elems(cout, cin))
+    assert pe > 0
+
+    def fresh():
+        return (torch.zeros((cout, 4), device=gpu), torch.full((cout,), 0.25, device=gpu), torch.full((cout,), -0.5, device=gpu),
+                torch.zeros(pe, dtype=dtype, device=gpu), torch.zeros(cin, device=gpu), torch.full((fco, fci), 0.5, device=gpu))
+    coef0, dg0, db0, pan0, c00, dw0 = fresh()
+    ops.bn_bwd_finalize(sums, count, mi, gamma, coef0, dg0, db0)
+    hip.call("x3d_pw_bwd_rc_prepare", w.data_ptr(), coef0.data_ptr(), pan0.data_ptr(), c00.data_ptr(), cout, cin, hip.dtype_code(dtype))
+    hip.call("x3d_pw_bwd_rc_finish", fsums.data_ptr(), fw.data_ptr(), fcoef.data_ptr(), dw0.data_ptr(), fco, fci, hip.dtype_code(dtype))
+    for with_prep in (True, False):
+        for with_fin in (True, False):
+            coef1, dg1, db1, pan1, c01, dw1 = fresh()
+            ops.bn_bwd_finalize_rc(sums, count, mi, gamma, coef1, dg1, db1, dtype, prep=(w, pan1, c01) if with_prep else None,
+                                   fin=(fsums, fw, fcoef, dw1) if with_fin else None)
+            torch.cuda.synchronize()
+            assert torch.equal(coef0, coef1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+            if with_prep:
+                assert torch.equal(pan0, pan1) and torch.equal(c00, c01)
+            if with_fin:
+                assert torch.equal(dw0, dw1)
+            else:
+                assert float((dw1 - 0.5).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD_TAIL)
 def test_pw_bwd_tail(gpu, dtype, shape):
     """x3d_pw_bwd with the residual-tail backward of the block below folded into its epilogue (tail_c / tail_r): the conv

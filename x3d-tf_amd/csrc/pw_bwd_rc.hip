@@ -437,6 +437,7 @@ bool pw_bwd_rc_supported(const x3d_pw_bwd_args* b) {
   if (b->tail_r && !b->tail_c) return false;
   // (two row tiles of x: the tail's extra epilogue operands spill 96-176 bytes per lane at the 256-VGPR cap -- those layers keep
   // the separate x3d_tail_bwd pass, as they do with pw_bwd_fused.hip)
+  // (measured, 48 <-> 108 @28x28 x 64 clips: 88 us + 54 us of x3d_tail_bwd against 186 us with the tail inside, 276 us with TAIL = 2)
   if (s.MT == 2 && b->tail_c) return false;
   return rc_lds_bytes(s.MT, s.KT) <= 160 * 1024;
 }
@@ -529,6 +530,97 @@ extern "C" int x3d_pw_bwd_rc_prepare(const float* w, const float* coef, void* rc
   else
     hipLaunchKernelGGL(rc_prepare_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, w, coef, (bf16*)rc_panel, rc_c0, Cout, Cin, rows, s.WP, s.KT * 32);
   X3D_LAUNCH_CHECK("pw_bwd_rc_prepare");
+  return X3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// x3d_bn_bwd_finalize_rc: the BatchNorm-backward finalize of the conv's BN, the panel it feeds (prepare) and the pending
+// dW of an EARLIER recomputed-output launch (finish) in ONE launch -- each of them is a ~5 us launch on the critical path of
+// the backward pass.  Workgroups [0, nprep): every one derives the coefficients of all C channels into LDS (C <= 127: a few
+// loads per thread), workgroup 0 publishes them (coef, dgamma, dbeta), then they split the panel; workgroups [nprep, ..):
+// the finish job, independent of this BatchNorm.
+// ------------------------------------------------------------------------------------------------------------------------
+struct RcFinalizeArgs {
+  const double* sums; double count; const float* mi; const float* gamma; float* coef; float* dgamma; float* dbeta; int C;
+  const float* w; void* panel; float* c0; int Ci, rows, WP, XR0, nprep;          // prepare (w == NULL: none)
+  const float* f_sums; const float* f_w; const float* f_coef; float* f_dw; int f_Co, f_Ci;   // finish (f_sums == NULL: none)
+};
+
+#define RCF_W_MAX (127 * 48)      // weights of one layer staged in LDS (Co <= 127, Ci <= 48: rc_shape)
+template <typename H>
+__global__ __launch_bounds__(256) void rc_finalize_kernel(const RcFinalizeArgs a) {
+  __shared__ float cf[128 * 4];
+  // the small operands (weights rounded as the matrix cores see them, the Gram block) in LDS: read from global inside the
+  // dot products every term was a dependent L2 round trip (prepare 16 us, finish 14 us per layer against a ~5 us launch floor)
+  __shared__ float wl[RCF_W_MAX];
+  __shared__ float xl[48 * 48];
+  if ((int)blockIdx.x >= a.nprep) {        // finish job
+    const int Co = a.f_Co, Ci = a.f_Ci;
+    const int i0 = (blockIdx.x - a.nprep) * 256, i = i0 + threadIdx.x;
+    const int co0 = i0 / Ci, co1 = min((i0 + 255) / Ci, Co - 1);      // the weight rows this workgroup's outputs touch
+    const float* sx = a.f_sums + (long long)Co * Ci;
+    const float* xx = a.f_sums + (long long)(Co + 1) * Ci;
+    for (int j = threadIdx.x; j < (co1 - co0 + 1) * Ci; j += 256) wl[j] = round_to<H>(a.f_w[(long long)co0 * Ci + j]);
+    for (int j = threadIdx.x; j < Ci * Ci; j += 256) xl[j] = xx[j];
+    __syncthreads();
+    if (i >= Co * Ci) return;
+    const int co = i / Ci, ci = i - co * Ci;
+    double acc = 0.0;
+    for (int k = 0; k < Ci; k++) acc += (double)wl[(co - co0) * Ci + k] * (double)xl[k * Ci + ci];
+    const double v = (double)a.f_coef[co * 4] * (double)a.f_sums[i] + (double)a.f_coef[co * 4 + 1] * acc + (double)a.f_coef[co * 4 + 2] * (double)sx[ci];
+    a.f_dw[i] += (float)v;
+    return;
+  }
+  // the finalize (the arithmetic of bn_bwd_finalize_kernel, elem.hip), every prepare workgroup for itself
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    const double mean = a.mi[c * 2], invstd = a.mi[c * 2 + 1];
+    const double dbe = a.sums[c * 2];
+    const double dga = (a.sums[c * 2 + 1] - mean * dbe) * invstd;
+    const double k1 = (double)a.gamma[c] * invstd;
+    const double B = -k1 * invstd * dga / a.count;
+    const float fA = (float)k1, fB = (float)B, fC = (float)(-k1 * dbe / a.count - B * mean);
+    if (a.w) { cf[c * 4] = fA; cf[c * 4 + 1] = fB; cf[c * 4 + 2] = fC; cf[c * 4 + 3] = 0.f; }
+    if (blockIdx.x == 0) {
+      a.coef[c * 4] = fA; a.coef[c * 4 + 1] = fB; a.coef[c * 4 + 2] = fC; a.coef[c * 4 + 3] = 0.f;
+      a.dgamma[c] += (float)dga;
+      a.dbeta[c] += (float)dbe;
+    }
+  }
+  if (!a.w) return;
+  for (int j = threadIdx.x; j < a.C * a.Ci; j += 256) wl[j] = a.w[j];      // (rc_prepare_body rounds: the same bits as from global)
+  __syncthreads();
+  rc_prepare_body<H>(wl, cf, (H*)a.panel, a.c0, a.C, a.Ci, a.rows, a.WP, a.XR0, blockIdx.x * 256 + threadIdx.x, a.nprep * 256);
+}
+
+extern "C" int x3d_bn_bwd_finalize_rc(const double* sums, double count, const float* mean_invstd, const float* gamma, float* coef,
+                                      float* dgamma, float* dbeta, int C, const float* w, void* rc_panel, float* rc_c0, int Cin,
+                                      const float* fin_sums, const float* fin_w, const float* fin_coef, float* fin_dw, int fin_Cout,
+                                      int fin_Cin, int dtype, void* stream) {
+  X3D_REQUIRE(sums && mean_invstd && gamma && coef && dgamma && dbeta && C > 0 && count > 0, "bn_bwd_finalize_rc: bad args");
+  X3D_REQUIRE(x3d_is_half(dtype), "bn_bwd_finalize_rc: 16-bit storage types only");
+  RcFinalizeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sums = sums; a.count = count; a.mi = mean_invstd; a.gamma = gamma; a.coef = coef; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C;
+  a.nprep = 1;
+  if (w) {
+    X3D_REQUIRE(rc_panel && rc_c0 && Cin > 0 && C <= 127, "bn_bwd_finalize_rc: prepare needs the panel, c0 and C <= 127");
+    RcShape s;
+    X3D_REQUIRE(rc_shape(Cin, C, &s), "bn_bwd_finalize_rc: layer shape not covered (x3d_pw_bwd_rc_panel_elems() == 0)");
+    a.w = w; a.panel = rc_panel; a.c0 = rc_c0; a.Ci = Cin; a.rows = s.MT * 32; a.WP = s.WP; a.XR0 = s.KT * 32;
+    a.nprep = ceil_div(a.rows * a.WP, 256 * 4);          // four panel entries per thread: the 24 -> 54 panel in 4 workgroups
+  } else {
+    X3D_REQUIRE(C <= 256 * 1024, "bn_bwd_finalize_rc: too many channels");
+  }
+  int nfin = 0;
+  if (fin_sums) {
+    X3D_REQUIRE(fin_w && fin_coef && fin_dw && fin_Cout > 0 && fin_Cin > 0 && fin_Cin <= 48, "bn_bwd_finalize_rc: finish job incomplete / Cin > 48");
+    a.f_sums = fin_sums; a.f_w = fin_w; a.f_coef = fin_coef; a.f_dw = fin_dw; a.f_Co = fin_Cout; a.f_Ci = fin_Cin;
+    nfin = ceil_div(fin_Cout * fin_Cin, 256);
+  }
+  const dim3 grid((unsigned)(a.nprep + nfin));
+  if (dtype == X3D_F16) hipLaunchKernelGGL(rc_finalize_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(rc_finalize_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  X3D_LAUNCH_CHECK("bn_bwd_finalize_rc");
   return X3D_OK;
 }
 

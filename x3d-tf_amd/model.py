@@ -986,6 +986,22 @@ class X3D:
         # PRODUCES dy -- the `a`-conv backward of the next block, whose conv input is this block's y -- wherever the fused
         # x3d_pw_bwd covers that layer with its tail epilogue; x3d_tail_bwd remains for the other blocks (and X3D_NO_TAIL_FOLD=1)
         fold_tail = self._fuse_pw_bwd and os.environ.get("X3D_NO_TAIL_FOLD") != "1"
+        # The per-step operands of the recomputed-output `a` backward ride on the BatchNorm-backward finalize launches that
+        # are on the critical path anyway (x3d_bn_bwd_finalize_rc): the panel of a layer with ITS bn_a finalize, the dW of a
+        # layer with the NEXT finalize recorded after its x3d_pw_bwd (X3D_PW_BWD_RC_MERGE=0: separate launches, A/B).
+        merge_rc = os.environ.get("X3D_PW_BWD_RC_MERGE", "1") != "0"
+        pending_fin = {"job": None}
+
+        def rec_bn_bwd_finalize(bn, count, gamma, dgamma, dbeta, c, prep=None):
+            fin, pending_fin["job"] = pending_fin["job"], None
+            if prep is None and fin is None:
+                pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", bn.bsums), float(count), bn.mi, gamma, bn.coef, dgamma, dbeta, c)
+                return
+            w_, panel_, c0_, cin_ = prep if prep is not None else (None, None, None, 0)
+            f_ = fin if fin is not None else (None, None, None, None, 0, 0)
+            pl.rec(Bk, "x3d_bn_bwd_finalize_rc", ("acc", bn.bsums), float(count), bn.mi, gamma, bn.coef, dgamma, dbeta, c,
+                   w_, panel_, c0_, cin_, ("acc", f_[0]) if f_[0] is not None else None, f_[1], f_[2], f_[3], f_[4], f_[5], dt)
+
         for bi in range(len(pl.blocks) - 1, -1, -1):
             B = pl.blocks[bi]
             prev = pl.blocks[bi - 1] if bi > 0 else None
@@ -1000,8 +1016,7 @@ class X3D:
                 pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
                        ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
             gten = dy
-            pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_c.bsums), float(n * P_out), B.bn_c.mi, p[f"{q}/bn_c/gamma"],
-                   B.bn_c.coef, g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout)
+            rec_bn_bwd_finalize(B.bn_c, n * P_out, p[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout)
             # c
             wc = hip.PwWgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate),
                                  ACT_SWISH, _p(g[f"{q}/c/kernel"]), n, b.inner, b.cout, t, B.ho, B.wo, 1, dt)
@@ -1040,15 +1055,14 @@ class X3D:
             B.db = db
             pl.rec_join(Bk)
             pl.rec(Bk, "x3d_dw3d_bwd", ("field", db, {"a_sums": B.bn_a.bsums}))
-            pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_a.bsums), float(n * P_in), B.bn_a.mi, p[f"{q}/bn_a/gamma"],
-                   B.bn_a.coef, g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
+            # (bn_a's backward finalize is recorded below, right in front of the `a` backward: whether it also builds that launch's
+            # panel is known there; the shortcut launches in between do not depend on it)
             # a
             wa = hip.PwWgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(B.x), None, None, ACT_NONE,
                                  _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, 1, dt)
             nxt = pl.gbuf[1 - cur][:B.x.numel()]
             if b.has_shortcut_conv:
-                pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", B.bn_r.bsums), float(n * P_out), B.bn_r.mi,
-                       p[f"{pre}/bn_r/gamma"], B.bn_r.coef, g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
+                rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
                 wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
                                      _p(g[f"{pre}/residual/kernel"]), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
                 pl.rec_side(Bk, "x3d_pw_wgrad", wr)
@@ -1103,7 +1117,12 @@ class X3D:
             fields = {} if rc is None else {"rc_sums": rc[2]}
             chosen = ft if ft is not None else (stem_ft if stem_ft is not None else (fa if self._fuse_pw_bwd and supported(fa) else None))
             B.a_bwd_rc = rc is not None and chosen is not None
-            if B.a_bwd_rc:
+            if B.a_bwd_rc and merge_rc:
+                rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner,
+                                    prep=(p[f"{q}/a/kernel"], rc[0], rc[1], b.cin))
+            else:
+                rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
+            if B.a_bwd_rc and not merge_rc:
                 pl.rec(Bk, "x3d_pw_bwd_rc_prepare", p[f"{q}/a/kernel"], B.bn_a.coef, rc[0], rc[1], b.inner, b.cin, dt)
             if ft is not None:
                 prev.tail_folded = True
@@ -1117,8 +1136,11 @@ class X3D:
                 pl.rec_side(Bk, "x3d_pw_wgrad", wa)
                 pl.rec(Bk, "x3d_pw_dgrad", da)
             if B.a_bwd_rc:
-                pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rc[2]), p[f"{q}/a/kernel"], B.bn_a.coef, g[f"{q}/a/kernel"],
-                       b.inner, b.cin, dt)
+                if merge_rc:    # dW rides on the next BatchNorm-backward finalize (the block below's bn_c, or the stem's)
+                    pending_fin["job"] = (rc[2], p[f"{q}/a/kernel"], B.bn_a.coef, g[f"{q}/a/kernel"], b.inner, b.cin)
+                else:
+                    pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rc[2]), p[f"{q}/a/kernel"], B.bn_a.coef, g[f"{q}/a/kernel"],
+                           b.inner, b.cin, dt)
             cur = 1 - cur
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt
@@ -1133,8 +1155,8 @@ class X3D:
         # gradient of the widest tensor of the network is neither written nor read back
         if not getattr(pl, "stem_bwd_folded", False):
             pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
-        pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b1.bsums), float(n * P1), b1.mi, p["conv1/bn/gamma"], b1.coef,
-               g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
+        rec_bn_bwd_finalize(b1, n * P1, p["conv1/bn/gamma"], g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
+        assert pending_fin["job"] is None
         pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
         pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,

@@ -238,6 +238,17 @@ def pw_bwd_rc(g, x, w, coef, dx, dw, epi, add, tail_c=None, tail_r=None, tail_su
     return True
 
 
+def bn_bwd_finalize_rc(sums, count, mi, gamma, coef, dgamma, dbeta, dtype, prep=None, fin=None):
+    """x3d_bn_bwd_finalize_rc: the BatchNorm-backward finalize + (prep = (w, panel, c0)) the recomputed-output panel of the conv
+    in front of this BatchNorm + (fin = (sums, w, coef, dw)) the pending dW of an earlier x3d_pw_bwd, one launch."""
+    w, panel, c0 = prep if prep is not None else (None, None, None)
+    fs, fw, fc, fdw = fin if fin is not None else (None, None, None, None)
+    _chk(sums, mi, gamma, coef, dgamma, dbeta, w, panel, c0, fs, fw, fc, fdw)
+    hip.call("x3d_bn_bwd_finalize_rc", ptr(sums), float(count), ptr(mi), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta),
+             gamma.numel(), ptr(w), ptr(panel), ptr(c0), 0 if w is None else w.shape[1], ptr(fs), ptr(fw), ptr(fc), ptr(fdw),
+             0 if fw is None else fw.shape[0], 0 if fw is None else fw.shape[1], hip.dtype_code(dtype))
+
+
 def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
     """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points."""
     _chk(g, yraw, coef, x, dw, in_ss, in_gate)
