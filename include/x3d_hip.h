@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 124
+#define X3D_ABI_VERSION 125
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -239,6 +239,10 @@ typedef struct {
   const void* rc_panel;        /* x3d_pw_bwd_rc_panel_elems(Cout, Cin) elements of the storage type, 16-byte aligned */
   const float* rc_c0;          /* [Cin] */
   float* rc_sums;              /* x3d_pw_bwd_rc_sums_elems(Cout, Cin) floats */
+  /* ... of a strided shortcut conv (reference model.py:360-367; rc_panel form only, epi = X3D_EPI_STORE: dx [N][Cin][T][H][W] is
+   * the gradient at the SAMPLED pixels, the operand of the `a` backward's X3D_EPI_ADD_STRIDED): x_stride = 2, x is the block
+   * input [N][Cin][T][xH][xW] with H = ceil(xH / 2), W = ceil(xW / 2).  x_stride = 0 / 1: dense (x [N][Cin][T][H][W]). */
+  int x_stride, xH, xW;
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);

@@ -132,6 +132,16 @@ PW_BWD_RC = [
     (1, 40, 100, 1, 12, 12, "add", 0), (1, 48, 90, 2, 8, 16, "add_strided", 0), (3, 48, 108, 4, 20, 20, "add", 0), # ... widths off the grid, three g tiles, X3D-L planes
 ]
 
+# ... of the strided shortcut conv (x_stride = 2, epilogue STORE): N, Cin, Cout, T, xH, xW (input extents)
+PW_BWD_RC_STRIDED = [
+    (2, 24, 24, 4, 32, 32), (2, 24, 24, 2, 112, 112),          # stage 2 (gather groups of 4)
+    (1, 24, 48, 4, 28, 28), (1, 24, 48, 2, 56, 56),            # stage 3: rows of 14 outputs (groups of 2) / 28
+    (1, 48, 96, 8, 14, 14), (2, 48, 96, 4, 28, 28),            # stage 4: two row tiles of x; rows of 7 outputs (groups of 1)
+    (1, 24, 48, 2, 39, 39), (1, 24, 24, 8, 78, 78), (1, 48, 96, 2, 39, 39),
+    (1, 24, 24, 2, 12, 156), (1, 24, 48, 8, 6, 78),            # X3D-L stage 2 / 3 rows: 156 -> 78 (groups of 2), 78 -> 39 (groups of 1)            # X3D-L: odd input rows (39 -> 20: the row's last group loaded early)
+    (1, 32, 32, 2, 16, 24), (1, 20, 40, 1, 12, 16),            # X3D-XL stage 2 (Cin = Cout = 32), widths off the grid
+]
+
 # ... with the residual-tail backward of the block below folded into the epilogue (the `a` convs: ADD epilogues, panels of
 # one or two row tiles): N, Cin, Cout, T, H, W, epilogue, tail (1 = identity shortcut below, 2 = shortcut conv below)
 PW_BWD_TAIL = [
@@ -284,6 +294,14 @@ def pw_bwd_rc_struct(shape, dtype):
     return hip.PwBwdArgs(A(), None, None, None, A(), PW_DGRAD_EPI.index(epi), A(), None, None, None, None, A(), None, n, cin,
                          cout, t, h, w, _code(dtype), A() if tail else None, A() if tail == 2 else None, A() if tail else None,
                          A() if tail == 2 else None, A(), A(), A())
+
+
+def pw_bwd_rc_strided_struct(shape, dtype):
+    from x3d_tf_amd import hip
+    n, cin, cout, t, xh, xw = shape
+    A = _Addr.new
+    return hip.PwBwdArgs(A(), None, None, None, A(), 0, None, None, None, None, None, A(), None, n, cin, cout, t, (xh + 1) // 2,
+                         (xw + 1) // 2, _code(dtype), None, None, None, None, A(), A(), A(), 2, xh, xw)
 
 
 def dw_fwd_struct(shape, dtype):

@@ -53,6 +53,10 @@ def _kernel_case_names():
                 st = S.pw_bwd_rc_struct(shp, dt)
                 assert hip.load().x3d_pw_bwd_supported(st), f"the recomputed-output fused backward does not cover the registered case {shp}"
                 add(st, f"test_pw_bwd_rc[{shp}, {dt}]")
+            for shp in S.PW_BWD_RC_STRIDED:
+                st = S.pw_bwd_rc_strided_struct(shp, dt)
+                assert hip.load().x3d_pw_bwd_supported(st), f"the strided recomputed-output backward does not cover the registered case {shp}"
+                add(st, f"test_pw_bwd_rc_strided[{shp}, {dt}]")
         for shp in S.DW:
             add(S.dw_fwd_struct(shp, dt), f"test_dw3d_fwd[{shp}, {dt}]")
             add(S.dw_bwd_struct(shp, dt), f"test_dw3d_bwd[{shp}, {dt}]")

@@ -350,6 +350,45 @@ def test_pw_bwd_rc(gpu, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", S.PW_BWD_RC_STRIDED)
+def test_pw_bwd_rc_strided(gpu, dtype, shape):
+    """The strided shortcut conv's backward (reference model.py:360-371: residual 1x1x1 stride (1, 2, 2) -> bn_r) in the
+    recomputed-output form: one launch streams g and the even pixels of the block input, no raw shortcut output.  Reference as
+    in test_pw_bwd_rc, on xs = x[..., ::2, ::2]."""
+    ops = _ops()
+    n, cin, cout, t, xh, xw = shape
+    ho, wo = (xh + 1) // 2, (xw + 1) // 2
+    g_ = _gen(38)
+    gy, gyd = rnd((n, cout, t, ho, wo), dtype, g_)
+    coef = torch.randn((cout, 4), generator=g_) * 0.5
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    x, xd = rnd((n, cin, t, xh, xw), dtype, g_)
+    xs = xd[:, :, :, ::2, ::2]
+    wr = round_to(wt, dtype)
+    c = coef.double()
+    yd = torch.einsum("oc,ncthw->nothw", wr, xs)
+    dy = c[:, 0].view(1, -1, 1, 1, 1) * gyd + c[:, 1].view(1, -1, 1, 1, 1) * yd + c[:, 2].view(1, -1, 1, 1, 1)
+    dx_def = torch.einsum("oc,nothw->ncthw", wr, dy)
+    w1 = round_to((wr * c[:, 0:1]).float(), dtype)
+    mm = round_to(torch.einsum("oc,o,od->cd", wr, c[:, 1], wr).float(), dtype)
+    dx_ref = (torch.einsum("oc,nothw->ncthw", w1, gyd) + torch.einsum("cd,ndthw->ncthw", mm, xs) +
+              (wr * c[:, 2:3]).sum(0).view(1, -1, 1, 1, 1))
+    fold_err = (dx_ref - dx_def).abs().max().item() / dx_def.abs().max().item()
+    assert fold_err < (2e-2 if dtype == torch.bfloat16 else 3e-3), fold_err
+    dev = lambda v: v.to(gpu)
+    dx = torch.empty((n, cin, t, ho, wo), dtype=dtype, device=gpu)
+    dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)
+    ok = ops.pw_bwd_rc(dev(gy), dev(x), dev(wt), dev(coef), dx, dw, ops.EPI_STORE, None, x_stride=2)
+    torch.cuda.synchronize()
+    assert ok, "the strided recomputed-output form should cover this shape"
+    rt, at = tol_gemm(dtype)
+    report("dx", dx, dx_ref, rt, at * dx_ref.abs().max().item())
+    dw_ref = torch.einsum("nothw,ncthw->oc", dy, xs)
+    tol = _wtol(dtype)
+    report("dw", dw, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("cout,cin,fco,fci", [(54, 24, 108, 24), (108, 48, 54, 24), (72, 32, 72, 32), (20, 8, 127, 24)])
 def test_bn_bwd_finalize_rc_equals_the_three_launches(gpu, dtype, cout, cin, fco, fci):
     """x3d_bn_bwd_finalize_rc (finalize + panel of this layer + dW of an earlier layer in one launch) writes the same bits as

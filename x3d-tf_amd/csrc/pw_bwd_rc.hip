@@ -36,6 +36,10 @@ struct PwBwdRcArgs {
   long long P;
   int tiles_per_block;
   const void* tail_c; const void* tail_r; double* tail_sums_c; double* tail_sums_r;
+  // XS (strided shortcut conv, reference model.py:360-367): x is the block input [N][Ci][T][xH][xW], the conv reads its
+  // pixels (2h, 2w); P counts the OUTPUT points (eH x eW per frame)
+  long long Pin;
+  int xH, xW;
 };
 
 #define RC_BN 128
@@ -45,8 +49,9 @@ struct PwBwdRcArgs {
 // MT: 32-row tiles of Ci; KT: 32-row tiles of Co + 1.  MT == 2 (Ci in 33..48): the image holds 48 x rows, not 64 -- with 64
 // the 48 <-> 108 layer needs 87 KB of LDS and runs one workgroup per CU; the moment-sum MFMAs then read 16 rows past the image
 // (into the panel that follows it: finite values, landing only in discarded rows / columns of the accumulators)
-template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V>
-__global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {
+// XS: 0 = dense conv input; 4 / 2 / 1 = strided shortcut conv, outputs per aligned load of the gather (common.h).
+template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V, int XS = 0>
+__global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : 2) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
   }
 
   const int srow = tid >> 4, sunit = tid & 15;
-  hx8 rg[NVY], rx[NVX];
+  hx8 rg[NVY], rx[NVX], rx2[XS ? NVX : 1];
   unsigned ymask[TAIL ? ROWS_PT : 1];
   if constexpr (TAIL) {
 #pragma unroll
@@ -101,8 +106,13 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
 #pragma unroll
     for (int i = 0; i < NVX; i++) {
       const int m = srow + 16 * i;
-      const long long o = (m < a.Ci && p < a.P) ? ((long long)n * a.Ci + m) * a.P + p : 0;
-      rx[i] = *(const hx8*)((const T*)a.x + o);
+      if constexpr (XS) {     // the even pixels of the even rows: 8 outputs = 16 input elements in rx | rx2 (clamped: row 0, point 0)
+        const bool ok = m < a.Ci && p < a.P;
+        strided_gather16<XS>((const T*)a.x + ((long long)n * a.Ci + (ok ? m : 0)) * a.Pin, ok ? p : 0, a.xH, a.xW, a.eH, a.eW, rx[i], rx2[i]);
+      } else {
+        const long long o = (m < a.Ci && p < a.P) ? ((long long)n * a.Ci + m) * a.P + p : 0;
+        rx[i] = *(const hx8*)((const T*)a.x + o);
+      }
     }
   };
   auto commit = [&](int tile) __attribute__((always_inline)) {
@@ -123,6 +133,12 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
 #pragma unroll
     for (int i = 0; i < NVX; i++) {
       const int m = srow + 16 * i;
+      if constexpr (XS) {     // output j of the vector = gathered element 2 j
+        hx8 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] = rx[i][2 * e]; v[4 + e] = rx2[i][2 * e]; }
+        rx[i] = v;
+      }
       if (!(pin && m < a.Ci)) {
 #pragma unroll
         for (int e = 0; e < 8; e++) rx[i][e] = (H)0.f;
@@ -203,9 +219,9 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
 
     // ---- global loads of this tile's epilogue, THEN the next tile's prefetch (countable waits: pw_bwd_fused.hip)
     const int oc = (tid & 15) * 8;
-    constexpr bool EPL8 = (EPI == X3D_EPI_ADD);
+    constexpr bool EPL8 = (EPI == X3D_EPI_ADD), EPL4 = (EPI == X3D_EPI_ADD_STRIDED);
     hx8 epl8[EPL8 ? ROWS_PT : 1];
-    hx4 epl4[EPL8 ? 1 : ROWS_PT];
+    hx4 epl4[EPL4 ? ROWS_PT : 1];
     hx8 tc8[TAIL ? ROWS_PT : 1], tr8[TAILR ? ROWS_PT : 1];
 #pragma unroll
     for (int i = 0; i < ROWS_PT; i++) {
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
         const hx8 l8 = *(const hx8*)((const T*)a.add + orow);
 #pragma unroll
         for (int e = 0; e < 8; e++) epl8[i][e] = ok ? l8[e] : (H)0.f;
-      } else {
+      } else if constexpr (EPL4) {
         const int hw = a.eH * a.eW;      // per-sample point counts fit 32 bits (host check): 32-bit divisions
         const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
         const int T_ = (int)a.P / hw;
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1) ? 3 : 2) void pw
         if constexpr (EPI == X3D_EPI_ADD) {
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] += (float)epl8[i][e];
-        } else {
+        } else if constexpr (EPL4) {
           if (E4V) {   // loaded above (zeros on odd rows)
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
@@ -378,15 +394,16 @@ static inline size_t rc_lds_bytes(int MT, int KT) {
   return (size_t)ZR * RC_YP * 2 + (size_t)MT * 32 * (ZR + 8) * 2;
 }
 
-template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V = true>
+template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V = true, int XS = 0>
 static int rc_launch(PwBwdRcArgs& a, hipStream_t st) {
   if constexpr (EPI == X3D_EPI_ADD_STRIDED && E4V) {
     if ((a.eW & 7) != 0) return rc_launch<H, MT, KT, EPI, TAIL, false>(a, st);
   }
   const size_t lds = rc_lds_bytes(MT, KT);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd (recomputed output): needs %zu B of LDS", lds);
+  if constexpr (XS != 0) X3D_DESCRIBE("pw_bwd_rc_kernel<%s, %d, %d, %d, %d, s%d>", HV<H>::name, MT, KT, EPI, TAIL, XS);
   X3D_DESCRIBE("pw_bwd_rc_kernel<%s, %d, %d, %d, %d%s>", HV<H>::name, MT, KT, EPI, TAIL, E4V ? "" : ", e");
-  auto kern = pw_bwd_rc_kernel<H, MT, KT, EPI, TAIL, E4V>;
+  auto kern = pw_bwd_rc_kernel<H, MT, KT, EPI, TAIL, E4V, XS>;
   static bool attr_set = false;
   static int slots = 0;
   if (!attr_set) {
@@ -425,21 +442,38 @@ static inline bool rc_shape(int Cin, int Cout, RcShape* s) {
 
 bool pw_bwd_rc_supported(const x3d_pw_bwd_args* b) {
   if (!x3d_is_half(b->dtype) || !b->rc_panel || !b->rc_c0 || !b->x) return false;   // (rc_sums: checked at the launch, as the tail sums are)
-  if (b->epi != X3D_EPI_ADD && b->epi != X3D_EPI_ADD_STRIDED) return false;
+  if (b->epi != X3D_EPI_ADD && b->epi != X3D_EPI_ADD_STRIDED && b->epi != X3D_EPI_STORE) return false;
   RcShape s;
   if (!rc_shape(b->Cin, b->Cout, &s)) return false;
   const long long P = (long long)b->T * b->H * b->W;
   if (P % 8 || P >= (1ll << 31)) return false;
   if ((long long)b->Cin * P * 2 >= (1ll << 31)) return false;   // one sample's dx inside the 2 GB buffer-store window
-  const void* ps[] = {b->g, b->x, b->dx, b->rc_panel, b->epi == X3D_EPI_ADD ? b->add : nullptr, b->tail_c, b->tail_r};
+  const void* ps[] = {b->g, b->x_stride == 2 ? nullptr : b->x, b->dx, b->rc_panel, b->epi == X3D_EPI_ADD ? b->add : nullptr, b->tail_c, b->tail_r};
   for (const void* p : ps) if (p && ((uintptr_t)p % 16)) return false;
-  if (!b->add || (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8))) return false;
+  if (b->epi == X3D_EPI_STORE) {
+    if (b->add || b->tail_c) return false;
+  } else if (!b->add || (b->epi == X3D_EPI_ADD_STRIDED && ((uintptr_t)b->add % 8))) return false;
+  if (b->x_stride == 2) {      // the strided shortcut conv: the STORE form only (its dx is the strided-add operand of the `a` backward)
+    if (b->epi != X3D_EPI_STORE || b->xH <= 0 || b->xW <= 0 || (b->xH + 1) / 2 != b->H || (b->xW + 1) / 2 != b->W) return false;
+    if (!((s.MT == 1 && s.KT <= 2) || (s.MT == 2 && s.KT == 4))) return false;          // (the X3D shortcut shapes: 24->24, 24->48, 48->96)
+    if (strided_gather_gv(b->xW, b->W, P, b->x) == 0) return false;
+    if ((long long)b->T * b->xH * b->xW >= (1ll << 31)) return false;
+  } else if (b->x_stride > 1) return false;
   if (b->tail_r && !b->tail_c) return false;
   // (two row tiles of x: the tail's extra epilogue operands spill 96-176 bytes per lane at the 256-VGPR cap -- those layers keep
   // the separate x3d_tail_bwd pass, as they do with pw_bwd_fused.hip)
   // (measured, 48 <-> 108 @28x28 x 64 clips: 88 us + 54 us of x3d_tail_bwd against 186 us with the tail inside, 276 us with TAIL = 2)
   if (s.MT == 2 && b->tail_c) return false;
   return rc_lds_bytes(s.MT, s.KT) <= 160 * 1024;
+}
+
+template <typename H>
+static int rc_pick_strided(PwBwdRcArgs& a, int MT, int KT, int gv, hipStream_t st) {
+#define RC_XS(M_, K_, G_) if (MT == M_ && KT == K_ && gv == G_) return rc_launch<H, M_, K_, X3D_EPI_STORE, 0, true, G_>(a, st);
+  RC_XS(1, 1, 4) RC_XS(1, 1, 2) RC_XS(1, 1, 1) RC_XS(1, 2, 4) RC_XS(1, 2, 2) RC_XS(1, 2, 1) RC_XS(2, 4, 4) RC_XS(2, 4, 2) RC_XS(2, 4, 1)
+#undef RC_XS
+  x3d_set_error("pw_bwd (recomputed output, strided input): unsupported tile shape");
+  return X3D_ERR_INVALID;
 }
 
 template <typename H, int EPI>
@@ -472,6 +506,13 @@ int pw_bwd_rc(const x3d_pw_bwd_args* b, hipStream_t st) {
   a.P = (long long)b->T * b->H * b->W;
   a.tail_c = b->tail_c; a.tail_r = b->tail_r; a.tail_sums_c = b->tail_sums_c; a.tail_sums_r = b->tail_sums_r;
   const int tail = b->tail_c ? (b->tail_r ? 2 : 1) : 0;
+  if (b->x_stride == 2) {
+    a.Pin = (long long)b->T * b->xH * b->xW; a.xH = b->xH; a.xW = b->xW;
+    const int gv = strided_gather_gv(b->xW, b->W, a.P, b->x);
+    return b->dtype == X3D_F16 ? rc_pick_strided<f16>(a, s.MT, s.KT, gv, st) : rc_pick_strided<bf16>(a, s.MT, s.KT, gv, st);
+  }
+  if (b->epi == X3D_EPI_STORE)
+    return b->dtype == X3D_F16 ? rc_pick<f16, X3D_EPI_STORE>(a, s.MT, s.KT, 0, st) : rc_pick<bf16, X3D_EPI_STORE>(a, s.MT, s.KT, 0, st);
   if (b->dtype == X3D_F16)
     return b->epi == X3D_EPI_ADD ? rc_pick<f16, X3D_EPI_ADD>(a, s.MT, s.KT, tail, st) : rc_pick<f16, X3D_EPI_ADD_STRIDED>(a, s.MT, s.KT, tail, st);
   return b->epi == X3D_EPI_ADD ? rc_pick<bf16, X3D_EPI_ADD>(a, s.MT, s.KT, tail, st) : rc_pick<bf16, X3D_EPI_ADD_STRIDED>(a, s.MT, s.KT, tail, st);

@@ -1062,15 +1062,42 @@ class X3D:
                                  _p(g[f"{q}/a/kernel"]), n, b.cin, b.inner, t, B.hh, B.ww, 1, dt)
             nxt = pl.gbuf[1 - cur][:B.x.numel()]
             if b.has_shortcut_conv:
-                rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
-                wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
-                                     _p(g[f"{pre}/residual/kernel"]), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
-                pl.rec_side(Bk, "x3d_pw_wgrad", wr)
                 rt = pl.rtmp[:n * b.cin * P_out]
-                dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(p[f"{pre}/residual/kernel"]), _p(rt),
-                                     EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
-                dr.w_panel = self._wp(f"{pre}/residual/kernel", True)
-                pl.rec(Bk, "x3d_pw_dgrad", dr)
+                # the strided shortcut conv's two gradients in ONE launch over g and the even pixels of the block input, its raw
+                # output recomputed algebraically like the `a` conv's (pw_bwd_rc.hip, x_stride = 2) -- where the shape is covered
+                sr = None
+                per = int(pl.lib.x3d_pw_bwd_rc_panel_elems(b.cout, b.cin)) if (self._fuse_pw_bwd and self._rc_pw_bwd and b.stride == 2
+                                                                                and self.dtype != torch.float32) else 0
+                if per:
+                    rcr = (pl.act(per), pl.f32(b.cin), pl.acc64((int(pl.lib.x3d_pw_bwd_rc_sums_elems(b.cout, b.cin)) + 1) // 2))
+                    sr = hip.PwBwdArgs(_p(gten), None, None, None, _p(rt), EPI_STORE, None, None, None, None, None, _p(B.x), None,
+                                       n, b.cin, b.cout, t, B.ho, B.wo, dt, None, None, None, None, _p(rcr[0]), _p(rcr[1]), None,
+                                       b.stride, B.hh, B.ww)
+                    if not pl.lib.x3d_pw_bwd_supported(C.byref(sr)):
+                        sr = None
+                B.r_bwd_rc = sr is not None
+                w_r, g_r = p[f"{pre}/residual/kernel"], g[f"{pre}/residual/kernel"]
+                if sr is not None:
+                    if merge_rc:
+                        rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"],
+                                            b.cout, prep=(w_r, rcr[0], rcr[1], b.cin))
+                    else:
+                        rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
+                        pl.rec(Bk, "x3d_pw_bwd_rc_prepare", w_r, B.bn_r.coef, rcr[0], rcr[1], b.cout, b.cin, dt)
+                    pl.rec(Bk, "x3d_pw_bwd", ("field", sr, {"rc_sums": rcr[2]}))
+                    if merge_rc:     # (the bn_a finalize recorded next carries this dW)
+                        pending_fin["job"] = (rcr[2], w_r, B.bn_r.coef, g_r, b.cout, b.cin)
+                    else:
+                        pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rcr[2]), w_r, B.bn_r.coef, g_r, b.cout, b.cin, dt)
+                else:
+                    rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
+                    wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
+                                         _p(g_r), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
+                    pl.rec_side(Bk, "x3d_pw_wgrad", wr)
+                    dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(w_r), _p(rt),
+                                         EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
+                    dr.w_panel = self._wp(f"{pre}/residual/kernel", True)
+                    pl.rec(Bk, "x3d_pw_dgrad", dr)
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt),
                                      EPI_ADD_STRIDED if b.stride == 2 else EPI_ADD, _p(rt), None, None, None, None, n,
                                      b.cin, b.inner, t, B.hh, B.ww, dt)

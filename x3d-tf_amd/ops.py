@@ -209,12 +209,13 @@ def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_s
     return True
 
 
-def pw_bwd_rc(g, x, w, coef, dx, dw, epi, add, tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None):
+def pw_bwd_rc(g, x, w, coef, dx, dw, epi, add, tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None, x_stride=1):
     """Fused dgrad + wgrad of an `a` conv WITHOUT its raw output (x3d_pw_bwd with rc_panel: the conv output y = W x is
     folded algebraically into the BatchNorm backward dY = A g + B y + C).  Three launches: x3d_pw_bwd_rc_prepare (per-step panel
     [W^T diag(A) | W^T diag(B) W] and c0 = W^T C from the fp32 weights w [Cout, Cin] and coef [Cout, 4]), x3d_pw_bwd (streams
-    g and x only), x3d_pw_bwd_rc_finish (dw += from the moment sums).  Returns False (nothing launched) when the shape is
-    not covered."""
+    g and x only), x3d_pw_bwd_rc_finish (dw += from the moment sums).  x_stride = 2: the strided shortcut conv (x is the
+    block input, g / dx live at the sampled pixels; epi = EPI_STORE, add = None).  Returns False (nothing launched) when the
+    shape is not covered."""
     _chk(g, x, w, coef, dx, dw, add, tail_c, tail_r, tail_sums_c, tail_sums_r)
     n, cout, t, h, ww = g.shape
     cin = dx.shape[1]
@@ -227,7 +228,7 @@ def pw_bwd_rc(g, x, w, coef, dx, dw, epi, add, tail_c=None, tail_r=None, tail_su
     sums = torch.zeros(int(lib.x3d_pw_bwd_rc_sums_elems(cout, cin)), dtype=torch.float32, device=g.device)
     a = hip.PwBwdArgs(ptr(g), None, None, None, ptr(dx), epi, ptr(add), None, None, None, None, ptr(x), None, n, cin, cout,
                       t, h, ww, hip.dtype_code(g.dtype), ptr(tail_c), ptr(tail_r), ptr(tail_sums_c), ptr(tail_sums_r),
-                      ptr(panel), ptr(c0), ptr(sums))
+                      ptr(panel), ptr(c0), ptr(sums), x_stride, x.shape[3], x.shape[4])
     import ctypes as C
     if not lib.x3d_pw_bwd_supported(C.byref(a)):
         return False
