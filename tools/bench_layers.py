@@ -35,10 +35,11 @@ def describe(name, st, eb):
         by = eb * n * t * h * w * (2 * f["Cout"] + f["Cin"] + extra)
         return f"{f['Cout']}->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}", by
     if name == "x3d_pw_bwd":   # fused dgrad + wgrad: dY twice-read tensors once, conv input / braw once, dx written
-        extra = {1: f["Cin"], 2: f["Cin"] // 4, 3: 0}[f["epi"]]
+        extra = {0: 0, 1: f["Cin"], 2: f["Cin"] // 4, 3: 0}[f["epi"]]
         rc = bool(getattr(st, "rc_panel", None))      # recomputed-output form: the conv's raw output is not read
         by = eb * n * t * h * w * ((1 if rc else 2) * f["Cout"] + 2 * f["Cin"] + extra)
-        return f"{f['Cout']}<->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}" + (" rc" if rc else ""), by
+        xs = " s2" if getattr(st, "x_stride", 0) == 2 else ""     # strided shortcut: g, the sampled input pixels, dx
+        return f"{f['Cout']}<->{f['Cin']} @{t}x{h}x{w} epi{f['epi']}" + (" rc" if rc else "") + xs, by
     if name == "x3d_pw_wgrad":
         by = eb * n * t * ho * wo * (2 * f["Cout"] + f["Cin"])
         return f"{f['Cout']}x{f['Cin']} @{t}x{ho}x{wo}", by
