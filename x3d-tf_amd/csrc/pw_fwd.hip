@@ -1,5 +1,6 @@
 // x3d_pw_fwd: pointwise convolution forward (see pw_gemm.h)
 #include "pw_gemm_wst.h"
+#include "pw_gemm_f32r.h"
 
 template <typename H>
 static int pw_fwd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st) {
@@ -74,9 +75,13 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     return pw_fwd_bnadd(a, f->dtype, vec, v16, ovec_, pro, st);
   }
   X3D_REQUIRE(!f->out_add && !f->out_add_scale_shift, "pw_fwd: out_add needs out_scale_shift");
-  if (f->dtype == X3D_F32)
+  if (f->dtype == X3D_F32) {
+    // weights resident in LDS, activations double-buffered (pw_gemm_f32r.h); the strided shortcut keeps the per-tile kernel
+    const int rc = pro ? f32r_try<PRO_AFFINE, EPI_STATS>(a, vec, st) : f32r_try<PRO_NONE, EPI_STATS>(a, vec, st);
+    if (rc >= 0) return rc;
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);
+  }
   // 16-bit storage: bf16 / f16 matrix cores (fp32 accumulate)
   int ovec = pick_vec(eb, a.P, f->y);
   int vec16 = vec;
