@@ -96,6 +96,7 @@ PW_WGRAD = [
     (1, 24, 48, 1, 78, 78, 2, None), (1, 48, 96, 2, 39, 39, 2, None), (1, 96, 192, 2, 20, 20, 2, None),
     (1, 96, 192, 8, 14, 14, 2, None), (1, 24, 48, 8, 78, 78, 2, None), (1, 24, 24, 8, 156, 156, 2, None),
     (1, 48, 108, 1, 16, 16, 1, None), (1, 108, 48, 1, 16, 16, 1, "swish"),
+    (2, 24, 108, 3, 12, 12, 1, None), (1, 24, 216, 2, 10, 10, 1, None), (2, 54, 24, 13, 10, 10, 1, "swish"),   # fp32 tile groups 4x1 / 8x1 / 1x2 with several point chunks
     (2, 96, 216, 13, 10, 10, 1, None), (2, 216, 96, 13, 10, 10, 1, "swish"), (1, 192, 432, 13, 5, 5, 1, None),   # X3D-S stages 4 / 5: ragged rows
     (1, 432, 192, 13, 5, 5, 1, "swish"),
     (1, 24, 48, 2, 11, 23, 2, None), (1, 32, 32, 4, 9, 27, 2, None), (1, 24, 48, 8, 13, 13, 2, None),   # strided, odd input width: vector gather

@@ -19,6 +19,7 @@ struct PwWgradArgs {
 };
 
 #include "pw_wgrad_bf16.h"
+#include "pw_wgrad_f32r.h"
 
 template <typename T, int VEC, int TPW, bool XPRO, bool STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
@@ -46,59 +47,95 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
     for (int j = 0; j < 16; j++) acc[s][j] = 0.f;
 
   constexpr int VPR = BP / VEC;
+  // per-row coefficients in LDS, once per workgroup: read from global next to every staged vector they were three (A rows) /
+  // two or three (B rows) dependent loads in front of each LDS write
+  float* Ca = Bs + rowsB * LP;     // [rowsA][4]  {A, B, C} of dY = A g + B yraw + C (zeros without coef)
+  float* Cb = Ca + rowsA * 4;      // [rowsB][4]  {s, t, gate} of the X prologue
+  for (int row = tid; row < rowsA; row += 256) {
+    const int co = co0 + row;
+    const bool ok = co < a.Cout && a.coef;
+    Ca[row * 4] = ok ? a.coef[co * 4] : 1.f; Ca[row * 4 + 1] = ok ? a.coef[co * 4 + 1] : 0.f; Ca[row * 4 + 2] = ok ? a.coef[co * 4 + 2] : 0.f;
+  }
+  if constexpr (XPRO) {
+    for (int row = tid; row < rowsB; row += 256) {
+      const bool ok = row < a.Cin;
+      Cb[row * 4] = ok ? a.xcoef[row * 2] : 0.f; Cb[row * 4 + 1] = ok ? a.xcoef[row * 2 + 1] : 0.f;
+      Cb[row * 4 + 2] = (ok && a.xgate) ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
+    }
+  }
+  constexpr int UX = 4;            // vectors per thread and round, their loads issued together (the rolled loop waited for each in turn)
   for (int step = s_begin; step < s_end; ++step) {
     const long long p0 = (long long)step * BP;
     __syncthreads();
-    for (int v = tid; v < rowsA * VPR; v += 256) {
-      const int row = v / VPR, pv = v - row * VPR;
-      const int co = co0 + row;
-      const long long p = p0 + (long long)pv * VEC;
-      float val[VEC];
-      if (co < a.Cout && p < a.P) {
-        const long long o = ((long long)n * a.Cout + co) * a.P + p;
-        VecIO<T, VEC>::load((const T*)a.g + o, val);
-        if (a.coef) {
-          float y2[VEC];
-          VecIO<T, VEC>::load((const T*)a.yraw + o, y2);
-          const float A = a.coef[co * 4], B = a.coef[co * 4 + 1], C = a.coef[co * 4 + 2];
+    for (int base = 0; base < rowsA * VPR; base += 256 * UX) {
+      float gv[UX][VEC], yv[UX][VEC];
 #pragma unroll
-          for (int e = 0; e < VEC; e++) val[e] = A * val[e] + B * y2[e] + C;
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        const int row = v / VPR, pv = v - row * VPR;
+        const int co = co0 + row;
+        const long long p = p0 + (long long)pv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { gv[u][e] = 0.f; yv[u][e] = 0.f; }
+        if (v < rowsA * VPR && co < a.Cout && p < a.P) {
+          const long long o = ((long long)n * a.Cout + co) * a.P + p;
+          VecIO<T, VEC>::load((const T*)a.g + o, gv[u]);
+          if (a.coef) VecIO<T, VEC>::load((const T*)a.yraw + o, yv[u]);
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; e++) val[e] = 0.f;
       }
 #pragma unroll
-      for (int e = 0; e < VEC; e++) As[row * LP + pv * VEC + e] = val[e];
-    }
-    for (int v = tid; v < rowsB * VPR; v += 256) {
-      const int row = v / VPR, pv = v - row * VPR;
-      const long long p = p0 + (long long)pv * VEC;
-      float val[VEC];
-      if (row < a.Cin && p < a.P) {
-        if constexpr (STRIDED) {
-          const long long hw = (long long)a.Ho * a.Wo;
-          const long long t = p / hw;
-          const int rem = (int)(p - t * hw);
-          const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-          const long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
-          val[0] = to_f<T>(((const T*)a.x)[((long long)n * a.Cin + row) * a.Pin + src]);
-        } else {
-          VecIO<T, VEC>::load((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p, val);
-        }
-        if constexpr (XPRO) {
-          const float s = a.xcoef[row * 2], t = a.xcoef[row * 2 + 1];
-          const float g = a.xgate ? a.xgate[(long long)n * a.Cin + row] : 1.0f;
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        if (v >= rowsA * VPR) continue;
+        const int row = v / VPR, pv = v - row * VPR;
+        const long long p = p0 + (long long)pv * VEC;
+        const bool ok = co0 + row < a.Cout && p < a.P;
+        const float A = Ca[row * 4], B = Ca[row * 4 + 1], C = Ca[row * 4 + 2];
 #pragma unroll
-          for (int e = 0; e < VEC; e++) val[e] = (s * val[e] + t) * g;
+        for (int e = 0; e < VEC; e++) As[row * LP + pv * VEC + e] = ok ? (A * gv[u][e] + B * yv[u][e] + C) : 0.f;
+      }
+    }
+    for (int base = 0; base < rowsB * VPR; base += 256 * UX) {
+      float xv[UX][VEC];
+#pragma unroll
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        const int row = v / VPR, pv = v - row * VPR;
+        const long long p = p0 + (long long)pv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) xv[u][e] = 0.f;
+        if (v < rowsB * VPR && row < a.Cin && p < a.P) {
+          if constexpr (STRIDED) {
+            const long long hw = (long long)a.Ho * a.Wo;
+            const long long t = p / hw;
+            const int rem = (int)(p - t * hw);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const long long src = (t * a.H + (long long)ho * a.stride) * a.W + (long long)wo * a.stride;
+            xv[u][0] = to_f<T>(((const T*)a.x)[((long long)n * a.Cin + row) * a.Pin + src]);
+          } else {
+            VecIO<T, VEC>::load((const T*)a.x + ((long long)n * a.Cin + row) * a.Pin + p, xv[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UX; u++) {
+        const int v = base + u * 256 + tid;
+        if (v >= rowsB * VPR) continue;
+        const int row = v / VPR, pv = v - row * VPR;
+        const long long p = p0 + (long long)pv * VEC;
+        const bool ok = row < a.Cin && p < a.P;
+        float val[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) val[e] = xv[u][e];
+        if constexpr (XPRO) {
+          const float s_ = Cb[row * 4], t_ = Cb[row * 4 + 1], g_ = Cb[row * 4 + 2];
+#pragma unroll
+          for (int e = 0; e < VEC; e++) val[e] = (s_ * val[e] + t_) * g_;
           act_vec<VEC>(val, a.xact);
         }
-      } else {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) val[e] = 0.f;
+        for (int e = 0; e < VEC; e++) Bs[row * LP + pv * VEC + e] = ok ? val[e] : 0.f;
       }
-#pragma unroll
-      for (int e = 0; e < VEC; e++) Bs[row * LP + pv * VEC + e] = val[e];
     }
     __syncthreads();
 #pragma unroll
@@ -147,7 +184,7 @@ static int pw_wgrad_launch(PwWgradArgs& a, hipStream_t st) {
   if (spb > steps_per_n) spb = (int)steps_per_n;
   a.steps_per_block = spb;
   const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
-  const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * 33 * sizeof(float);
+  const size_t lds = (size_t)(a.mt_per_group + a.nt_total) * 32 * (33 + 4) * sizeof(float);   // tiles + the coefficient tables
   X3D_DESCRIBE("pw_wgrad_kernel<float, %d, %d, %d, %d>", VEC, TPW, (int)XPRO, (int)STRIDED);
   auto kern = pw_wgrad_kernel<T, VEC, TPW, XPRO, STRIDED>;
   if (lds > 48 * 1024) {
@@ -209,7 +246,17 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   a.ragged = (pw_ragged_rows(a.P, eb) &&
               (((uintptr_t)w->g | (uintptr_t)w->yraw | (uintptr_t)w->x) % 16) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (w->dtype == X3D_F32) return pw_wgrad_dispatch<float>(a, vec, xpro, st);
+  if (w->dtype == X3D_F32) {
+    if (a.stride == 1 && a.P >= 4 && x3d_env_int("X3D_PW_F32R", 1) != 0) {      // tile groups of <= 8, long double-buffered runs (pw_wgrad_f32r.h)
+      PwWgradRArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.g = a.g; ra.yraw = a.yraw; ra.coef = a.coef; ra.x = a.x; ra.xcoef = a.xcoef; ra.xgate = a.xgate; ra.xact = a.xact;
+      ra.dw = a.dw; ra.N = a.N; ra.Cout = a.Cout; ra.Cin = a.Cin; ra.P = a.P;
+      const int rc = xpro ? wgrad_f32r_pick<true>(ra, st) : wgrad_f32r_pick<false>(ra, st);
+      if (rc >= 0) return rc;
+    }
+    return pw_wgrad_dispatch<float>(a, vec, xpro, st);
+  }
   // bf16 storage: bf16 matrix cores; v2 = aligned fast path, v1 = generic (odd point counts / widths)
   if (w->dtype == X3D_F16) {
     const int rc = pw_wgrad_v2_dispatch<f16>(a, vec, xpro, st);
