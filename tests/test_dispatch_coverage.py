@@ -25,9 +25,9 @@ def _kernel_case_names():
             add(S.pw_fwd_struct(shp, dt, False), f"test_pw_fwd[{shp}, {dt}]")
             if half:
                 add(S.pw_fwd_struct(shp, dt, True), f"test_pw_fwd[{shp}, {dt}, panel]")
-        if half:
-            for shp in S.PW_FWD_TAIL:
-                add(S.pw_fwd_struct(shp, dt, False), f"test_pw_fwd_tail[{shp}, {dt}]")
+        for shp in S.PW_FWD_TAIL:
+            add(S.pw_fwd_struct(shp, dt, False), f"test_pw_fwd_tail[{shp}, {dt}]")
+            if half:
                 add(S.pw_fwd_struct(shp, dt, True), f"test_pw_fwd_tail[{shp}, {dt}, panel]")
         for shp in S.PW_FWD_INFER:
             add(S.pw_fwd_infer_struct(shp, dt, False), f"test_pw_fwd_infer[{shp}, {dt}]")

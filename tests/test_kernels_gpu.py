@@ -108,7 +108,7 @@ def test_pw_fwd(gpu, dtype, shape, panel):
 
 
 @pytest.mark.parametrize("panel", [False, True])
-@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", S.PW_FWD_TAIL)
 def test_pw_fwd_tail(gpu, dtype, shape, panel):
     """x3d_pw_fwd with the residual tail of the block below folded into its prologue (in_add / in_store): x is that block's
@@ -116,6 +116,8 @@ def test_pw_fwd_tail(gpu, dtype, shape, panel):
     the block's output: the shortcut conv, the next tail and the backward pass read it) and multiplied.  y against the fp64
     formula at the storage tolerance, bit-identical to what x3d_tail_fwd stores up to one rounding of the fused affine; the
     conv against the oracle on the stored y."""
+    if panel and dtype == torch.float32:
+        pytest.skip("weight panels exist for the 16-bit storage types only")
     ops, O = _ops(), _oracle()
     n, cin, cout, t, h, w, stride, pro = shape
     g = _gen(19)

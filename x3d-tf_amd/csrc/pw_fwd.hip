@@ -21,7 +21,14 @@ int pw_fwd_affst(PwGemmArgs& a, int dtype, int vec, int ovec, hipStream_t st);
 // storage, stride 1, BN + ReLU prologue without a gate, training epilogue
 extern "C" int x3d_pw_fwd_tail_supported(const x3d_pw_fwd_args* f) {
   if (!f || !f->in_store || !f->in_scale_shift || (!f->in_add && f->in_add_scale_shift)) return 0;
-  if (f->dtype == X3D_F32 || f->stride != 1 || f->in_gate || f->in_act != X3D_ACT_RELU || f->out_scale_shift) return 0;
+  if (f->stride != 1 || f->in_gate || f->in_act != X3D_ACT_RELU || f->out_scale_shift) return 0;
+  if (f->dtype == X3D_F32) {      // fp32 storage: the resident-weights kernel carries the fold (pw_gemm_f32r.h) where it covers the layer
+    PwGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = f->Cin; a.M = f->Cout; a.stride = 1; a.P = (long long)f->T * f->H * f->W;
+    int MT, NT;
+    return (f32r_enabled() && a.P >= 4 && f32r_shape(a, 2, &MT, &NT)) ? 1 : 0;
+  }
   return 1;
 }
 
@@ -59,6 +66,11 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     int v16 = vt;
     if (((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->in_add % 16) == 0 && ((uintptr_t)f->in_store % 16) == 0 &&
         ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) v16 = ot = 8;
+    if (f->dtype == X3D_F32) {
+      const int rc = f->in_add ? f32r_try<PRO_TAIL, EPI_STATS>(a, 4, st) : f32r_try<PRO_AFFST, EPI_STATS>(a, 4, st);
+      X3D_REQUIRE(rc >= 0, "pw_fwd: folded tail in fp32 storage: layer not covered by the resident-weights kernel");
+      return rc;
+    }
     return f->in_add ? pw_fwd_tail(a, f->dtype, v16, ot, st) : pw_fwd_affst(a, f->dtype, v16, ot, st);
   }
   if (f->out_scale_shift) {      // inference epilogue: folded BN + residual Add + activation on the accumulators

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
   constexpr int BM = MT * 32, BN = NT * 32, KC = F32R_KC, NW = F32R_THREADS / 64;
   constexpr int NTILE = MT * NT, TPW = (NTILE + NW - 1) / NW;
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
-  constexpr bool TWO = PRO == PRO_BNBWD;
+  constexpr bool TWO = (PRO == PRO_BNBWD) || (PRO == PRO_TAIL);    // a second streamed tensor (a.x2)
+  constexpr bool SIDE = (PRO == PRO_TAIL) || (PRO == PRO_AFFST);   // the activated input is also stored (a.ystore): the folded tail / stem BN
   constexpr int VPR = BN / VEC;                              // staging vectors per k row
   constexpr int NXV = KC * VPR / F32R_THREADS;               // ... per thread and chunk
   static_assert(KC * VPR % F32R_THREADS == 0, "chunk must divide over the workgroup");
@@ -108,9 +109,12 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
       for (int k = tid; k < Kp; k += F32R_THREADS) {
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
         if (k < a.K) {
-          if constexpr (PRO == PRO_AFFINE) {
+          if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFST) {
             c0 = a.coef[k * 2]; c1 = a.coef[k * 2 + 1];
             c2 = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
+          } else if constexpr (PRO == PRO_TAIL) {   // s_c * x + (s_r | 1) * x2 + (t_c + t_r | 0), then ReLU (pw_gemm_bf16.h)
+            c0 = a.coef[k * 2]; c1 = a.coef2 ? a.coef2[k * 2] : 1.0f;
+            c2 = a.coef[k * 2 + 1] + (a.coef2 ? a.coef2[k * 2 + 1] : 0.f);
           } else {
             c0 = a.coef[k * 4]; c1 = a.coef[k * 4 + 1]; c2 = a.coef[k * 4 + 2];
           }
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
         if (VEC == 1 || p + VEC <= a.P) {
           // (rows of P % 4 != 0 points -- 13 frames of 5 x 5 -- start at any 4-byte address: the compute queues run in unaligned
           // access mode, so the 16-byte loads stay; the scalar staging form took twice the time per chunk)
-          pw_load_raw<T, VEC, PRO, false>(a, n, k, p, xr[i], yr[TWO ? i : 0]);
+          pw_load_raw<T, VEC, TWO ? PRO_BNBWD : PRO_NONE, false>(a, n, k, p, xr[i], yr[TWO ? i : 0]);
         } else {            // the row ends inside this vector: its elements one by one
           const long long o = ((long long)n * a.K + k) * a.Pin + p;
 #pragma unroll
@@ -182,7 +186,23 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
 #pragma unroll
       for (int e = 0; e < VEC; e++) val[e] = xr[i][e];
       if (k < a.K && p < a.P) {
-        pw_prologue<VEC, PRO>(a, Pk + k * 4, val, yr[TWO ? i : 0]);
+        if constexpr (PRO == PRO_TAIL) {
+          const float* ck = Pk + k * 4;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) val[e] = fmaxf(ck[0] * val[e] + ck[1] * yr[TWO ? i : 0][e] + ck[2], 0.f);
+        } else {
+          pw_prologue<VEC, PRO == PRO_AFFST ? PRO_AFFINE : PRO>(a, Pk + k * 4, val, yr[TWO ? i : 0]);
+        }
+        if constexpr (SIDE) {     // y of the block below (the stem), kept for its other readers: written by the first row group
+          if (blockIdx.y == 0) {
+            T* yd = (T*)a.ystore + ((long long)n * a.K + k) * a.Pin + p;
+            if (VEC == 1 || p + VEC <= a.P) VecIO<T, VEC>::store(yd, val);
+            else {
+#pragma unroll
+              for (int e = 0; e < VEC; e++) if (p + e < a.P) yd[e] = val[e];
+            }
+          }
+        }
         if (VEC > 1 && p + VEC > a.P) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) if (p + e >= a.P) val[e] = 0.f;
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     if (n != n_cur) {                   // (the registers hold RAW chunk 0 of this tile: the tables only matter from its commit on)
       flush_nc(n_cur);
-      if constexpr (PRO == PRO_AFFINE || EPI == X3D_EPI_SWISH_BWD) {
+      if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFST || EPI == X3D_EPI_SWISH_BWD) {
         __syncthreads();                // every commit / epilogue of the previous sample has read its rows
         fill_tables(n);
         __syncthreads();
