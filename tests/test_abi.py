@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.x3d_last_error() is not None
 
 
+def test_product_library_reads_no_environment():
+    """the kernel-selection A/B switches exist only in -DX3D_EXPERIMENTS builds (csrc/common.h x3d_env_int): the product
+    library must not even import getenv, so no X3D_* variable can change which kernel a launch takes"""
+    import shutil
+    import subprocess
+    import pytest
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm):
+        pytest.skip("no nm in this image")
+    from x3d_tf_amd import build
+    if "-DX3D_EXPERIMENTS" in build.FLAGS:
+        pytest.skip("experiments build")
+    out = subprocess.run([nm, "-D", "--undefined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+
+
 def test_stale_library_is_refused(tmp_path, monkeypatch):
     """a library built from another version of the header must not load (its argument lists may have shifted)"""
     import pytest

@@ -19,22 +19,17 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
-// A/B switches (X3D_* environment variables): the product library reads each ONCE (first use, cached by name); a build
-// made with -DX3D_EXPERIMENTS re-reads them on every launch, which is what the in-process A/B tools (tools/ab_mx.py,
-// tools/ab_dot.py) need.  `name` must be a string literal (the cache is keyed by its address).
+// Kernel-selection A/B switches (X3D_* environment variables): every one of them belongs to an experiment whose outcome
+// is recorded next to the call site and in DESIGN.md, so the PRODUCT library reads no environment at all -- x3d_env_int
+// is its default there.  A build made with -DX3D_EXPERIMENTS (X3D_EXPERIMENTS=1 python -m x3d-tf_amd.build; tools/ab_*)
+// reads the variable on every call, which is what the in-process A/B tools need.
 static inline int x3d_env_int(const char* name, int dflt) {
 #ifdef X3D_EXPERIMENTS
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 #else
-  struct Slot { const char* name; int val; };
-  static Slot slots[64];
-  static int nslots = 0;
-  for (int i = 0; i < nslots; i++) if (slots[i].name == name) return slots[i].val;
-  const char* e = getenv(name);
-  const int v = e ? atoi(e) : dflt;
-  if (nslots < 64) { slots[nslots].name = name; slots[nslots].val = v; nslots++; }
-  return v;
+  (void)name;
+  return dflt;
 #endif
 }
 
@@ -46,8 +41,7 @@ static inline int x3d_env_int(const char* name, int dflt) {
 // element accesses for a row's last one, sums masked by element (the scalar form it used to fall back to ran the
 // 216 -> 96 @ 13x10x10 layer in 311 us).  X3D_PW_RAGGED=0: A/B hook.
 static inline bool pw_ragged_rows(long long P, int dtype_bytes) {
-  static const char* e = getenv("X3D_PW_RAGGED");
-  return dtype_bytes == 2 && (P & 7) != 0 && P >= 8 && !(e && atoi(e) == 0);
+  return dtype_bytes == 2 && (P & 7) != 0 && P >= 8 && x3d_env_int("X3D_PW_RAGGED", 1) != 0;
 }
 
 // 8 elements of a row of which only the first nv exist (the row -- P % 8 != 0 points -- ends inside the vector): element
@@ -300,8 +294,7 @@ __device__ __forceinline__ void strided_gather16(const HT* base, long long p, in
 }
 // largest group size the gather supports for a stride-2 source of row length W sampled to Wo (0: use the scalar path)
 static inline bool strided_odd_enabled() {
-  static const char* e = getenv("X3D_PW_STRIDED_ODD");   // A/B hook: 0 = odd input widths on the scalar gather
-  return !(e && atoi(e) == 0);
+  return x3d_env_int("X3D_PW_STRIDED_ODD", 1) != 0;   // A/B hook: 0 = odd input widths on the scalar gather
 }
 static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
   if ((P % 8) != 0 && !pw_ragged_rows(P, 2)) return 0;   // (P % 8 != 0: the RAG instantiations; P % GV == 0 since GV | Wo)
@@ -321,8 +314,7 @@ static inline int strided_gather_gv(int W, int Wo, long long P, const void* x) {
 // Replicated statistics accumulators (include/x3d_hip.h): STATS_R copies of [C][2] doubles, stats_stride(C) apart.
 // A/B switch X3D_XCD_PAD=0: do not pad grid.x to a multiple of the XCD count (see pw_bwd_fused.hip, pw_wgrad_bf16.h)
 static inline bool xcd_pad_enabled() {
-  static const char* e = getenv("X3D_XCD_PAD");
-  return !(e && atoi(e) == 0);
+  return x3d_env_int("X3D_XCD_PAD", 1) != 0;
 }
 
 #define STATS_R 32

@@ -361,8 +361,8 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   // ragged rows (39, 78, 91 ... wide; stride 2 with a left pad; a misaligned tensor): flat staging with unaligned
   // 16 / 8-byte vectors and per-thread vector / scalar own strips instead of the unprefetched generic path.
   // X3D_DW_FLAT=0: A/B hook.
-  static const char* flat_env = getenv("X3D_DW_FLAT");
-  if ((cv == 0 || (flat_env && atoi(flat_env) == 2)) && !(flat_env && atoi(flat_env) == 0)) {   // 2: force (experiment)
+  const int flat_env = x3d_env_int("X3D_DW_FLAT", 1);
+  if ((cv == 0 || flat_env == 2) && flat_env != 0) {   // 2: force (experiment)
     const int rv = dw_flat_vec(sizeof(T), a.g.W < a.g.Wo ? a.g.W : a.g.Wo);
     if (rv > 0) {
       const int fa = dw_nsv_flat(a.g.RIN, a.g.W, rv, bd), fb = dw_nsv_flat(a.RB, a.g.Wo, rv, bd);
@@ -373,8 +373,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   // thread and tensor covers the tile
   // stride 2: depth 2 (144 VGPRs, 3 waves; no vmcnt(0) drain before the stores: 1066 -> 961 us at 112x112); depth 4 is
   // 160-190 VGPRs and slower.  X3D_DW_PD_S2=1 / X3D_DW_PD=1 switch back to the one-plane-ahead kernel (A/B hooks).
-  static const char* pd_s2 = getenv("X3D_DW_PD_S2");
-  const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : (pd_s2 ? atoi(pd_s2) : 2));
+  const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : x3d_env_int("X3D_DW_PD_S2", 2));
   if (dw_bwd_mx_launch(a, f->dtype, S, st) || dw_bwd_mxw_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, bf16: both gradients on the matrix cores (dw_mx.hip)
     if (x3d_describe.out) return X3D_OK;
     X3D_LAUNCH_CHECK("dw3d_bwd");
@@ -387,9 +386,8 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   }
   // stride 2, rows that only admit narrow vectors (28 x 28: 8 bytes, 14 x 14: 4 bytes): the deep-prefetch kernel with FLAT
   // 16-byte staging vectors when those bring the tile down to one vector per thread.  X3D_DW_PDFLAT=0: A/B hook.
-  static const char* pdflat_env = getenv("X3D_DW_PDFLAT");
   int pd_cv = cv, pd_nsv = nsv;
-  if (S == 2 && pd > 1 && cv > 0 && nsv > 1 && !(pdflat_env && atoi(pdflat_env) == 0)) {
+  if (S == 2 && pd > 1 && cv > 0 && nsv > 1 && x3d_env_int("X3D_DW_PDFLAT", 1) != 0) {
     const int va = 16 / (int)sizeof(T), vb = va / 2;
     if (a.g.W >= va && a.g.Wo >= vb && dw_nsv_flat(a.g.RIN, a.g.W, va, bd) <= 1 && dw_nsv_flat(a.RB, a.g.Wo, vb, bd) <= 1) {
       pd_cv = -va; pd_nsv = 1;
@@ -397,7 +395,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   }
   // ... and with ragged own strips (left pad of an odd row, strips cut by the row end: 39 -> 20, 78 -> 39), 16-bit storage
   bool pd_ragged = false;
-  if (S == 2 && sizeof(T) == 2 && pd > 1 && cv <= 0 && SW <= 2 && !(pdflat_env && atoi(pdflat_env) == 0)) {
+  if (S == 2 && sizeof(T) == 2 && pd > 1 && cv <= 0 && SW <= 2 && x3d_env_int("X3D_DW_PDFLAT", 1) != 0) {
     if (a.g.W >= 8 && a.g.Wo >= 4 && dw_nsv_flat(a.g.RIN, a.g.W, 8, bd) <= 1 && dw_nsv_flat(a.RB, a.g.Wo, 4, bd) <= 1) {
       pd_cv = -108; pd_nsv = 1; pd_ragged = true;
     }

@@ -359,8 +359,8 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
   const int items = g.Ho * g.nstrips;
   if (items <= 64) bd = 64;
   else if (items <= 128) bd = 128;
-  static const char* bd_env = getenv("X3D_DW_BD");   // A/B hook: cap the workgroup size (64 / 128): more, smaller H-tiles
-  if (bd_env && atoi(bd_env) >= 64 && atoi(bd_env) < bd) bd = atoi(bd_env);
+  const int bd_env = x3d_env_int("X3D_DW_BD", 0);   // A/B hook: cap the workgroup size (64 / 128): more, smaller H-tiles
+  if (bd_env >= 64 && bd_env < bd) bd = bd_env;
   if (g.nstrips > bd) return -1;
   int th = bd / g.nstrips;
   if (th > g.Ho) th = g.Ho;
@@ -375,10 +375,10 @@ static int dw_geom(DwGeom& g, int N, int C, int T, int H, int W, int stride, int
 }
 
 static int dw_pick_sw(int Wo) {
-  static const char* e = getenv("X3D_DW_SW14");   // experiment hook: strip width for 10 <= Wo < 20
-  if (e && Wo >= 10 && Wo < 20) return atoi(e);
-  static const char* e2 = getenv("X3D_DW_SW28");  // experiment hook: strip width for Wo >= 20
-  if (e2 && Wo >= 20) return atoi(e2);
+  const int e = x3d_env_int("X3D_DW_SW14", 0);    // experiment hook: strip width for 10 <= Wo < 20
+  if (e > 0 && Wo >= 10 && Wo < 20) return e;
+  const int e2 = x3d_env_int("X3D_DW_SW28", 0);   // experiment hook: strip width for Wo >= 20
+  if (e2 > 0 && Wo >= 20) return e2;
   return Wo >= 20 ? 4 : (Wo >= 10 ? 2 : 1);
 }
 

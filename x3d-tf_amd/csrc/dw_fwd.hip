@@ -226,10 +226,10 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   }
   // ragged rows (39, 78, 91 ... wide, or a misaligned tensor): flat staging with unaligned 16 / 8-byte vectors instead
   // of the run-time-width path.  X3D_DW_FLAT=0: A/B hook.
-  static const char* flat_env = getenv("X3D_DW_FLAT");
+  const int flat_env = x3d_env_int("X3D_DW_FLAT", 1);
   // (also when the strips are whole but the rows only admit 2 / 4-byte vectors: 39 -> 20, 23 -> 12 at stride 2)
   const bool narrow = cv > 0 && cv * sizeof(T) < 8;
-  if ((cv == 0 || narrow) && !(flat_env && atoi(flat_env) == 0)) {
+  if ((cv == 0 || narrow) && flat_env != 0) {
     const int rv = dw_flat_vec(sizeof(T), a.g.W);
     if (rv > 0 && dw_nsv_flat(a.g.RIN, a.g.W, rv, bd) <= 4) { cv = -rv; nsv = dw_nsv_flat(a.g.RIN, a.g.W, rv, bd); }
   }

@@ -741,8 +741,7 @@ __global__ __launch_bounds__(256, (BwdPdWaves<1, SW, CV>::v)) void dw3d_bwd_pd_s
 // dispatch.  Depth 4 for strips of 1 / 2 outputs (rows of < 20 outputs), depth 2 for strips of 4 (stride 1).
 // ================================================================================================
 int dw_pick_pd(int SW) {   // depth 4 for strips of 1 / 2 outputs; wider strips keep the one-plane-ahead kernels
-  static const char* e = getenv("X3D_DW_PD");
-  if (e && atoi(e) <= 1) return 1;
+  if (x3d_env_int("X3D_DW_PD", 4) <= 1) return 1;
   return SW <= 2 ? 4 : 1;
 }
 
@@ -764,9 +763,9 @@ static bool bwd_go(const DwBwdArgs& a, unsigned grid, int bd, size_t lds, hipStr
   // stride 1, strips of 2 (14x14 / 10x10 planes): the register-role form at depth 3 (164 -> 155 us at 14x14).  Strips of 1
   // (7x7) keep the copying form at depth 4: there the role form needs the 128-VGPR cap's spills and was 0.7x.
   // X3D_DW_ROLES=0: copying form everywhere (A/B hook).
-  static const char* roles = getenv("X3D_DW_ROLES");
+  const int roles = x3d_env_int("X3D_DW_ROLES", 1);
   if constexpr (S == 1 && SW == 2) {
-    if (!(roles && atoi(roles) == 0)) {
+    if (roles != 0) {
       if (x3d_describe.out) {
         snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_pd_s1_kernel<%s, %d, %d, %d, %d>", TypeName<T>::v,
                  SW, CV, 3, 6);

@@ -379,11 +379,7 @@ static bool bwd_pk_t(const DwBwdArgs& a, hipStream_t st) {
              (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7, dot ? (odd7 ? 3 : pk_env("X3D_DW_DOTMASK", 3)) : 0);
     return true;
   }
-#ifdef X3D_EXPERIMENTS   // result-changing timing hook: only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)
-  pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;
-#else
-  pa.noload = 0;
-#endif
+  pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;   // result-changing timing hook: -DX3D_EXPERIMENTS builds only
   auto kern = fixed ? dw3d_bwd_pk_kernel<T, SW, 2, 6, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10), false>
                     : dw3d_bwd_pk_kernel<T, SW, 2, 6, 0, 0, false>;
   if constexpr (SW == 4 && sizeof(T) == 2) {
@@ -645,11 +641,7 @@ static bool fwd_pk_t(const DwFwdArgs& a, hipStream_t st) {
              (fixed || odd7) ? pa.LP : 0, (fixed || odd7) ? g.H : 0, (int)odd7);
     return true;
   }
-#ifdef X3D_EXPERIMENTS   // result-changing timing hook: only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)
-  pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;
-#else
-  pa.noload = 0;
-#endif
+  pa.noload = pk_env("X3D_DW_PK_NOLOAD", 0) == 1;   // result-changing timing hook: -DX3D_EXPERIMENTS builds only
   auto kern = fixed ? dw3d_fwd_pk_kernel<T, SW, 2, 2, (SW == 4 ? 16 : 12), (SW == 4 ? 14 : 10), false>
                     : dw3d_fwd_pk_kernel<T, SW, 2, 2, 0, 0, false>;
   if constexpr (SW == 4 && sizeof(T) == 2) {

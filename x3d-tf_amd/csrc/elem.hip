@@ -393,8 +393,7 @@ extern "C" int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid = elem_grid(P, vec, N * C);
   // small planes in 16-bit storage: NB samples of one channel per workgroup (X3D_TAIL_SMALL=0: A/B hook)
-  static const char* small_env = getenv("X3D_TAIL_SMALL");
-  if (dtype != X3D_F32 && vec == 8 && P / 8 < ELEM_BLOCK && !(small_env && atoi(small_env) == 0)) {
+  if (dtype != X3D_F32 && vec == 8 && P / 8 < ELEM_BLOCK && x3d_env_int("X3D_TAIL_SMALL", 1) != 0) {
     int nb = (int)(4 * ELEM_BLOCK / (P / 8));
     if (nb > N) nb = N;
     if (nb > 16) nb = 16;

@@ -282,8 +282,7 @@ static inline size_t bw_lds_bytes() {
 // the layers this kernel is for: `c` convs whose input channels exceed one panel of the sliced kernel (129..224) with at
 // most 96 output channels -- stage 4 of X3D-XS / S / M / L (216 <-> 96)
 bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b) {
-  static const char* e = getenv("X3D_PW_BWD_WST");   // A/B switch: 0 = off
-  if (e && atoi(e) == 0) return false;
+  if (x3d_env_int("X3D_PW_BWD_WST", 1) == 0) return false;   // A/B switch: 0 = off
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw || b->epi != X3D_EPI_SWISH_BWD || b->tail_c) return false;
   if (b->Cin <= 128 || b->Cin > 224 || ((b->Cout + 15) >> 4) != 6) return false;   // (six k-steps: the panel's pitch is roundup(Co, 16) + 8)
   const long long P = (long long)b->T * b->H * b->W;

@@ -291,8 +291,7 @@ static inline size_t bwa_lds_bytes() {
 // the layers this kernel is for: `a` convs with an identity shortcut whose dY tile is too tall for the sliced kernel --
 // Co in 209..224 (fourteen k-steps), Ci <= 96: stage 4 of X3D-XS / S / M / L (96 <-> 216)
 bool pw_bwd_wsta_applies(const x3d_pw_bwd_args* b) {
-  static const char* e = getenv("X3D_PW_BWD_WSTA");   // A/B switch: 0 = off
-  if (e && atoi(e) == 0) return false;
+  if (x3d_env_int("X3D_PW_BWD_WSTA", 1) == 0) return false;   // A/B switch: 0 = off
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw || b->epi != X3D_EPI_ADD || !b->x || !b->add) return false;
   if (b->Cin <= 64 || b->Cin > 96 || ((b->Cout + 15) >> 4) != 14) return false;
   const long long P = (long long)b->T * b->H * b->W;

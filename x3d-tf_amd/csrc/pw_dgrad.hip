@@ -31,8 +31,8 @@ static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int v
   // the stationary kernel needs 132-146 VGPRs = one workgroup per CU (216 -> 96 dgrad: 58 -> 61 us)
   // (strided shortcut gradient: even image width only -- pairs of points never straddle a row)
   const int shp_ = (d->epi != X3D_EPI_ADD_STRIDED || (d->W % 2 == 0 && ((uintptr_t)d->add % 2) == 0)) ? pw_wst_shape(a, vec, ovec) : 0;
-  static const char* wst4 = getenv("X3D_PW_DGRAD_WST4");   // experiment: the K = 96 -> M <= 224 stationary kernel for the stage-4 c-conv dgrad
-  if (const int shp = (shp_ <= 2 || (shp_ == 4 && wst4 && atoi(wst4) == 1)) ? shp_ : 0) {
+  const bool wst4 = x3d_env_int("X3D_PW_DGRAD_WST4", 0) == 1;   // experiment: the K = 96 -> M <= 224 stationary kernel for the stage-4 c-conv dgrad
+  if (const int shp = (shp_ <= 2 || (shp_ == 4 && wst4)) ? shp_ : 0) {
     switch (d->epi) {
       case X3D_EPI_ADD_STRIDED: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, shp, st);
       case X3D_EPI_STORE: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_STORE>(a, shp, st);

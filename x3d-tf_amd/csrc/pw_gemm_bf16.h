@@ -610,7 +610,11 @@ static inline size_t pw_bf16_lds_bytes(int mt, int K) {
 static inline int pw_bf16_pick_mt(int M, int K) {
   const int mt = ceil_div(M, 32);
   // experiment hook: X3D_PW_MTMAP="7:4,14:7" maps a row-tile count to a panel height
-  static const char* map = getenv("X3D_PW_MTMAP");
+#ifdef X3D_EXPERIMENTS
+  const char* map = getenv("X3D_PW_MTMAP");
+#else
+  const char* map = nullptr;
+#endif
   if (map) {
     for (const char* q = map; *q;) {
       const int key = atoi(q);
@@ -671,8 +675,7 @@ static int pw_bf16_launch_cfg(PwGemmArgs& a, hipStream_t st) {
   // a wide weight panel (K*BM bf16 per workgroup, through L2) must be amortised over several tiles even if that
   // leaves fewer workgroups than slots (r01c sweep: 4 tiles is the optimum for K >= 192 with packed panels)
   int tpb_min = a.K >= 192 ? 4 : (a.K >= 96 ? 2 : 1);
-  static const char* tpb_env = getenv("X3D_PW_TPBMIN");   // experiment hook
-  if (tpb_env) tpb_min = atoi(tpb_env);
+  tpb_min = x3d_env_int("X3D_PW_TPBMIN", tpb_min);   // experiment hook
   if (tpb < tpb_min) tpb = tpb_min;
   a.tiles_per_block = tpb;
   const long long gx = ceil_div_ll(total_tiles, tpb);

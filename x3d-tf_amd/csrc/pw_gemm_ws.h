@@ -293,11 +293,11 @@ static inline size_t pw_ws_lds_bytes(int K) {
 
 // the deep, narrow layers: few 128-point tiles per launch and a wide contraction or output
 static inline bool pw_ws_applies(const PwGemmArgs& a, int vec, int ovec) {
-  static const char* e = getenv("X3D_PW_WS");   // A/B switch: 0 = never, 1 = whenever legal
-  if (e && atoi(e) == 0) return false;
+  const int e_ws = x3d_env_int("X3D_PW_WS", -1);   // A/B switch: 0 = never, 1 = whenever legal
+  if (e_ws == 0) return false;
   if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || (a.P % 8) != 0) return false;
   if (a.K > 448 || a.M > 128 * WS_MAXMT) return false;
-  if (e && atoi(e) == 1) return true;
+  if (e_ws == 1) return true;
   // measured on X3D-M stage 5 (r01g): wins where the resident-panel kernel needs 32-row panels and repeats the prologue
   // per row block (K = 432 -> M = 192: 94 -> 71 us forward, 84 -> 67 us dgrad); loses for narrow K / wide M (K = 192 ->
   // M = 432: 37 -> 60 us), where streaming all of W per 32-point tile (tiles x |W| = 265 MB through L2) is the bound

@@ -407,13 +407,13 @@ static inline size_t pw_wst_lds_bytes() {
 // workgroup's prologue overlaps the other's MFMAs): 3 = K 209..224 -> M <= 96 (3 x 1 x 14), 4 = K 81..96 -> M <= 224
 // (7 x 1 x 6), 5 = K 81..96 -> M <= 448 (7 x 2 x 6)
 static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
-  static const char* e = getenv("X3D_PW_WST");   // A/B switch: 0 = never, 1 = stage 5 only
-  if (e && atoi(e) == 0) return 0;
+  const int e_wst = x3d_env_int("X3D_PW_WST", -1);   // A/B switch: 0 = never, 1 = stage 5 only
+  if (e_wst == 0) return 0;
   if (!a.wp || vec < 8 || ovec < 8 || a.stride != 1 || a.P < 8) return 0;   // (P % 8 != 0: the RAG instantiations)
   const int ks = (a.K + 15) >> 4;
   if (ks == 27 && a.M <= 192) return 1;
   if (ks == 12 && a.M <= 448) return 2;
-  if (e && atoi(e) == 1) return 0;
+  if (e_wst == 1) return 0;
   if (ks == 14 && a.M <= 96) return 3;
   if (ks == 6 && a.M <= 224) return 4;
   if (ks == 6 && a.M <= 448) return 5;     // stage-5 block 0 `a` conv: 96 -> 432 (7 x 2 x 6)
@@ -421,8 +421,7 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   // LDS in every wave (>= 1 KB of LDS traffic per MFMA: LDS-bound below a third of the matrix-core rate) and repeats the
   // swish prologue per 32- / 64- / 96-row block; measured on 60 clips of 16x312x312 in fp16: 630 -> 280 279 us (floor 22),
   // 306 -> 136 237 us (floor 42), 280 -> 630 108 us, 136 -> 306 137 us.  Row blocks beyond NW * RB go to blockIdx.y.
-  static const char* xl = getenv("X3D_PW_WST_XL");   // A/B switch: 0 = off
-  if (xl && atoi(xl) == 0) return 0;
+  if (x3d_env_int("X3D_PW_WST_XL", 1) == 0) return 0;   // A/B switch: 0 = off
   if (ks == 20 && a.M <= 160) return 6;    // stage-4 `c`: 306 -> 136 (5 waves x 1 row block x 20 k-steps)
   if (ks == 9 && a.M <= 640) return 7;     // stage-4 `a`: 136 -> 306 (5 x 2 x 9); stage-5 block 0: 136 -> 630 in two slices
   if (ks == 40 && a.M <= 288) return 8;    // stage-5 `c`: 630 -> 280 (3 x 1 x 40, three slices)

@@ -486,15 +486,10 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   // 12-tile groups flush 12 K fp32 atomics per workgroup: 216 x 96 @ 14x14 with 242 workgroups per group 64 us, with
   // 157 (20 steps each) 58 us; the stage-5 layers (61 per group) are unaffected
   if (MG * NG > 8 && ceil_div_ll(total_steps, spb) > 160) spb = ceil_div_ll(total_steps, 160);
-  static const char* spb_env = getenv("X3D_PW_WG_SPBMIN");   // experiment hook
-  if (spb_env && spb < atoi(spb_env)) spb = atoi(spb_env);
+  const int spb_env = x3d_env_int("X3D_PW_WG_SPBMIN", 0);   // experiment hook
+  if (spb < spb_env) spb = spb_env;
   a.steps_per_block = (int)spb;
-#ifdef X3D_EXPERIMENTS   // result-changing timing hooks exist only in builds made with -DX3D_EXPERIMENTS (tools/, never the product)
-  static const char* nf_env = getenv("X3D_PW_WG_NOFLUSH");   // timing experiment: how much of the run time is the atomic flush
-  a.noflush = (nf_env && atoi(nf_env) == 1) ? 1 : 0;
-#else
-  a.noflush = 0;
-#endif
+  a.noflush = x3d_env_int("X3D_PW_WG_NOFLUSH", 0) == 1 ? 1 : 0;   // result-changing timing experiment (the atomic flush's share): -DX3D_EXPERIMENTS builds only
   long long gx = ceil_div_ll(total_steps, spb);
   if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(NTHR), lds, st, a);
@@ -513,8 +508,7 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
     // Measured (tools/ab_wgrad5.sh, X3D_PW_WG_NOFLUSH=1 for the split): the streaming part gets faster (52 -> 38 us,
     // 37 -> 31 us) but one workgroup per CU means 104 point chunks instead of 56, and the fp32 atomic flush -- 35 MB
     // instead of 19 MB -- grows from 14 to 25-28 us: 64 vs 66 us and 59 vs 52 us in total, so the 12-tile groups stay.
-    static const char* ew = getenv("X3D_PW_WG_WIDE");
-    if (ew && atoi(ew) == 1) {
+    if (x3d_env_int("X3D_PW_WG_WIDE", 0) == 1) {
       if (nt >= 4 && nt <= 6 && mt >= 10 && mt <= 14) return pw_wgrad_v2_launch<H, 7, 6, XPRO, STRIDED, 512>(a, st);
       if (mt >= 4 && mt <= 6 && nt >= 10 && nt <= 14) return pw_wgrad_v2_launch<H, 6, 7, XPRO, STRIDED, 512>(a, st);
     }
@@ -523,16 +517,14 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
     // experiment hook X3D_PW_WG_NG4=1: 128 x 128 tiles for the wide layers (stage 5: 192 x 432) halve the re-reads of
     // every dY / X row by the other tile groups, but need 232-252 VGPRs + 64 AGPRs (one workgroup per CU):
     // measured slower (80 -> 100 us), so 128 x 64 stays the default
-    static const char* e = getenv("X3D_PW_WG_NG4");
-    if (MG == 4 && nt >= 4 && e && atoi(e) == 1) return pw_wgrad_v2_launch<H, 4, 4, XPRO, STRIDED>(a, st);
+    if (MG == 4 && nt >= 4 && x3d_env_int("X3D_PW_WG_NG4", 0) == 1) return pw_wgrad_v2_launch<H, 4, 4, XPRO, STRIDED>(a, st);
   }
   if constexpr (STRIDED == 0) {
     // wide layers: every dY (+ yraw) row is staged once per N-group and every X row once per M-group, so the tile shape
     // sets the traffic: gz * (1 or 2) * Cout + gy * Cin rows of P points.  12-tile shapes (3 tiles per wave) still
     // fit two workgroups per CU; pick the cheapest of 4x2 / 4x3 / 3x4 (216 x 96: 1056 -> 624 rows, 192 x 432:
     // 3552 -> 2400, 432 x 192: 3360 -> 2496).
-    static const char* e12 = getenv("X3D_PW_WG_T12");   // A/B switch: 0 = 4x2 only
-    if (MG == 4 && nt >= 3 && !(e12 && atoi(e12) == 0)) {
+    if (MG == 4 && nt >= 3 && x3d_env_int("X3D_PW_WG_T12", 1) != 0) {   // A/B switch: 0 = 4x2 only
       const int dyr = a.coef ? 2 : 1;
       auto rows = [&](int mg, int ng) { return (long long)ceil_div(nt, ng) * dyr * a.Cout + (long long)ceil_div(mt, mg) * a.Cin; };
       const long long r42 = rows(4, 2), r43 = rows(4, 3), r34 = rows(3, 4);

@@ -756,8 +756,7 @@ extern "C" int x3d_dwt_bwd(const void* g, const void* yraw, const float* rss, co
   const int eb = dtype == X3D_F32 ? 4 : 2;
   X3D_REQUIRE((long long)T * HW * eb < (1ll << 30), "dwt_bwd: one channel slab exceeds the 1 GB buffer window");
   const int vec = pick_vec(eb, HW, g, yraw, x, dx);
-  static const char* vec_env = getenv("X3D_DWT_BWD_VEC");   // experiment hook: elements per thread (bf16: 2 or 4)
-  const int want = vec_env ? atoi(vec_env) : 4;
+  const int want = x3d_env_int("X3D_DWT_BWD_VEC", 4);   // experiment hook: elements per thread (bf16: 2 or 4)
   if (dtype == X3D_F32)
     return vec >= 2 ? dwt_bwd_kt<float, 2>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st)
                     : dwt_bwd_kt<float, 1>(g, yraw, rss, coef, x, w, dx, dw, N * C, C, T, HW, KT, st);
