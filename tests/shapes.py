@@ -189,6 +189,11 @@ DW = [
     (5, 3, 4, 7, 7, 1), (2, 2, 8, 7, 7, 1), (4, 2, 16, 7, 7, 1),          #   7x7 planes four to a tile (partial last group), T % 4 == 0
     (2, 2, 4, 12, 14, 1), (1, 2, 5, 14, 12, 1),                           #   12 / 14 rows and columns
     (2, 3, 5, 28, 28, 1), (1, 2, 4, 26, 30, 1), (2, 2, 8, 28, 26, 1),     #   H-tiled backward for rows of 26 .. 30 elements (dw3d_bwd_mxw_kernel)
+    # H- and W-tiled matrix-core backward for ragged rows (dw3d_bwd_mxg_kernel<bf16, NT, W-tiled, odd, ...>): one window of 3 column
+    # tiles (39, 45, 44), two / three W-tiles (78 = 40 + 38, 91 = 32 + 32 + 27 odd), windows of 2 column tiles (30, 29, 54 = 28 + 26,
+    # 55 = 28 + 27), both T loops, a partial last H-tile
+    (2, 3, 4, 39, 39, 1), (1, 2, 8, 78, 78, 1), (1, 2, 5, 39, 39, 1), (1, 2, 4, 36, 45, 1), (1, 2, 4, 36, 44, 1), (1, 2, 4, 28, 91, 1),
+    (1, 2, 4, 22, 30, 1), (1, 2, 4, 28, 29, 1), (2, 2, 4, 28, 54, 1), (1, 2, 5, 28, 55, 1), (1, 2, 7, 22, 78, 1),
     # ragged rows (flat staging, CV < 0): X3D-S 182-pixel test crops (91 / 46 / 23), vectors that cross rows and H-tiles,
     # rows shorter than a 16-byte vector (13 -> 7: 8-byte vectors), short planes
     (1, 2, 3, 91, 91, 1), (1, 2, 3, 91, 91, 2), (1, 2, 4, 46, 46, 1), (1, 2, 3, 23, 23, 1), (1, 2, 3, 23, 23, 2),

@@ -374,7 +374,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
   // stride 2: depth 2 (144 VGPRs, 3 waves; no vmcnt(0) drain before the stores: 1066 -> 961 us at 112x112); depth 4 is
   // 160-190 VGPRs and slower.  X3D_DW_PD_S2=1 / X3D_DW_PD=1 switch back to the one-plane-ahead kernel (A/B hooks).
   const int pd = S == 1 ? dw_pick_pd(SW) : (dw_pick_pd(1) == 1 ? 1 : x3d_env_int("X3D_DW_PD_S2", 2));
-  if (dw_bwd_mx_launch(a, f->dtype, S, st) || dw_bwd_mxw_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, bf16: both gradients on the matrix cores (dw_mx.hip)
+  if (dw_bwd_mx_launch(a, f->dtype, S, st) || dw_bwd_mxw_launch(a, f->dtype, S, st) || dw_bwd_mxg_launch(a, f->dtype, S, st)) {   // 14x14 stride-1 planes, bf16: both gradients on the matrix cores (dw_mx.hip)
     if (x3d_describe.out) return X3D_OK;
     X3D_LAUNCH_CHECK("dw3d_bwd");
     return X3D_OK;

@@ -80,6 +80,7 @@ bool dw_fwd_pk_launch(const DwFwdArgs& a, int dtype, int S, int SW, hipStream_t 
 bool dw_fwd_mx_launch(const DwFwdArgs& a, int dtype, int S, hipStream_t st);
 bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);
 bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);   // rows of 18 .. 30 elements (28 x 28, 20 x 20), H-tiled
+bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st);   // ragged rows of 26 columns and more (39, 78 ...), H- and W-tiled (dw_mxg.hip)
 
 // ---- bounds-checked buffer accesses of BYTES (2/4/8/16) per lane: an out-of-range offset (voff + soff >= the
 // resource's num_records) loads zeros / drops the store WITHOUT touching memory, so the instruction itself can be

@@ -505,8 +505,9 @@ bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
     if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, true>), grid, dim3(64), 0, st, pa);
     else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, true>), grid, dim3(64), 0, st, pa);
   } else {
-    if (exact && x3d_env_int("X3D_DW_MX_PD", 2) == 4) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 4, true, false>), grid, dim3(64), 0, st, pa);
-    else if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);
+    // (four planes in flight instead of two, <4, 4, 4>: 104.9 -> 101.8 us in isolation, 165 VGPRs; the 28 x 28 kernel 263.5 -> 269.5 us
+    // at 216 VGPRs: neither is short of loads in flight -- round 4, not kept)
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);
     else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, false>), grid, dim3(64), 0, st, pa);
   }
   return true;
@@ -761,8 +762,7 @@ bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   pa.bytes = (unsigned)bytes;
   pa.HT = HT;
   const dim3 grid((unsigned)((long long)g.C * g.N * HT));
-  if (exact && x3d_env_int("X3D_DW_MX_PD", 2) == 4) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 4, true>), grid, dim3(64), 0, st, pa);
-  else if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
+  if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
   else hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
   return true;
 }
