@@ -468,6 +468,8 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
 template <typename H, int PRO, int EPI>
 static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
   switch (shape) {
+    // (stage 5 at two workgroups per CU over two row slices -- <3, 1, 27, 2> with four waves, <7, 1, 12, 2> -- measured in round 4:
+    // forward 31 -> 48 us and 26.5 -> 29 us, dgrad 53 -> 178 / 58 us: one workgroup per CU stays)
     case 1: return pw_wst_launch_t<H, PRO, EPI, 6, 1, 27, 1>(a, st);
     case 2: return pw_wst_launch_t<H, PRO, EPI, 7, 2, 12, 1>(a, st);
     case 3: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 14, (PRO == PRO_BNBWD ? 1 : 2)>(a, st);   // BNBWD: 132-146 VGPRs (unused: pw_dgrad.hip)
