@@ -71,6 +71,7 @@ PW_FWD_INFER = [(n, ci, co, t, h, w, pro, ("identity", "conv")[i % 2], "relu")
     (2, 96, 216, 2, 14, 14, None, None, "relu"), (1, 280, 630, 1, 8, 8, None, "conv", "relu"),
     (1, 54, 24, 2, 20, 20, "swish", "identity", "relu"), (1, 108, 48, 2, 10, 10, "swish", "conv", "relu"),   # fp32 panels of 1 / 2 row tiles
     (1, 216, 96, 2, 10, 10, "swish", "identity", "relu"), (1, 432, 192, 4, 5, 5, "swish", "identity", "relu"),   # ... 3 / 4 (X3D-XS, config 1)
+    (2, 630, 280, 2, 10, 10, "swish", "conv", "relu"),    # X3D-XL stage-5 `c`: three row slices, two samples, a partial last tile (in_store form)
 ]
 
 # ---- x3d_pw_dgrad: N, Cin, Cout, T, H, W  x  epilogue -----------------------------------------------------------------
@@ -251,13 +252,15 @@ def pw_fwd_struct(shape, dtype, panel):
                          A() if panel else None)
 
 
-def pw_fwd_infer_struct(shape, dtype, panel):
+def pw_fwd_infer_struct(shape, dtype, panel, store=False):
+    """store: the in_store (= x) form test_pw_fwd_infer runs as well for 16-bit storage with a prologue"""
     from x3d_tf_amd import hip
     n, cin, cout, t, h, w, pro, res, oact = shape
     A = _Addr.new
-    return hip.PwFwdArgs(A(), A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
+    x = A()
+    return hip.PwFwdArgs(x, A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, 1, _code(dtype),
-                         A() if panel else None, out_scale_shift=A(), out_add=A() if res else None,
+                         A() if panel else None, in_store=x if store else None, out_scale_shift=A(), out_add=A() if res else None,
                          out_add_scale_shift=A() if res == "conv" else None, out_act=1 if oact == "relu" else 0)
 
 
