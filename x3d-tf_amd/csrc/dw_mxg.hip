@@ -36,6 +36,7 @@ struct DwMxgBwdArgs {
   unsigned bytes;    // whole-tensor size (buffer num_records)
   int HT, WT;        // H-tiles (of 14 rows) and W-tiles per plane
   int own_w;         // own columns of a W-tile (a multiple of 4; the last tile takes what is left)
+  int own0;          // ... of the first W-tile (it has no left halo strip, so it may own 4 columns more)
 };
 
 // element masks of a strip: `v` leading elements valid -> AND masks of its two dwords
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, 2) void dw3d_bwd_mxg_kernel(const DwMxgBwdArgs 
   const int c = nc % g.C, n = nc / g.C;
   const int H = g.H, W = g.W;
   const int r0 = ht * 14;
-  const int c_lo = wt * pa.own_w, c_hi = min(W, c_lo + pa.own_w);   // own image columns
+  const int c_lo = wt ? pa.own0 + (wt - 1) * pa.own_w : 0, c_hi = min(W, c_lo + (wt ? pa.own_w : pa.own0));   // own image columns
   const int w0 = wt ? c_lo - 4 : 0;                                  // image column of window column 0
 
   for (int i = lane; i < ((RB + 2) * TILE + 128) / 16; i += 64) ((uint4*)lds)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -305,11 +306,15 @@ __global__ __launch_bounds__(64, 2) void dw3d_bwd_mxg_kernel(const DwMxgBwdArgs 
 // Removed: only the backward, 54 multiply-adds per output and VALU-bound in the vector form, gains.)
 
 // the tiling of a plane: false when the shape is not covered
-static bool mxg_tiling(const DwGeom& g, int* NTp, int* WTp, int* own_w, int* HTp) {
+static bool mxg_tiling(const DwGeom& g, int* NTp, int* WTp, int* own_w, int* own0, int* HTp) {
   const int W = g.W, H = g.H;
   if (W < 26 || H < 12) return false;
   // the last H-tile must be worth a wave (rows 14 k + 1 .. 14 k + 7 waste more than half of it)
   if (H % 14 != 0 && H % 14 < 8) return false;
+  *HTp = ceil_div(H, 14);
+  // (78 columns as THREE windows of 32 -- own 28 + 24 + 26 -- instead of two of 48: 344 -> 468 us, 235 -> 323 us in isolation.  Fewer,
+  // wider waves win: a wave's set-up -- operands, ring zeroing, pipeline fill -- and its 29 reductions + atomics at the end are
+  // paid per wave; twice the planes per wave (T = 32 instead of 16 at the same bytes) is -9 % at 14 x 14 and -7 % at 28 x 28)
   // W-tiles of `own` columns (a multiple of 4, the last tile takes the rest).  Window columns a tile needs: the first
   // own + 1 (right halo), a middle one 4 + own + 1, the last 4 + its own columns (right of it is the zero pad)
   for (int wt = W <= 48 ? 1 : ceil_div(W, 40); wt <= 16; wt++) {
@@ -318,7 +323,7 @@ static bool mxg_tiling(const DwGeom& g, int* NTp, int* WTp, int* own_w, int* HTp
     if (last <= 0) return false;
     for (int nt = 2; nt <= 3; nt++) {
       const bool fits = wt == 1 ? W <= 16 * nt : (own + 1 <= 16 * nt && (wt == 2 || own + 5 <= 16 * nt) && 4 + last <= 16 * nt);
-      if (fits) { *NTp = nt; *WTp = wt; *own_w = own; *HTp = ceil_div(H, 14); return true; }
+      if (fits) { *NTp = nt; *WTp = wt; *own_w = own; *own0 = own; return true; }
     }
   }
   return false;
@@ -327,9 +332,9 @@ static bool mxg_tiling(const DwGeom& g, int* NTp, int* WTp, int* own_w, int* HTp
 bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
   const int e = x3d_env_int("X3D_DW_MXG", 1);   // A/B hook (experiments builds): 0 = never
-  int NT, WT, own_w, HT;
+  int NT, WT, own_w, own0, HT;
   // bf16 only: dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back
-  if (e == 0 || dtype != X3D_BF16 || S != 1 || !mxg_tiling(g, &NT, &WT, &own_w, &HT)) return false;
+  if (e == 0 || dtype != X3D_BF16 || S != 1 || !mxg_tiling(g, &NT, &WT, &own_w, &own0, &HT)) return false;
   // Only rows the vector kernels must take with ragged (flat, unaligned) staging.  Measured in isolation, vector -> this kernel:
   // 108 ch x 16 clips of 16 x 39 x 39 (X3D-L stage 3) 226.7 -> 160.5 us, 162 ch x 8 (XL) 157.3 -> 109.3; 54 ch x 16 of 78 x 78
   // (two W-tiles of 40 + 38 columns in windows of 48) 380.5 -> 361.7, 72 ch x 8 275.5 -> 242.4; but the ALIGNED 56 x 56 plane of
@@ -347,7 +352,7 @@ bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   DwMxgBwdArgs pa;
   pa.b = a;
   pa.bytes = (unsigned)bytes;
-  pa.HT = HT; pa.WT = WT; pa.own_w = own_w;
+  pa.HT = HT; pa.WT = WT; pa.own_w = own_w; pa.own0 = own0;
   const dim3 grid((unsigned)((long long)g.C * g.N * HT * WT));
 #define MXG_GO(NT_, WTL_, ODD_) do { \
     if (exact) hipLaunchKernelGGL((dw3d_bwd_mxg_kernel<bf16, NT_, WTL_, ODD_, 4, 4, 2, true>), grid, dim3(64), 0, st, pa); \
