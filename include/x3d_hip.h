@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 126
+#define X3D_ABI_VERSION 127
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -56,12 +56,18 @@ const char* x3d_last_error(void);
  * K1  stem spatial conv: tf.pad(0,1,1) + Conv3D(k=(1,3,3), s=(1,2,2), valid, no bias)
  *     reference model.py:161-166,178-184,203-204
  *     x [N][Cin][T][H][W] -> y [N][Cout][T][Ho][Wo], Ho=(H-1)/2+1.  w [Cout][Cin][3][3] fp32.
+ *     x_layout = X3D_LAYOUT_NTHWC (ABI 127): x is the caller's channels-last clip batch [N][T][H][W][Cin] itself -- the
+ *     layout of the reference's input (model.py:113) -- read in place by the matrix-core kernels (16-bit storage, Cin = 3,
+ *     W % 8 == 0, 16-byte aligned: x3d_stem_s_nthwc_supported); no x3d_nthwc_to_ncthw pass and no planar copy of the batch.
  * ------------------------------------------------------------------------------------------ */
+#define X3D_LAYOUT_NCTHW 0
+#define X3D_LAYOUT_NTHWC 1
+int x3d_stem_s_nthwc_supported(int Cin, int W, int Cout, int dtype);
 int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int Cin, int T, int H, int W,
-                   int Cout, int dtype, void* stream);
+                   int Cout, int dtype, int x_layout, void* stream);
 /* dW of the same conv (the input needs no gradient).  dy = grad wrt y.  dw [Cout][Cin][3][3] += */
 int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, int T, int H, int W,
-                     int Cout, int dtype, void* stream);
+                     int Cout, int dtype, int x_layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  stem temporal depthwise conv: tf.pad(KT/2,0,0) + Conv3D(k=(KT,1,1), groups=C, no bias)

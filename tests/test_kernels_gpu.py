@@ -884,6 +884,20 @@ def test_stem(gpu, dtype, shape):
     ops.stem_s_wgrad(x.to(gpu), dx, dws)
     torch.cuda.synchronize()
     report("stem_s_dw", dws, dws_ref, 2e-4, 2e-4 * dws_ref.abs().max().item())
+    # the clip batch channels-last, as the reference's model takes it (X3D_LAYOUT_NTHWC): the matrix-core kernels read it in
+    # place -- same products in the same order as the planar form, so the outputs are bit-identical
+    from x3d_tf_amd import hip
+    if hip.load().x3d_stem_s_nthwc_supported(3, w, c1, hip.dtype_code(dtype)):
+        xcl = x.to(gpu).permute(0, 2, 3, 4, 1).contiguous()
+        ys_cl = ops.stem_s_fwd(xcl, ws.to(gpu), channels_last=True)
+        dws_cl = torch.zeros((c1, 3, 3, 3), dtype=torch.float32, device=gpu)
+        ops.stem_s_wgrad(xcl, dx, dws_cl, channels_last=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ys_cl, ys), "channels-last stem forward differs from the planar form"
+        report("stem_s_dw channels-last", dws_cl, dws_ref, 2e-4, 2e-4 * dws_ref.abs().max().item())
+    else:
+        with pytest.raises(Exception):
+            ops.stem_s_fwd(x.to(gpu).permute(0, 2, 3, 4, 1).contiguous(), ws.to(gpu), channels_last=True)
 
 
 @pytest.mark.parametrize("dtype", S.HALF_DTYPES)

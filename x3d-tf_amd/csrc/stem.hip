@@ -47,6 +47,65 @@ __global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x
 }
 
 
+// x staging of the matrix-core stem kernels when x is channels-last ([N][T][H][W][3], 16-bit): thread (q = segment of the step,
+// kh, v) owns the 8 input pixels 2 wo0 + 8 v .. of input row 2 ho + kh - 1 -- 48 contiguous bytes, three 16-byte loads --
+// and commits its three channels to the im2col tile exactly as the channel-planar form does (even pixels -> tap kw = 1,
+// odd -> kw = 2 and, one point later, kw = 0; the pixel left of the segment for point 0 of kw = 0).
+template <typename HT>
+struct StemNhwcStage {
+  typedef typename HV<HT>::x8 hx8; typedef typename HV<HT>::x4 hx4;
+  int q, kh, v;
+  bool on;
+  hx8 r[3];
+  HT rl[3];
+  __device__ __forceinline__ void roles(int tid) {
+    q = tid / 48;
+    const int rem = tid - q * 48;
+    kh = rem >> 4; v = rem & 15;
+    on = tid < 192;
+  }
+  __device__ __forceinline__ void issue(const HT* __restrict__ x, int s0, int seg_end, int nws, int Ho, int Tn, int H, int W) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) r[i][e] = (HT)0.f;
+      rl[i] = (HT)0.f;
+    }
+    const int seg = s0 + q;
+    if (!on || seg >= seg_end) return;
+    const int ws = seg % nws;
+    int tmp = seg / nws;
+    const int ho = tmp % Ho; tmp /= Ho;
+    const int t = tmp % Tn;
+    const int n = tmp / Tn;
+    const int wo0 = ws * 64;
+    const int hi = 2 * ho + kh - 1;
+    if (hi >= 0 && hi < H && 2 * wo0 + 8 * v < W) {
+      const HT* src = x + ((((long long)n * Tn + t) * H + hi) * W + 2 * wo0 + 8 * v) * 3;
+      r[0] = *(const hx8*)src; r[1] = *(const hx8*)(src + 8); r[2] = *(const hx8*)(src + 16);
+      if (v == 0 && wo0 > 0) { rl[0] = src[-3]; rl[1] = src[-2]; rl[2] = src[-1]; }
+    }
+  }
+  __device__ __forceinline__ HT at(int i) const { return i < 8 ? r[0][i] : (i < 16 ? r[1][i - 8] : r[2][i - 16]); }
+  __device__ __forceinline__ void commit(HT* Bs, int LP) const {
+    if (!on) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int tap1 = c * 9 + kh * 3 + 1;
+      hx4 ev, od;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { ev[e] = at(3 * (2 * e) + c); od[e] = at(3 * (2 * e + 1) + c); }
+      *(hx4*)&Bs[tap1 * LP + q * 64 + 4 * v] = ev;          // kw = 1: wi = 2wo
+      *(hx4*)&Bs[(tap1 + 1) * LP + q * 64 + 4 * v] = od;    // kw = 2: wi = 2wo + 1
+      HT* k0 = &Bs[(tap1 - 1) * LP + q * 64 + 4 * v + 1];    // kw = 0: wi = 2wo - 1  (one point later)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (4 * v + 1 + e < 64) k0[e] = od[e];
+      if (v == 0) Bs[(tap1 - 1) * LP + q * 64] = rl[c];
+    }
+  }
+};
+
 // ---- bf16 fast path of the stem forward on the matrix cores -----------------------------------------------
 // The direct kernel above is VALU bound (648 FMAs + 27 two-byte loads per output position: 0.56 ms on X3D-M B=64
 // against ~0.23 ms of HBM time).  Here the im2col tile [tap][point] is built in LDS exactly as in the weight-gradient
@@ -55,7 +114,11 @@ __global__ __launch_bounds__(256) void stem_s_fwd_kernel(const T* __restrict__ x
 // is two k-steps of v_mfma_f32_32x32x16_bf16 per 32 points: A = the 32x32 weight tile (bf16, held in registers for
 // the whole kernel), B = the im2col tile read transposed (ds_read_b64_tr_b16).  One wave = one 64-column segment of
 // an output row; its 24x64 result goes through a private LDS slab so that the stores are 16-byte row pieces.
-template <typename HT, int SEGS>
+// NHWC = true: x is the caller's channels-last clip batch [N][T][H][W][3] itself (the reference's input layout): a thread
+// loads the 8 pixels x 3 channels of its vector as three 16-byte loads and separates the channels in registers, so the
+// stand-alone layout pass (x3d_nthwc_to_ncthw: 2 x 308 MB per X3D-M step) is not needed.  Staging roles then are
+// (segment, kh, vector) -- 4 x 3 x 16 = 192 threads, each committing its three channels.
+template <typename HT, int SEGS, bool NHWC>
 __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restrict__ x, const float* __restrict__ w,
                                                               HT* __restrict__ y, int Cin, int Cout, int Tn, int H,
                                                               int W, int Ho, int Wo, int nws, int total_segs,
@@ -97,7 +160,10 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restri
   const bool xrow_ok = xrow < Cin * 3;
   hx8 rx[SEGS];
   HT rl[SEGS];
+  StemNhwcStage<HT> st3;
+  st3.roles(tid);
   auto issue = [&](int s0) {
+    if constexpr (NHWC) { st3.issue(x, s0, seg_end, nws, Ho, Tn, H, W); return; }
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
       const int seg = s0 + q;
@@ -121,6 +187,7 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restri
     }
   };
   auto commit = [&]() {
+    if constexpr (NHWC) { st3.commit(Bs, LP); return; }
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
       if (xrow_ok) {
@@ -194,8 +261,13 @@ __global__ __launch_bounds__(256) void stem_s_fwd_bf16_kernel(const HT* __restri
   }
 }
 
+// the matrix-core kernels take the clip batch channels-last as it is: 16-bit storage, three channels, rows of whole vectors
+extern "C" int x3d_stem_s_nthwc_supported(int Cin, int W, int Cout, int dtype) {
+  return (x3d_is_half(dtype) && Cin == 3 && (W % 8) == 0 && Cout <= 32) ? 1 : 0;
+}
+
 extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int Cin, int T, int H, int W,
-                              int Cout, int dtype, void* stream) {
+                              int Cout, int dtype, int x_layout, void* stream) {
   X3D_REQUIRE(x && w && y && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_fwd: bad args");
   X3D_REQUIRE(Cin == 3, "stem_s_fwd: Cin must be 3 (DATA.NUM_INPUT_CHANNELS)");
   X3D_REQUIRE(Cout == 24 || Cout == 32 || Cout == 8 || Cout == 16, "stem_s_fwd: unsupported Cout %d", Cout);
@@ -204,6 +276,10 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
   dim3 grid(ceil_div(Ho * Wo, 256), T, N);
   hipStream_t st = (hipStream_t)stream;
   // (W % 8 == 0: input rows are whole 16-byte vectors, output rows whole 8-byte ones -- W = 312 has Wo = 156 = 19.5 vectors)
+  X3D_REQUIRE(x_layout == X3D_LAYOUT_NCTHW || x_layout == X3D_LAYOUT_NTHWC, "stem_s_fwd: bad x_layout");
+  const bool nhwc = x_layout == X3D_LAYOUT_NTHWC;
+  X3D_REQUIRE(!nhwc || (x3d_stem_s_nthwc_supported(Cin, W, Cout, dtype) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0),
+              "stem_s_fwd: channels-last x needs 16-bit storage, W %% 8 == 0 and 16-byte aligned tensors (x3d_stem_s_nthwc_supported)");
   if (x3d_is_half(dtype) && (W % 8) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && Cout <= 32) {
     // matrix-core path (weights rounded to bf16 like every pointwise conv): rows of x / y 16-byte aligned
     constexpr int SEGS = 4;
@@ -214,7 +290,7 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
       int nb = 0, dev = 0, cus = 256;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_fwd_bf16_kernel<bf16, SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_fwd_bf16_kernel<bf16, SEGS, false>, 256, 0) != hipSuccess || nb < 1) nb = 2;
       slots = nb * cus;
     }
     long long spb2 = ceil_div_ll(total_segs, slots);
@@ -222,12 +298,11 @@ extern "C" int x3d_stem_s_fwd(const void* x, const float* w, void* y, int N, int
     spb2 = ceil_div_ll(spb2, SEGS) * SEGS;
     const long long gx2 = ceil_div_ll(total_segs, spb2);
     X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_fwd: too many row segments");
-    if (dtype == X3D_F16)
-      hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<f16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const f16*)x, w, (f16*)y,
-                         Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
-    else
-      hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<bf16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x, w, (bf16*)y,
-                         Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+#define STEM_FWD(TT, NHWC_) hipLaunchKernelGGL((stem_s_fwd_bf16_kernel<TT, SEGS, NHWC_>), dim3((unsigned)gx2), dim3(256), 0, st, (const TT*)x, w, \
+                                               (TT*)y, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2)
+    if (dtype == X3D_F16) { if (nhwc) STEM_FWD(f16, true); else STEM_FWD(f16, false); }
+    else { if (nhwc) STEM_FWD(bf16, true); else STEM_FWD(bf16, false); }
+#undef STEM_FWD
     X3D_LAUNCH_CHECK("stem_s_fwd");
     return X3D_OK;
   }
@@ -324,7 +399,7 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_kernel(const T* __restrict__
 //     one point) kw=0.  That IS the im2col tile [tap][point], bf16, k-contiguous -- the B operand;
 //   * one v_mfma_f32_32x32x16_bf16 tile D[co][tap] per wave (wave = segment), summed across the four waves in LDS
 //     and added to dW with <= Cout*Cin*9 atomics per workgroup.
-template <typename HT, int SEGS>
+template <typename HT, int SEGS, bool NHWC>
 __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __restrict__ x, const HT* __restrict__ dy,
                                                                 float* dw, int Cin, int Cout, int Tn, int H, int W,
                                                                 int Ho, int Wo, int nws, int total_segs,
@@ -357,7 +432,10 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __rest
   hx8 rd[SEGS], rx[SEGS];
   HT rl[SEGS];
   bool okd[SEGS], okx[SEGS];
+  StemNhwcStage<HT> st3;
+  st3.roles(tid);
   auto issue = [&](int s0) {
+    if constexpr (NHWC) st3.issue(x, s0, seg_end, nws, Ho, Tn, H, W);
 #pragma unroll
     for (int q = 0; q < SEGS; q++) {
       const int seg = s0 + q;
@@ -387,7 +465,7 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __rest
         }
       }
       const int hi = 2 * ho + xkh - 1;
-      if (xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
+      if (!NHWC && xrow_ok && hi >= 0 && hi < H && 2 * wo0 + 8 * xv < W) {
         const HT* src = x + ((((long long)n * Cin + xci) * Tn + t) * H + hi) * W + 2 * wo0 + 8 * xv;
         rx[q] = *(const hx8*)src;
         if (xv == 0 && wo0 > 0) rl[q] = src[-1];
@@ -402,7 +480,8 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __rest
         const int row = tid >> 3, v = tid & 7;
         *(hx8*)&As[row * LP + q * 64 + 8 * v] = rd[q];   // zeros where invalid
       }
-      if (xrow_ok) {
+      if constexpr (NHWC) { if (q == 0) st3.commit(Bs, LP); }
+      else if (xrow_ok) {
         const int tap1 = xci * 9 + xkh * 3 + 1;
         hx4 ev, od;
 #pragma unroll
@@ -447,7 +526,7 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_bf16_kernel(const HT* __rest
 }
 
 extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N, int Cin, int T, int H, int W,
-                                int Cout, int dtype, void* stream) {
+                                int Cout, int dtype, int x_layout, void* stream) {
   X3D_REQUIRE(x && dy && dw && N > 0 && T > 0 && H > 0 && W > 0, "stem_s_wgrad: bad args");
   X3D_REQUIRE(Cin * 9 <= 32 && Cout <= 32, "stem_s_wgrad: needs Cin*9 <= 32 and Cout <= 32");
   X3D_REQUIRE(x3d_dtype_ok(dtype), "stem_s_wgrad: bad dtype");
@@ -460,6 +539,10 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
   if (spb > steps_per_n) spb = (int)steps_per_n;
   const long long gx = ceil_div_ll(steps_per_n, spb) * N;
   hipStream_t st = (hipStream_t)stream;
+  X3D_REQUIRE(x_layout == X3D_LAYOUT_NCTHW || x_layout == X3D_LAYOUT_NTHWC, "stem_s_wgrad: bad x_layout");
+  const bool nhwc = x_layout == X3D_LAYOUT_NTHWC;
+  X3D_REQUIRE(!nhwc || (x3d_stem_s_nthwc_supported(Cin, W, Cout, dtype) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0),
+              "stem_s_wgrad: channels-last x needs 16-bit storage, W %% 8 == 0 and 16-byte aligned tensors (x3d_stem_s_nthwc_supported)");
   if (x3d_is_half(dtype) && (W % 8) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
     // fast path: rows of x are whole 16-byte vectors, rows of dY whole 8-byte ones (W % 8 == 0 -> Wo % 4 == 0)
     constexpr int SEGS = 4;
@@ -470,7 +553,7 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
       int nb = 0, dev = 0, cus = 256;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_wgrad_bf16_kernel<bf16, SEGS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_s_wgrad_bf16_kernel<bf16, SEGS, false>, 256, 0) != hipSuccess || nb < 1) nb = 2;
       slots = nb * cus;
     }
     long long spb2 = ceil_div_ll(total_segs, slots);
@@ -479,12 +562,11 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
     const long long gx2 = ceil_div_ll(total_segs, spb2);
     X3D_REQUIRE(gx2 < (1ll << 31), "stem_s_wgrad: grid too large");
     X3D_REQUIRE(total_segs + spb2 < (1ll << 31), "stem_s_wgrad: too many row segments");
-    if (dtype == X3D_F16)
-      hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<f16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const f16*)x,
-                         (const f16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
-    else
-      hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<bf16, SEGS>), dim3((unsigned)gx2), dim3(256), 0, st, (const bf16*)x,
-                         (const bf16*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2);
+#define STEM_WG(TT, NHWC_) hipLaunchKernelGGL((stem_s_wgrad_bf16_kernel<TT, SEGS, NHWC_>), dim3((unsigned)gx2), dim3(256), 0, st, (const TT*)x, \
+                                              (const TT*)dy, dw, Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2)
+    if (dtype == X3D_F16) { if (nhwc) STEM_WG(f16, true); else STEM_WG(f16, false); }
+    else { if (nhwc) STEM_WG(bf16, true); else STEM_WG(bf16, false); }
+#undef STEM_WG
     X3D_LAUNCH_CHECK("stem_s_wgrad");
     return X3D_OK;
   }

@@ -155,6 +155,8 @@ class _Plan:
         # CUs and HBM, so the default is one stream.
         self.side_on = training and os.environ.get("X3D_SIDE_WGRAD") == "1"
         self.side_entries = set()      # (id(list), index) of launches that go to the side stream
+        self.input_slots = []          # (list, index) of the launches whose first argument is the input batch
+        self.x_cl = False              # those launches read the caller's channels-last batch in place (no planar copy)
         self.side = None               # torch.cuda.Stream, created with the first forked launch
         self._side_pending = False
 
@@ -583,11 +585,14 @@ class X3D:
 
         # ---- input + stem ------------------------------------------------------------------------------------------
         pl.x_in = None
-        pl.x = pl.act(n, self.in_channels, t, h, w)
+        # 16-bit storage: the stem's matrix-core kernels read the caller's channels-last batch in place (x3d_hip.h K1)
+        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and os.environ.get("X3D_NO_STEM_NTHWC") != "1"   # (A/B switch)
+        pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
         pl.s_raw = view(abuf, n, a.c1, t, h1, w1)     # conv_s output: dead once conv_t has run, shares the `a` scratch
         pl.y0 = view(ybuf[0], n, a.c1, t, h1, w1)
         pl.bn1 = bn_coef("conv1/bn", a.c1)
-        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt)
+        pl.input_slots.append((F, len(F)))     # (the launch reads the caller's batch in place when pl.x_cl: _bind_input)
+        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
         pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.y0, None, pl.bn1.ss, ACT_RELU, n, a.c1, t, h1 * w1,
                a.c1_temp_filter, dt)
         # ---- residual stages ---------------------------------------------------------------------------------------
@@ -732,13 +737,16 @@ class X3D:
             F.append(None)   # slot 0: x3d_bn_eval_coef_batched, filled in once every BN layer is known
         # ---- input + stem --------------------------------------------------------------------
         pl.x_in = None  # bound at run time (NTHWC user tensor)
-        pl.x = pl.act(n, self.in_channels, t, h, w)
+        # 16-bit storage: the stem's matrix-core kernels read the caller's channels-last batch in place (x3d_hip.h K1)
+        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and os.environ.get("X3D_NO_STEM_NTHWC") != "1"   # (A/B switch)
+        pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
         h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         pl.s_raw = pl.act(n, a.c1, t, h1, w1)
         pl.t_raw = pl.act(n, a.c1, t, h1, w1)
         pl.y0 = pl.act(n, a.c1, t, h1, w1)
         pl.bn1 = bn_bufs("conv1/bn", a.c1)
-        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt)
+        pl.input_slots.append((F, len(F)))     # (the launch reads the caller's batch in place when pl.x_cl: _bind_input)
+        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
         pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.t_raw,
                ("acc", pl.bn1.stats) if training else None, None, ACT_NONE, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
         if fold_on:
@@ -1189,8 +1197,9 @@ class X3D:
         assert pending_fin["job"] is None
         pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
+        pl.input_slots.append((Bk, len(Bk)))
         pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
-               a.c1, dt)
+               a.c1, dt, int(pl.x_cl))
         pl.rec_join(Bk)
         pl.bwd_stage_marks[-1] = len(Bk)
 
@@ -1208,9 +1217,19 @@ class X3D:
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (x.dtype != torch.float32 and x.dtype != self.dtype):
             x = x.float()
         n, t, h, w, c = x.shape
-        hip.call("x3d_nthwc_to_ncthw", x.data_ptr(), hip.dtype_code(x.dtype), pl.x.data_ptr(),
-                 hip.dtype_code(self.dtype), n, c, t * h * w)
-        pl._x_keepalive = x
+        if pl.x_cl:
+            # the stem reads the batch where it lies: storage type of the model, 16-byte aligned (a copy only if it is neither)
+            if x.dtype != self.dtype:
+                x = x.to(self.dtype)
+            if x.data_ptr() % 16:
+                x = x.clone()
+            for lst, i in pl.input_slots:
+                name, fn, args = lst[i]
+                lst[i] = (name, fn, (x.data_ptr(),) + tuple(args[1:]))
+        else:
+            hip.call("x3d_nthwc_to_ncthw", x.data_ptr(), hip.dtype_code(x.dtype), pl.x.data_ptr(),
+                     hip.dtype_code(self.dtype), n, c, t * h * w)
+        pl._x_keepalive = x      # (until the next batch is bound: the backward pass reads it again)
 
     def _draw_dropout(self, pl: _Plan):
         if pl.drop_mask is None:

@@ -26,22 +26,29 @@ def _out_hw(h, w, stride):
 
 
 # ---- stem ---------------------------------------------------------------------------------------
-def stem_s_fwd(x, w, y=None):
+def stem_s_fwd(x, w, y=None, channels_last=False):
+    """channels_last: x is the clip batch [N, T, H, W, Cin] as the reference's model takes it (X3D_LAYOUT_NTHWC)."""
     _chk(x, w, y)
-    n, cin, t, h, ww = x.shape
+    if channels_last:
+        n, t, h, ww, cin = x.shape
+    else:
+        n, cin, t, h, ww = x.shape
     cout = w.shape[0]
     ho, wo = (h - 1) // 2 + 1, (ww - 1) // 2 + 1
     if y is None:
         y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
-    hip.call("x3d_stem_s_fwd", ptr(x), ptr(w), ptr(y), n, cin, t, h, ww, cout, hip.dtype_code(x.dtype))
+    hip.call("x3d_stem_s_fwd", ptr(x), ptr(w), ptr(y), n, cin, t, h, ww, cout, hip.dtype_code(x.dtype), int(channels_last))
     return y
 
 
-def stem_s_wgrad(x, dy, dw):
+def stem_s_wgrad(x, dy, dw, channels_last=False):
     _chk(x, dy, dw)
-    n, cin, t, h, ww = x.shape
+    if channels_last:
+        n, t, h, ww, cin = x.shape
+    else:
+        n, cin, t, h, ww = x.shape
     hip.call("x3d_stem_s_wgrad", ptr(x), ptr(dy), ptr(dw), n, cin, t, h, ww, dy.shape[1],
-             hip.dtype_code(x.dtype))
+             hip.dtype_code(x.dtype), int(channels_last))
 
 
 # ---- replicated statistics accumulators (include/x3d_hip.h) ----------------------------------------
