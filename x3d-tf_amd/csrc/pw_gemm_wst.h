@@ -495,6 +495,7 @@ static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
     switch (shape) {
       case 6: return pw_wst_launch_t<H, PRO, EPI, 5, 1, 20, 1>(a, st);
       case 8: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 40, 1, false, 4>(a, st);
+      // (162 -> 72 as four 4-wave workgroups per CU, <3, 1, 11, 4, false, 4>: config 5 33.0 -> 33.3 ms, round 4 -- not kept)
       case 10: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 11, 2>(a, st);
     }
   }
