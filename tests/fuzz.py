@@ -21,7 +21,9 @@ def case_calls(rng: random.Random):
     out.append(("test_dw3d_bwd", (dt, shp)))
     # the planes the matrix-core depthwise kernels take (dw_mx.hip): 12 / 14 rows and columns, 7 x 7 four to a tile (any sample
     # count), rows of 26 .. 30 elements in H-tiles of 14 rows; T around the prefetch depth and the exit-free loop (T % 4 == 0)
-    hm, wm = rng.choice([(14, 14), (12, 14), (14, 12), (12, 12), (7, 7), (7, 7), (28, 28), (26, 28), (28, 30), (14, 26), (24, 28)])
+    # (round 4: + ragged rows of 26 columns and more -- windows of 2 / 3 column tiles, W-tiles, odd row lengths: dw_mxg.hip)
+    hm, wm = rng.choice([(14, 14), (12, 14), (14, 12), (12, 12), (7, 7), (7, 7), (28, 28), (26, 28), (28, 30), (14, 26), (24, 28),
+                         (39, 39), (22, 30), (28, 29), (36, 45), (28, 54), (14, 55), (22, 78), (36, 44), (28, 91), (40, 39), (13, 31)])
     shm = (rng.choice([1, 2, 3, 4, 5, 6]), rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4, 5, 8, 9]), hm, wm, 1)
     out.append(("test_dw3d_fwd", (dt, shm)))
     out.append(("test_dw3d_bwd", (dt, shm)))
