@@ -220,6 +220,7 @@ MODEL_TRAIN_HALF = [     # teacher-forced block by block, bf16 and fp16 storage
 MODEL_INFER = [           # variant, views, crops, T, S, dtype
     ("XS", 10, 1, 4, 160, F32), ("S", 2, 1, 13, 96, F32),
     ("XL", 10, 3, 2, 96, F32), ("XL", 10, 3, 2, 96, F16), ("XL", 10, 3, 2, 96, BF16),   # BASELINE config 5: 30 views per video
+    ("XL", 2, 1, 8, 96, F16),     # stage 5 with P = 8 x 3 x 3 = 72 points (P % 8 == 0): the sliced 630 -> 280 conv in its in_store form
 ]
 
 
