@@ -176,10 +176,7 @@ typedef struct {
    * model.py:202-210) folded into the first block's `a` conv. */
   const void* in_add;               /* [N][Cin][P]: raw shortcut-conv output of the block below, or its input (identity); NULL: no Add */
   const float* in_add_scale_shift;  /* [Cin][2] (bn_r of the block below) or NULL */
-  void* in_store;                   /* [N][Cin][P] the block's output y.  With the INFERENCE epilogue (out_scale_shift) and a
-                                     * prologue, 16-bit storage: permission to leave the activated input f(x) there (in_store == x
-                                     * allowed) -- a layer whose row blocks are spread over several workgroup sets (X3D-XL
-                                     * 630 -> 280) then evaluates the prologue once; afterwards the buffer holds f(x) or is untouched */
+  void* in_store;                   /* [N][Cin][P] the block's output y */
   const float* out_scale_shift;     /* [Cout][2] or NULL (training form: raw store + stats) */
   const void* out_add;              /* [N][Cout][T][Ho][Wo] or NULL */
   const float* out_add_scale_shift; /* [Cout][2] applied to out_add, or NULL */

@@ -71,7 +71,6 @@ PW_FWD_INFER = [(n, ci, co, t, h, w, pro, ("identity", "conv")[i % 2], "relu")
     (2, 96, 216, 2, 14, 14, None, None, "relu"), (1, 280, 630, 1, 8, 8, None, "conv", "relu"),
     (1, 54, 24, 2, 20, 20, "swish", "identity", "relu"), (1, 108, 48, 2, 10, 10, "swish", "conv", "relu"),   # fp32 panels of 1 / 2 row tiles
     (1, 216, 96, 2, 10, 10, "swish", "identity", "relu"), (1, 432, 192, 4, 5, 5, "swish", "identity", "relu"),   # ... 3 / 4 (X3D-XS, config 1)
-    (2, 630, 280, 2, 10, 10, "swish", "conv", "relu"),    # X3D-XL stage-5 `c`: three row slices, two samples, a partial last tile (in_store form)
 ]
 
 # ---- x3d_pw_dgrad: N, Cin, Cout, T, H, W  x  epilogue -----------------------------------------------------------------
@@ -220,7 +219,7 @@ MODEL_TRAIN_HALF = [     # teacher-forced block by block, bf16 and fp16 storage
 MODEL_INFER = [           # variant, views, crops, T, S, dtype
     ("XS", 10, 1, 4, 160, F32), ("S", 2, 1, 13, 96, F32),
     ("XL", 10, 3, 2, 96, F32), ("XL", 10, 3, 2, 96, F16), ("XL", 10, 3, 2, 96, BF16),   # BASELINE config 5: 30 views per video
-    ("XL", 2, 1, 8, 96, F16),     # stage 5 with P = 8 x 3 x 3 = 72 points (P % 8 == 0): the sliced 630 -> 280 conv in its in_store form
+    ("XL", 2, 1, 8, 96, F16),     # stage 5 with P = 8 x 3 x 3 = 72 points (P % 8 == 0): the sliced 630 -> 280 conv on whole vectors
 ]
 
 
@@ -253,15 +252,13 @@ def pw_fwd_struct(shape, dtype, panel):
                          A() if panel else None)
 
 
-def pw_fwd_infer_struct(shape, dtype, panel, store=False):
-    """store: the in_store (= x) form test_pw_fwd_infer runs as well for 16-bit storage with a prologue"""
+def pw_fwd_infer_struct(shape, dtype, panel):
     from x3d_tf_amd import hip
     n, cin, cout, t, h, w, pro, res, oact = shape
     A = _Addr.new
-    x = A()
-    return hip.PwFwdArgs(x, A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
+    return hip.PwFwdArgs(A(), A(), A(), None, A() if pro else None, A() if pro == "swish" else None,
                          {None: 0, "relu": 1, "swish": 2}[pro], n, cin, cout, t, h, w, 1, _code(dtype),
-                         A() if panel else None, in_store=x if store else None, out_scale_shift=A(), out_add=A() if res else None,
+                         A() if panel else None, out_scale_shift=A(), out_add=A() if res else None,
                          out_add_scale_shift=A() if res == "conv" else None, out_act=1 if oact == "relu" else 0)
 
 

@@ -33,9 +33,6 @@ def _kernel_case_names():
             add(S.pw_fwd_infer_struct(shp, dt, False), f"test_pw_fwd_infer[{shp}, {dt}]")
             if half:
                 add(S.pw_fwd_infer_struct(shp, dt, True), f"test_pw_fwd_infer[{shp}, {dt}, panel]")
-                if shp[6]:      # with a prologue the test also runs the in_store (= x) form
-                    add(S.pw_fwd_infer_struct(shp, dt, False, store=True), f"test_pw_fwd_infer[{shp}, {dt}, in_store]")
-                    add(S.pw_fwd_infer_struct(shp, dt, True, store=True), f"test_pw_fwd_infer[{shp}, {dt}, panel, in_store]")
         for shp in S.PW_DGRAD:
             for epi in S.PW_DGRAD_EPI:
                 add(S.pw_dgrad_struct(shp, epi, dt, False), f"test_pw_dgrad[{shp}, {epi}, {dt}]")

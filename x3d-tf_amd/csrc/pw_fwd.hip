@@ -57,7 +57,7 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   const int vec = pick_vec(eb, a.P, f->x);
   const bool pro = f->in_scale_shift != nullptr || f->in_gate != nullptr || f->in_act != X3D_ACT_NONE;
   X3D_REQUIRE(!pro || f->in_scale_shift, "pw_fwd: gate/activation prologue needs in_scale_shift");
-  if ((f->in_add || f->in_store || f->in_add_scale_shift) && !f->out_scale_shift) {      // residual tail of the block below folded into the prologue
+  if (f->in_add || f->in_store || f->in_add_scale_shift) {      // residual tail of the block below folded into the prologue
     X3D_REQUIRE(x3d_pw_fwd_tail_supported(f), "pw_fwd: in_add / in_store (folded residual tail) need 16-bit storage, stride 1, "
                                               "in_scale_shift + ReLU, no gate (x3d_pw_fwd_tail_supported)");
     a.x2 = f->in_add; a.coef2 = f->in_add_scale_shift; a.ystore = f->in_store;
@@ -78,11 +78,6 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     X3D_REQUIRE(f->stride == 1, "pw_fwd: the inference epilogue is for stride 1 (the strided shortcut stays raw)");
     X3D_REQUIRE(f->out_act == X3D_ACT_NONE || f->out_act == X3D_ACT_RELU, "pw_fwd: out_act must be none or ReLU");
     X3D_REQUIRE(!f->out_add_scale_shift || f->out_add, "pw_fwd: out_add_scale_shift without out_add");
-    X3D_REQUIRE(!f->in_add && !f->in_add_scale_shift, "pw_fwd: the inference epilogue takes no folded residual tail (in_add)");
-    // in_store with the inference epilogue: PERMISSION to leave the activated input there (in_store == x allowed) -- used by
-    // the layers whose row blocks are sliced over several workgroup sets (pw_fwd_infer.hip), untouched otherwise
-    X3D_REQUIRE(!f->in_store || (pro && f->dtype != X3D_F32), "pw_fwd: in_store with the inference epilogue needs a prologue and 16-bit storage");
-    a.ystore = f->in_store;
     a.e_ss = f->out_scale_shift; a.e_ass = f->out_add_scale_shift; a.add = f->out_add; a.eact = f->out_act;
     int ovec_ = pick_vec(eb, a.P, f->y);
     if (f->out_add) ovec_ = ovec_ < pick_vec(eb, a.P, f->out_add) ? ovec_ : pick_vec(eb, a.P, f->out_add);

@@ -7,21 +7,6 @@
 template <typename H>
 static int pw_fwd_bnadd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st) {
   const int shp_ = pw_wst_shape(a, vec, ovec);
-  // X3D-XL stage-5 `c` conv (630 -> 280): the stationary weights of its nine row blocks take three slices of workgroups, and
-  // each slice used to repeat the BN_b * gate -> swish prologue over the whole input (181 M element evaluations for 60 M; the
-  // prologue, two transcendentals per element on four waves, is longer than a slice's MFMAs).  With `in_store` (which may be x
-  // itself) the caller lets the first slice leave the activated input there; the other slices run as a second launch that
-  // stages it as it is.  Measured on 60 clips of 16 x 312 x 312, fp16: see DESIGN section 4.
-  if (shp_ == 8 && pro && a.ystore && a.P % 8 == 0 && ((uintptr_t)a.ystore % 16) == 0) {
-    PwGemmArgs a0 = a;
-    a0.slice0 = 0; a0.nslices = 1;
-    const int rc = pw_wst_launch<H, PRO_AFFST, EPI_BNADD>(a0, 8, st);
-    if (rc != X3D_OK) return rc;
-    PwGemmArgs a1 = a;
-    a1.x = a.ystore; a1.coef = nullptr; a1.gate = nullptr; a1.act = X3D_ACT_NONE; a1.ystore = nullptr;
-    a1.slice0 = 1; a1.nslices = 0;
-    return pw_wst_launch<H, PRO_NONE, EPI_BNADD>(a1, 8, st);
-  }
   if (const int shp = ((shp_ == 5 && pro) || (shp_ >= 6 && pw_wst_shape_has_prologue(shp_) != pro)) ? 0 : shp_)
     return pro ? pw_wst_launch<H, PRO_AFFINE, EPI_BNADD>(a, shp, st) : pw_wst_launch<H, PRO_NONE, EPI_BNADD>(a, shp, st);
   if (pw_ws_applies(a, vec, ovec))

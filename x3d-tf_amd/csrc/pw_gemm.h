@@ -42,7 +42,6 @@ struct PwGemmArgs {
   long long P, Pin;    // points per sample of the output side (y, add, braw) / of the streamed operand x, x2
   int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
   int KC, nchunks, tiles_per_block;
-  int slice0, nslices; // weights-stationary kernel, row blocks over blockIdx.y: this launch covers slices slice0 .. (nslices = 0: all from slice0)
   int wvec;            // bf16 kernel: fp32 vector width for the weight-panel staging
   const void* wp;      // bf16 kernel: packed panel (x3d_pw_pack_weights) [wp_rows][KC + 8] or null
   int wp_rows;

@@ -34,8 +34,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
   constexpr bool HAS_SUMS = (EPI == EPI_STATS) || (EPI == X3D_EPI_SWISH_BWD);
   constexpr bool BNA_ = (EPI == EPI_BNADD);
   constexpr bool EPI_LOADS = (EPI == X3D_EPI_ADD) || (EPI == X3D_EPI_SWISH_BWD) || BNA_;
-  constexpr bool AFF = (PRO == PRO_AFFINE) || (PRO == PRO_AFFST);   // PRO_AFFST: PRO_AFFINE + the activated input stored (first slice)
-  constexpr int CSW = AFF ? 2 : 4;
+  constexpr int CSW = (PRO == PRO_AFFINE) ? 2 : 4;
   constexpr int NSV = (Kp * 4 + NT - 1) / NT;             // staging vectors (8 points) per thread
   H* Xs = (H*)smem_raw;                                               // [2][Kp][32]
   float* Cs = (float*)(smem_raw + (size_t)2 * Kp * 64);                     // [Kp][CSW]
@@ -45,8 +44,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
   const int mt = (a.M + 31) >> 5;
   // wide outputs (X3D-XL: M = 280 / 306 / 630 with K up to 630): the row blocks are split over blockIdx.y -- each slice is
   // its own persistent workgroup set with NW * RB stationary row blocks (the streamed operand is staged once per slice)
-  const int slice = (int)blockIdx.y + a.slice0;   // (slice0: a launch that covers the slices from slice0 on)
-  const int mib = slice * (NW * RB);
+  const int mib = blockIdx.y * (NW * RB);
   const int rsh = 8 - (int)(a.P & 7);   // RAG: places a row's last vector (loaded from row_end - 8) moves down by
   const int tiles_per_n = (int)((a.P + BN - 1) / BN);
   const int total_tiles = tiles_per_n * a.N;
@@ -77,7 +75,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
       for (int k = tid; k < Kp; k += NT) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         if (k < a.K) {
-          if constexpr (AFF) {
+          if constexpr (PRO == PRO_AFFINE) {
             const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
             c[0] = a.coef[k * 2] * g;
             c[1] = a.coef[k * 2 + 1] * g;
@@ -140,7 +138,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
         float val[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) val[e] = (float)xv[e];
-        if constexpr (AFF) {
+        if constexpr (PRO == PRO_AFFINE) {
           const float2 cf = *(const float2*)&Cs[k * 2];
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] = cf.x * val[e] + cf.y;
@@ -154,17 +152,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] = 0.f;
         }
-        if constexpr (PRO == PRO_AFFST) {
-          // the activated tile also goes to `ystore` (which may be x itself: a tile is read and written by this workgroup only),
-          // so that the launch for the other row slices stages it without the prologue
-          hx8 hv;
-#pragma unroll
-          for (int e = 0; e < 8; e++) hv[e] = (H)val[e];
-          *(hx8*)dst = hv;
-          if (ok && slice == 0) *(hx8*)((T*)a.ystore + ((long long)n * a.K + k) * a.Pin + p0 + (v & 3) * 8) = hv;
-        } else {
-          VecIO<H, 8>::store(dst, val);
-        }
+        VecIO<H, 8>::store(dst, val);
       }
     }
   };
@@ -323,7 +311,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
     // loads with vmcnt, which retires in order and counts stores -- after the epilogue it would also wait for this
     // tile's output stores, every tile
     if (tile + 1 < tile_end) {
-      if constexpr (AFF) {
+      if constexpr (PRO == PRO_AFFINE) {
         const int n1 = (tile + 1) / tiles_per_n;
         if (a.gate && n1 != n) {        // every earlier read of the table is behind the previous barrier
           fill_coef(n1);
@@ -436,6 +424,8 @@ static inline int pw_wst_shape(const PwGemmArgs& a, int vec, int ovec) {
   if (x3d_env_int("X3D_PW_WST_XL", 1) == 0) return 0;   // A/B switch: 0 = off
   if (ks == 20 && a.M <= 160) return 6;    // stage-4 `c`: 306 -> 136 (5 waves x 1 row block x 20 k-steps)
   if (ks == 9 && a.M <= 640) return 7;     // stage-4 `a`: 136 -> 306 (5 x 2 x 9); stage-5 block 0: 136 -> 630 in two slices
+  // (round 4: the first slice storing the activated tile in place and the other two running without the prologue as a second
+  // launch: 168 vs 166 us -- a slice takes its 55 us with or without the prologue; removed again)
   if (ks == 40 && a.M <= 288) return 8;    // stage-5 `c`: 630 -> 280 (3 x 1 x 40, three slices)
   if (ks == 18 && a.M <= 640) return 9;    // stage-5 `a` / conv5: 280 -> 630 (5 x 2 x 18, two slices)
   if (ks == 11 && a.M <= 96) return 10;    // stage-3 `c`: 162 -> 72 (3 x 1 x 11)
@@ -467,9 +457,7 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   }
   const long long total_tiles = ceil_div_ll(a.P, WS_BN) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_gemm_wst: too many tiles");
-  const int gy_all = ceil_div(ceil_div(a.M, 32), NW * RB);   // row-block slices (1 for every X3D-S / M / L layer)
-  const int gy = a.nslices > 0 ? a.nslices : gy_all - a.slice0;   // (a launch of some of the slices: pw_fwd_infer.hip)
-  X3D_REQUIRE(gy > 0 && a.slice0 + gy <= gy_all, "pw_gemm_wst: bad slice range");
+  const int gy = ceil_div(ceil_div(a.M, 32), NW * RB);       // row-block slices (1 for every X3D-S / M / L layer)
   const long long slots = (long long)cus * OCC / gy > 0 ? (long long)cus * OCC / gy : 1;
   const long long tpb = ceil_div_ll(total_tiles, slots);
   a.tiles_per_block = (int)tpb;
@@ -498,11 +486,6 @@ static int pw_wst_launch(PwGemmArgs& a, int shape, hipStream_t st) {
       // (162 -> 72 as four 4-wave workgroups per CU, <3, 1, 11, 4, false, 4>: config 5 33.0 -> 33.3 ms, round 4 -- not kept)
       case 10: return pw_wst_launch_t<H, PRO, EPI, 3, 1, 11, 2>(a, st);
     }
-  }
-  if constexpr (PRO == PRO_AFFST || (PRO == PRO_NONE && EPI == EPI_BNADD)) {
-    // the two launches of the sliced stage-5 `c` conv at inference (pw_fwd_infer.hip): first slice with the prologue, storing the
-    // activated input; the other slices read that
-    if (shape == 8) return pw_wst_launch_t<H, PRO, EPI, 3, 1, 40, 1, false, 4>(a, st);
   }
   if constexpr (PRO == PRO_NONE) {
     switch (shape) {

@@ -639,12 +639,9 @@ class X3D:
             else:
                 B.r_raw, B.bn_r = None, None
                 add, add_ss = x_cur, None
-            # c: BN_b * gate -> swish on load; relu(bn_c(acc) + shortcut) on the accumulators.  b_raw has no other reader at
-            # inference: 16-bit storage hands it over as in_store (= x), so a layer whose row blocks take several workgroup
-            # sets (X3D-XL 630 -> 280) runs the prologue once and leaves the activated input in place for the other sets
+            # c: BN_b * gate -> swish on load; relu(bn_c(acc) + shortcut) on the accumulators
             sc = hip.PwFwdArgs(_p(B.b_raw), _p(p[f"{q}/c/kernel"]), _p(B.y), None, _p(B.bn_b.ss), _p(B.gate),
                                ACT_SWISH, n, b.inner, b.cout, t, ho, wo, 1, dt, self._wp(f"{q}/c/kernel"),
-                               in_store=(_p(B.b_raw) if self.dtype != torch.float32 else None),
                                out_scale_shift=_p(B.bn_c.ss), out_add=_p(add), out_add_scale_shift=_p(add_ss), out_act=ACT_RELU)
             B.sc = sc
             pl.rec(F, "x3d_pw_fwd", sc)
