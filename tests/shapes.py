@@ -49,6 +49,10 @@ PW_FWD_TAIL = [
     (1, 48, 216, 1, 16, 16, 1, "tail"), (1, 32, 72, 1, 16, 16, 1, "tail"), (1, 72, 162, 1, 8, 8, 1, "tail_conv"),     # stage-4 block 0; X3D-XL
     (1, 48, 108, 13, 5, 5, 1, "tail"), (2, 96, 216, 13, 10, 10, 1, "tail_conv"), (1, 24, 54, 1, 3, 4, 1, "tail"),     # odd / ragged point counts
     (3, 40, 72, 2, 7, 8, 1, "tail_conv"),
+    # stages 4 / 5: the weights-stationary kernel carries the fold (shapes 4, 5, 2 of pw_gemm_wst.h; with a weight panel), whole and
+    # ragged rows (13 frames of 10 x 10 / 5 x 5), two samples, a partial last tile
+    (2, 96, 216, 4, 14, 14, 1, "tail"), (1, 96, 432, 2, 14, 14, 1, "tail_conv"), (2, 192, 432, 4, 7, 7, 1, "tail"), (1, 192, 432, 8, 7, 7, 1, "tail_conv"),
+    (1, 96, 216, 13, 10, 10, 1, "tail"), (2, 192, 432, 13, 5, 5, 1, "tail_conv"),
     # "tail1": no Add -- the stem's BatchNorm + ReLU folded into the first block's `a` conv (x = raw conv_t output, in_store = y0)
     (2, 24, 54, 2, 16, 16, 1, "tail1"), (1, 32, 72, 1, 16, 16, 1, "tail1"), (1, 24, 54, 1, 3, 4, 1, "tail1"), (2, 24, 54, 13, 5, 5, 1, "tail1"),
 ]

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
             const float g = a.gate ? a.gate[(long long)n * a.K + k] : 1.0f;
             c[0] = a.coef[k * 2] * g;
             c[1] = a.coef[k * 2 + 1] * g;
+          } else if constexpr (PRO == PRO_TAIL) {   // s_c*x + (s_r|1)*x2 + (t_c + t_r|0), as in pw_gemm_bf16.h
+            c[0] = a.coef[k * 2]; c[1] = a.coef2 ? a.coef2[k * 2] : 1.0f;
+            c[2] = a.coef[k * 2 + 1] + (a.coef2 ? a.coef2[k * 2 + 1] : 0.f);
           } else {
             c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2];
           }
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
   // TWO register sets: the loads of tile t+2 are issued before the commit of tile t+1, so a whole iteration (commit,
   // epilogue, barrier, MFMAs) covers their latency.  Tiles past the end re-load the last tile (unconditional: the
   // number of loads in flight stays static and the compiler can wait with an exact vmcnt).
-  constexpr int NSY = PRO == PRO_BNBWD ? NSV : 1;
+  constexpr bool TWO = (PRO == PRO_BNBWD) || (PRO == PRO_TAIL);   // a second streamed tensor (a.x2)
+  constexpr int NSY = TWO ? NSV : 1;
   hx8 xr0[NSV], yr0[NSY], xr1[NSV], yr1[NSY];
   auto issue_loads = [&](int tile_, hx8 (&xr)[NSV], hx8 (&yr)[NSY]) {
     const int tile = min(tile_, tile_end - 1);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
       const long long pl = (RAG && a.P - p < 8) ? a.P - 8 : p;      // the row's last, partial vector: from row_end - 8
       const long long o = ok ? ((long long)n * a.K + k) * a.Pin + pl : 0;
       xr[i] = *(const hx8*)((const T*)a.x + o);
-      if constexpr (PRO == PRO_BNBWD) yr[i] = *(const hx8*)((const T*)a.x2 + o);
+      if constexpr (TWO) yr[i] = *(const hx8*)((const T*)a.x2 + o);
     }
   };
   auto commit = [&](int tile, H* dstbuf, const hx8 (&xr)[NSV], const hx8 (&yr)[NSY]) {
@@ -125,11 +129,11 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
       hx8 z;
 #pragma unroll
       for (int e = 0; e < 8; e++) z[e] = (H)0.f;
-      hx8 xv = xr[i], yv = yr[PRO == PRO_BNBWD ? i : 0];
+      hx8 xv = xr[i], yv = yr[TWO ? i : 0];
       if constexpr (RAG) {
         if (ok && a.P - (p0 + (v & 3) * 8) < 8) {
           xv = shift_down8(xv, rsh);
-          if constexpr (PRO == PRO_BNBWD) yv = shift_down8(yv, rsh);
+          if constexpr (TWO) yv = shift_down8(yv, rsh);
         }
       }
       if constexpr (PRO == PRO_NONE) {
@@ -146,13 +150,26 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
         } else {
           const f32x4 cf = *(const f32x4*)&Cs[k * 4];
 #pragma unroll
-          for (int e = 0; e < 8; e++) val[e] = cf[0] * val[e] + cf[1] * (float)yv[e] + cf[2];
+          for (int e = 0; e < 8; e++) {
+            val[e] = cf[0] * val[e] + cf[1] * (float)yv[e] + cf[2];
+            if constexpr (PRO == PRO_TAIL) val[e] = fmaxf(val[e], 0.f);
+          }
         }
         if (!ok) {
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] = 0.f;
         }
         VecIO<H, 8>::store(dst, val);
+        if constexpr (PRO == PRO_TAIL) {
+          // the activated input IS the output y of the block below: kept for its other readers (the next shortcut, the backward
+          // pass) -- what the separate x3d_tail_fwd pass would have written
+          if (ok && blockIdx.y == 0) {
+            const long long p_ = p0 + (v & 3) * 8;
+            T* yd = (T*)a.ystore + ((long long)n * a.K + k) * a.Pin + p_;
+            if (!RAG || a.P - p_ >= 8) VecIO<T, 8>::store(yd, val);
+            else for (int e = 0; e < (int)(a.P - p_); e++) yd[e] = from_f<T>(val[e]);
+          }
+        }
       }
     }
   };
@@ -465,6 +482,19 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(NWT * 64), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm_wst");
   return X3D_OK;
+}
+
+// the folded residual tail (PRO_TAIL, training epilogue) on the stage-4 / stage-5 `a` convs and conv5 -- the shapes those layers take
+static inline bool pw_wst_shape_has_tail(int shape) { return shape == 2 || shape == 4 || shape == 5; }
+template <typename H>
+static int pw_wst_launch_tail(PwGemmArgs& a, int shape, hipStream_t st) {
+  switch (shape) {
+    case 2: return pw_wst_launch_t<H, PRO_TAIL, EPI_STATS, 7, 2, 12, 1>(a, st);
+    case 4: return pw_wst_launch_t<H, PRO_TAIL, EPI_STATS, 7, 1, 6, 2>(a, st);
+    case 5: return pw_wst_launch_t<H, PRO_TAIL, EPI_STATS, 7, 2, 6, 2>(a, st);
+  }
+  x3d_set_error("pw_gemm_wst: shape %d has no tail instantiation", shape);
+  return X3D_ERR_INVALID;
 }
 
 template <typename H, int PRO, int EPI>

@@ -769,8 +769,11 @@ class X3D:
             c_raw, c_ss, shortcut, r_ss, y, cout_, p_out_ = tl
             ft = hip.PwFwdArgs(_p(c_raw), st.w, st.y, None, _p(c_ss), None, ACT_RELU, st.N, st.Cin, st.Cout, st.T, st.H, st.W,
                                1, st.dtype, st.w_panel, in_add=_p(shortcut), in_add_scale_shift=_p(r_ss), in_store=_p(y))
+            # (the fold must not cost a layer its stationary kernel: stages 4 / 5 fold where the weights-stationary kernel carries
+            # the prologue itself -- x3d_pw_kernel_name of the folded form says which kernel it gets)
             if (fold_fwd and st.stride == 1 and pl.lib.x3d_pw_fwd_tail_supported(C.byref(ft))
-                    and not hip.pw_kernel_name(st).startswith(("pw_gemm_wst", "pw_gemm_ws_kernel"))):
+                    and (not hip.pw_kernel_name(st).startswith(("pw_gemm_wst", "pw_gemm_ws_kernel"))
+                         or (hip.pw_kernel_name(ft).startswith("pw_gemm_wst") and os.environ.get("X3D_NO_TAIL_FOLD_WST") != "1"))):
                 if pl.blocks:
                     pl.blocks[-1].tail_fwd_folded = True
                 else:
