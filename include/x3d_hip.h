@@ -252,15 +252,15 @@ typedef struct {
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
-/* the per-step operands of the recomputed-output form.  panel_elems == 0: the layer shape is not covered (Cin <= 32,
- * Cout <= 127).  prepare: after x3d_bn_bwd_finalize produced `coef` [Cout][4]; finish: after x3d_pw_bwd, dw [Cout][Cin] +=. */
+/* the per-step operands of the recomputed-output form.  panel_elems == 0: the layer shape is not covered (covered: Cin <= 32
+ * with Cout <= 127; Cin 33..48 with Cout 65..127 or 193..223 -- the X3D stage-3 `a` convs and the first one of stage 4).  prepare: after x3d_bn_bwd_finalize produced `coef` [Cout][4]; finish: after x3d_pw_bwd, dw [Cout][Cin] +=. */
 long long x3d_pw_bwd_rc_panel_elems(int Cout, int Cin);
 long long x3d_pw_bwd_rc_sums_elems(int Cout, int Cin);
 int x3d_pw_bwd_rc_prepare(const float* w /* [Cout][Cin] fp32 */, const float* coef, void* rc_panel, float* rc_c0, int Cout, int Cin,
                           int dtype, void* stream);
 int x3d_pw_bwd_rc_finish(const float* rc_sums, const float* w, const float* coef, float* dw, int Cout, int Cin, int dtype, void* stream);
 /* x3d_bn_bwd_finalize (arguments up to C: the same arithmetic, the same outputs) + x3d_pw_bwd_rc_prepare for the conv this
- * BatchNorm follows (w != NULL: its [C][Cin] weights; C <= 127) + x3d_pw_bwd_rc_finish of an EARLIER recomputed-output launch
+ * BatchNorm follows (w != NULL: its [C][Cin] weights; C <= 223) + x3d_pw_bwd_rc_finish of an EARLIER recomputed-output launch
  * (fin_sums != NULL), in ONE launch: three ~5 us launches of the backward pass's critical path become one. */
 int x3d_bn_bwd_finalize_rc(const double* sums, double count, const float* mean_invstd, const float* gamma, float* coef,
                            float* dgamma, float* dbeta, int C, const float* w, void* rc_panel, float* rc_c0, int Cin,

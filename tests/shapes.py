@@ -135,6 +135,11 @@ PW_BWD_RC = [
     (5, 24, 54, 8, 28, 28, "add", 1),                                                                              # several tiles per workgroup, across samples
     (2, 48, 108, 2, 28, 28, "add", 0), (24, 48, 108, 8, 28, 28, "add", 0),                                         # stage 3: two row tiles of x (48 rows in the image)
     (1, 40, 100, 1, 12, 12, "add", 0), (1, 48, 90, 2, 8, 16, "add_strided", 0), (3, 48, 108, 4, 20, 20, "add", 0), # ... widths off the grid, three g tiles, X3D-L planes
+    # first `a` conv of stage 4 (48 -> 216: seven row tiles of g, one workgroup per CU): strided add (the model's case, vector and
+    # element forms), plain add, several tiles per workgroup across samples, Cout off the grid
+    (2, 48, 216, 2, 16, 16, "add_strided", 0), (1, 48, 216, 2, 28, 28, "add_strided", 0), (1, 48, 216, 1, 16, 16, "add", 0),
+    (9, 48, 216, 4, 28, 28, "add_strided", 0), (1, 40, 200, 1, 12, 12, "add", 0),
+    (1, 48, 216, 8, 13, 13, "add_strided", 0),      # X3D-L / XL: rows of odd length (39 x 39) take the element form of the strided add
 ]
 
 # ... of the strided shortcut conv (x_stride = 2, epilogue STORE): N, Cin, Cout, T, xH, xW (input extents)

@@ -391,7 +391,7 @@ def test_pw_bwd_rc_strided(gpu, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", HALF)
-@pytest.mark.parametrize("cout,cin,fco,fci", [(54, 24, 108, 24), (108, 48, 54, 24), (72, 32, 72, 32), (20, 8, 127, 24)])
+@pytest.mark.parametrize("cout,cin,fco,fci", [(54, 24, 108, 24), (108, 48, 54, 24), (72, 32, 72, 32), (20, 8, 127, 24), (216, 48, 108, 48), (54, 24, 216, 48)])
 def test_bn_bwd_finalize_rc_equals_the_three_launches(gpu, dtype, cout, cin, fco, fci):
     """x3d_bn_bwd_finalize_rc (finalize + panel of this layer + dW of an earlier layer in one launch) writes the same bits as
     x3d_bn_bwd_finalize, x3d_pw_bwd_rc_prepare and x3d_pw_bwd_rc_finish one after the other -- with and without each job."""

@@ -50,8 +50,10 @@ struct PwBwdRcArgs {
 // the 48 <-> 108 layer needs 87 KB of LDS and runs one workgroup per CU; the moment-sum MFMAs then read 16 rows past the image
 // (into the panel that follows it: finite values, landing only in discarded rows / columns of the accumulators)
 // XS: 0 = dense conv input; 4 / 2 / 1 = strided shortcut conv, outputs per aligned load of the gather (common.h).
-template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V, int XS = 0>
-__global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : 2) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {
+// E4V (strided add): 1 = rows of whole 8-point vectors (eW % 8 == 0: one 8-byte load of the four even-column operands), 2 = rows of
+// whole 4-point groups (eW % 4 == 0, e.g. 28: two 4-byte loads per vector), 0 = element by element
+template <typename H, int MT, int KT, int EPI, int TAIL, int E4V, int XS = 0>
+__global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : (KT > 4 ? 1 : 2)) void pw_bwd_rc_kernel(const PwBwdRcArgs a) {   // (KT > 4: one workgroup per CU by LDS anyway)
   typedef typename HV<H>::x8 hx8; typedef typename HV<H>::x4 hx4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef H T;
@@ -250,10 +252,24 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : 2) 
         const int t = (int)p / hw;
         const int rem = (int)p - t * hw;
         const int h = rem / a.eW, w = rem - h * a.eW;
-        const bool okv = ok && E4V && (h & 1) == 0;
-        const hx4 l4 = *(const hx4*)((const T*)a.add + (okv ? ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1) : 0));
+        if constexpr (E4V == 2) {      // two groups of four points: each inside one image row (eW % 4 == 0), the second may be in the next
+          typedef typename HV<H>::x2 hx2;
+          const T* abase = (const T*)a.add + ((long long)n * a.Ci + m) * T_ * Hh * Wh;
 #pragma unroll
-        for (int e = 0; e < 4; e++) epl4[i][e] = okv ? l4[e] : (H)0.f;
+          for (int gq = 0; gq < 2; gq++) {
+            int wq = w + 4 * gq, hq = h, tq = t;
+            if (wq >= a.eW) { wq -= a.eW; hq++; if (hq >= a.eH) { hq = 0; tq++; } }
+            const bool okq = ok && tq < T_ && (hq & 1) == 0;
+            const hx2 l2 = *(const hx2*)(abase + (okq ? ((long long)tq * Hh + (hq >> 1)) * Wh + (wq >> 1) : 0));
+            epl4[i][2 * gq] = okq ? l2[0] : (H)0.f;
+            epl4[i][2 * gq + 1] = okq ? l2[1] : (H)0.f;
+          }
+        } else {
+          const bool okv = ok && E4V == 1 && (h & 1) == 0;
+          const hx4 l4 = *(const hx4*)((const T*)a.add + (okv ? ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1) : 0));
+#pragma unroll
+          for (int e = 0; e < 4; e++) epl4[i][e] = okv ? l4[e] : (H)0.f;
+        }
       }
     }
     issue(min(tile + 1, tile_end - 1));   // (past the end: the last tile again -- the number of loads in flight stays static)
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : 2) 
 #pragma unroll
           for (int e = 0; e < 8; e++) val[e] += (float)epl8[i][e];
         } else if constexpr (EPL4) {
-          if (E4V) {   // loaded above (zeros on odd rows)
+          if (E4V != 0) {   // loaded above (zeros on odd rows)
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           } else if (rvalid) {
@@ -394,15 +410,18 @@ static inline size_t rc_lds_bytes(int MT, int KT) {
   return (size_t)ZR * RC_YP * 2 + (size_t)MT * 32 * (ZR + 8) * 2;
 }
 
-template <typename H, int MT, int KT, int EPI, int TAIL, bool E4V = true, int XS = 0>
+template <typename H, int MT, int KT, int EPI, int TAIL, int E4V = 1, int XS = 0>
 static int rc_launch(PwBwdRcArgs& a, hipStream_t st) {
-  if constexpr (EPI == X3D_EPI_ADD_STRIDED && E4V) {
-    if ((a.eW & 7) != 0) return rc_launch<H, MT, KT, EPI, TAIL, false>(a, st);
+  if constexpr (EPI == X3D_EPI_ADD_STRIDED && E4V == 1) {
+    if constexpr (MT == 2 && KT == 7) {     // (the 28-wide planes of stage 4's first block: groups of four)
+      if ((a.eW & 7) != 0 && (a.eW & 3) == 0) return rc_launch<H, MT, KT, EPI, TAIL, 2>(a, st);
+    }
+    if ((a.eW & 7) != 0) return rc_launch<H, MT, KT, EPI, TAIL, 0>(a, st);
   }
   const size_t lds = rc_lds_bytes(MT, KT);
   X3D_REQUIRE(lds <= 160 * 1024, "pw_bwd (recomputed output): needs %zu B of LDS", lds);
   if constexpr (XS != 0) X3D_DESCRIBE("pw_bwd_rc_kernel<%s, %d, %d, %d, %d, s%d>", HV<H>::name, MT, KT, EPI, TAIL, XS);
-  X3D_DESCRIBE("pw_bwd_rc_kernel<%s, %d, %d, %d, %d%s>", HV<H>::name, MT, KT, EPI, TAIL, E4V ? "" : ", e");
+  X3D_DESCRIBE("pw_bwd_rc_kernel<%s, %d, %d, %d, %d%s>", HV<H>::name, MT, KT, EPI, TAIL, E4V == 1 ? "" : (E4V == 2 ? ", g4" : ", e"));
   auto kern = pw_bwd_rc_kernel<H, MT, KT, EPI, TAIL, E4V, XS>;
   static bool attr_set = false;
   static int slots = 0;
@@ -431,8 +450,11 @@ struct RcShape { int MT, KT, ZR, WP, Kg, Cip; };
 static inline bool rc_shape(int Cin, int Cout, RcShape* s) {
   s->MT = ceil_div(Cin, 32);
   s->KT = ceil_div(Cout + 1, 32);
-  if (s->MT < 1 || s->MT > 2 || Cin > 48 || s->KT < 1 || s->KT > 4) return false;   // (wider inputs: two workgroups per CU no longer fit)
-  if (s->MT == 2 && s->KT < 3) return false;                    // (instantiated for the X3D stage-3 shape class only)
+  if (s->MT < 1 || s->MT > 2 || Cin > 48 || s->KT < 1 || s->KT > 7) return false;   // (wider inputs: two workgroups per CU no longer fit)
+  if (s->MT == 1 && s->KT > 4) return false;
+  // two row tiles of x: instantiated for the X3D stage-3 shape class (KT = 3, 4) and for the first `a` conv of stage 4
+  // (48 -> 216: KT = 7, 123 KB of LDS with the panel -- one workgroup per CU; its unfused dgrad + wgrad pair moved 2.8x the bytes)
+  if (s->MT == 2 && !(s->KT == 3 || s->KT == 4 || s->KT == 7)) return false;
   s->ZR = rc_zrows(s->MT, s->KT);
   s->WP = s->ZR + 8;
   s->Kg = (Cout + 1 + 15) & ~15;
@@ -488,6 +510,7 @@ static int rc_pick(PwBwdRcArgs& a, int MT, int KT, int tail, hipStream_t st) {
 #undef RC_CASE
   if (MT == 2 && KT == 3 && tail == 0) return rc_launch<H, 2, 3, EPI, 0>(a, st);
   if (MT == 2 && KT == 4 && tail == 0) return rc_launch<H, 2, 4, EPI, 0>(a, st);
+  if (MT == 2 && KT == 7 && tail == 0) return rc_launch<H, 2, 7, EPI, 0>(a, st);
   x3d_set_error("pw_bwd (recomputed output): unsupported tile shape");
   return X3D_ERR_INVALID;
 }
@@ -577,7 +600,7 @@ extern "C" int x3d_pw_bwd_rc_prepare(const float* w, const float* coef, void* rc
 // ------------------------------------------------------------------------------------------------------------------------
 // x3d_bn_bwd_finalize_rc: the BatchNorm-backward finalize of the conv's BN, the panel it feeds (prepare) and the pending
 // dW of an EARLIER recomputed-output launch (finish) in ONE launch -- each of them is a ~5 us launch on the critical path of
-// the backward pass.  Workgroups [0, nprep): every one derives the coefficients of all C channels into LDS (C <= 127: a few
+// the backward pass.  Workgroups [0, nprep): every one derives the coefficients of all C channels into LDS (C <= 223: a few
 // loads per thread), workgroup 0 publishes them (coef, dgamma, dbeta), then they split the panel; workgroups [nprep, ..):
 // the finish job, independent of this BatchNorm.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -587,10 +610,11 @@ struct RcFinalizeArgs {
   const float* f_sums; const float* f_w; const float* f_coef; float* f_dw; int f_Co, f_Ci;   // finish (f_sums == NULL: none)
 };
 
-#define RCF_W_MAX (127 * 48)      // weights of one layer staged in LDS (Co <= 127, Ci <= 48: rc_shape)
+#define RCF_C_MAX 224             // channels of the BatchNorm behind the conv (rc_shape: Co <= 223)
+#define RCF_W_MAX (RCF_C_MAX * 48)      // weights of one layer staged in LDS (Ci <= 48: rc_shape)
 template <typename H>
 __global__ __launch_bounds__(256) void rc_finalize_kernel(const RcFinalizeArgs a) {
-  __shared__ float cf[128 * 4];
+  __shared__ float cf[RCF_C_MAX * 4];
   // the small operands (weights rounded as the matrix cores see them, the Gram block) in LDS: read from global inside the
   // dot products every term was a dependent L2 round trip (prepare 16 us, finish 14 us per layer against a ~5 us launch floor)
   __shared__ float wl[RCF_W_MAX];
@@ -644,7 +668,7 @@ extern "C" int x3d_bn_bwd_finalize_rc(const double* sums, double count, const fl
   a.sums = sums; a.count = count; a.mi = mean_invstd; a.gamma = gamma; a.coef = coef; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C;
   a.nprep = 1;
   if (w) {
-    X3D_REQUIRE(rc_panel && rc_c0 && Cin > 0 && C <= 127, "bn_bwd_finalize_rc: prepare needs the panel, c0 and C <= 127");
+    X3D_REQUIRE(rc_panel && rc_c0 && Cin > 0 && C <= RCF_C_MAX - 1, "bn_bwd_finalize_rc: prepare needs the panel, c0 and C <= 223");
     RcShape s;
     X3D_REQUIRE(rc_shape(Cin, C, &s), "bn_bwd_finalize_rc: layer shape not covered (x3d_pw_bwd_rc_panel_elems() == 0)");
     a.w = w; a.panel = rc_panel; a.c0 = rc_c0; a.Ci = Cin; a.rows = s.MT * 32; a.WP = s.WP; a.XR0 = s.KT * 32;

@@ -1123,6 +1123,8 @@ class X3D:
             rc = None
             pe = int(pl.lib.x3d_pw_bwd_rc_panel_elems(b.inner, b.cin)) if (self._fuse_pw_bwd and self._rc_pw_bwd and
                                                                             self.dtype != torch.float32) else 0
+            if b.inner > 127 and os.environ.get("X3D_PW_BWD_RC_WIDE") == "0":      # (A/B switch: the 48 -> 216 layer unfused as before)
+                pe = 0
             if pe:
                 rc = (pl.act(pe), pl.f32(b.cin), pl.acc64((int(pl.lib.x3d_pw_bwd_rc_sums_elems(b.inner, b.cin)) + 1) // 2))
 
