@@ -140,6 +140,9 @@ PW_BWD_RC = [
     (2, 48, 216, 2, 16, 16, "add_strided", 0), (1, 48, 216, 2, 28, 28, "add_strided", 0), (1, 48, 216, 1, 16, 16, "add", 0),
     (9, 48, 216, 4, 28, 28, "add_strided", 0), (1, 40, 200, 1, 12, 12, "add", 0),
     (1, 48, 216, 8, 13, 13, "add_strided", 0),      # X3D-L / XL: rows of odd length (39 x 39) take the element form of the strided add
+    # ... and rows of 4 k + 2 points (78 x 78): element form too (rows of 4 k take the group form: 12, 28, 156)
+    (1, 24, 108, 2, 10, 10, "add_strided", 1), (1, 24, 108, 2, 10, 10, "add_strided", 0), (1, 24, 108, 2, 10, 10, "add_strided", 2),
+    (1, 24, 54, 2, 6, 14, "add_strided", 1), (2, 24, 54, 2, 9, 8, "add_strided", 0),
 ]
 
 # ... of the strided shortcut conv (x_stride = 2, epilogue STORE): N, Cin, Cout, T, xH, xW (input extents)

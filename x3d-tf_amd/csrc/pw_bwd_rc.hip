@@ -254,13 +254,14 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : (KT
         const int h = rem / a.eW, w = rem - h * a.eW;
         if constexpr (E4V == 2) {      // two groups of four points: each inside one image row (eW % 4 == 0), the second may be in the next
           typedef typename HV<H>::x2 hx2;
-          const T* abase = (const T*)a.add + ((long long)n * a.Ci + m) * T_ * Hh * Wh;
+          // (rows m >= Ci of the last sample: no address may be formed from them -- the clamp is on the WHOLE offset)
+          const long long abase = ((long long)n * a.Ci + m) * T_ * Hh * Wh;
 #pragma unroll
           for (int gq = 0; gq < 2; gq++) {
             int wq = w + 4 * gq, hq = h, tq = t;
             if (wq >= a.eW) { wq -= a.eW; hq++; if (hq >= a.eH) { hq = 0; tq++; } }
             const bool okq = ok && tq < T_ && (hq & 1) == 0;
-            const hx2 l2 = *(const hx2*)(abase + (okq ? ((long long)tq * Hh + (hq >> 1)) * Wh + (wq >> 1) : 0));
+            const hx2 l2 = *(const hx2*)((const T*)a.add + (okq ? abase + ((long long)tq * Hh + (hq >> 1)) * Wh + (wq >> 1) : 0));
             epl4[i][2 * gq] = okq ? l2[0] : (H)0.f;
             epl4[i][2 * gq + 1] = okq ? l2[1] : (H)0.f;
           }
@@ -325,18 +326,20 @@ __global__ __launch_bounds__(256, (KT <= 2 && !TAIL && MT == 1 && !XS) ? 3 : (KT
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           } else if (rvalid) {
+            // element by element (rows of odd length, or of 4 k + 2 points): the coordinates of the first point by division, the
+            // other seven by stepping -- two divisions per ELEMENT were most of this epilogue's time (272 us for the 48 -> 216 layer
+            // on rows of 28 before they got the group form)
             const int hw = a.eH * a.eW;
             const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
             const int T_ = (int)a.P / hw;
+            int t = (int)p / hw;
+            const int rem = (int)p - t * hw;
+            int h = rem / a.eW, w = rem - h * a.eW;
+            const T* abase = (const T*)a.add + ((long long)n * a.Ci + m) * T_ * Hh * Wh;
+#pragma unroll
             for (int e = 0; e < 8; e++) {
-              const int pe = (int)p + e;
-              const int t = pe / hw;
-              const int rem = pe - t * hw;
-              const int h = rem / a.eW, w = rem - h * a.eW;
-              if (((h | w) & 1) == 0) {
-                const long long oa = ((((long long)n * a.Ci + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
-                val[e] += to_f<T>(((const T*)a.add)[oa]);
-              }
+              if (((h | w) & 1) == 0 && t < T_) val[e] += to_f<T>(abase[((long long)t * Hh + (h >> 1)) * Wh + (w >> 1)]);
+              if (++w == a.eW) { w = 0; if (++h == a.eH) { h = 0; ++t; } }
             }
           }
         }
@@ -413,9 +416,8 @@ static inline size_t rc_lds_bytes(int MT, int KT) {
 template <typename H, int MT, int KT, int EPI, int TAIL, int E4V = 1, int XS = 0>
 static int rc_launch(PwBwdRcArgs& a, hipStream_t st) {
   if constexpr (EPI == X3D_EPI_ADD_STRIDED && E4V == 1) {
-    if constexpr (MT == 2 && KT == 7) {     // (the 28-wide planes of stage 4's first block: groups of four)
-      if ((a.eW & 7) != 0 && (a.eW & 3) == 0) return rc_launch<H, MT, KT, EPI, TAIL, 2>(a, st);
-    }
+    // rows of 28 points (stage 4's first block), of 156 (X3D-L / XL stage 2): groups of four
+    if ((a.eW & 7) != 0 && (a.eW & 3) == 0) return rc_launch<H, MT, KT, EPI, TAIL, 2>(a, st);
     if ((a.eW & 7) != 0) return rc_launch<H, MT, KT, EPI, TAIL, 0>(a, st);
   }
   const size_t lds = rc_lds_bytes(MT, KT);
