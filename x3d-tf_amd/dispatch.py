@@ -74,3 +74,44 @@ def kernel_set(rows) -> Dict[str, str]:
     for entry, kern, shape in rows:
         d.setdefault(kern, f"{entry} {shape}")
     return d
+
+
+def _pointer_values(args, st):
+    """Every integer a recorded launch hands to the library that could be an address: its positional arguments and the
+    pointer fields of its argument struct."""
+    vals = [a for a in args if isinstance(a, int) and not isinstance(a, bool)]
+    if st is not None:
+        for fname, ftype in st._fields_:
+            v = getattr(st, fname)
+            if isinstance(v, int) and not isinstance(v, bool) and ftype in (C.c_void_p,):
+                vals.append(v)
+    return [v for v in vals if v]
+
+
+def gradient_writes(model, pl) -> List[Tuple[int, str, str]]:
+    """(index in pl.bwd, entry point, parameter name) for every backward launch that is handed the address of a parameter's
+    gradient (a view of model.flat_grads).  A launch that FINISHES a gradient later than its conv launch (the pending dW of
+    a recomputed-output layer, x3d_bn_bwd_finalize_rc) shows up with its own index, which is what the data-parallel bucket
+    hooks must wait for (model.forward_backward `on_stage_done`)."""
+    lo = model.flat_grads.data_ptr()
+    hi = lo + model.flat_grads.numel() * 4
+    starts = sorted((model.grads[k].data_ptr(), k) for k in model.grads)
+    out = []
+    for i, item in enumerate(pl.bwd):
+        if item is None or not item[2]:
+            continue
+        st = pl.structs.get((id(pl.bwd), i))
+        for v in _pointer_values(item[2], st):
+            if lo <= v < hi:
+                name = [k for p, k in starts if p <= v][-1]
+                out.append((i, item[0], name))
+    return out
+
+
+def stage_of(model, name: str) -> int:
+    """Bucket of a parameter (model.grad_bucket's numbering: len(stages) = head, 0.. = residual stages, -1 = stem)."""
+    if name.startswith("conv1/"):
+        return -1
+    if name.startswith("stages/"):
+        return int(name.split("/")[1])
+    return len(model.arch.stages)

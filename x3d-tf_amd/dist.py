@@ -10,6 +10,7 @@ traffic (15 MB total for X3D-M; ~0.2 ms on a 153 GB/s xGMI link) hides under the
 depthwise/pointwise kernels.  ``backend="nccl"`` is RCCL on ROCm; the same code runs on gloo/CPU
 tensors for the multi-process tests.
 """
+import collections
 import os
 import time
 from typing import List, Optional, Sequence, Tuple
@@ -119,6 +120,7 @@ class BucketReducer:
     once (RCCL runs it on its own stream); ``finish()`` makes the current stream wait for all of them.
     With world_size 1 both are no-ops.
     """
+    EVENT_WINDOW = 64          # timing-event pairs kept alive at most (exposed_ms)
 
     def __init__(self, buckets: Sequence[torch.Tensor], group=None):
         self.buckets = list(buckets)
@@ -129,7 +131,10 @@ class BucketReducer:
         self.launched = 0          # all-reduces enqueued so far (bench.py reports them)
         self.launched_bytes = 0
         self._t_mark, self._ev_mark = None, None
-        self._pairs, self._host_s, self._host_n = [], 0.0, 0
+        # (start, done) event pairs of the most recent steps only: a training run that never asks for exposed_ms() must not
+        # accumulate two HIP events per step without bound; completed pairs that fall out of the window are folded into sums
+        self._pairs, self._host_s, self._host_n = collections.deque(), 0.0, 0
+        self._dev_ms, self._dev_n = 0.0, 0
 
     def launch(self, i: int):
         if not self.active:
@@ -165,6 +170,11 @@ class BucketReducer:
             done = torch.cuda.Event(enable_timing=True)
             done.record()
             self._pairs.append((self._ev_mark, done))      # read later (exposed_ms), after the caller's own synchronisation
+            while len(self._pairs) > self.EVENT_WINDOW:    # steps old: long finished, elapsed_time does not block
+                a, b = self._pairs.popleft()
+                if b.query():
+                    self._dev_ms += a.elapsed_time(b)
+                    self._dev_n += 1
         else:
             self._host_s += time.perf_counter() - self._t_mark
             self._host_n += 1
@@ -175,12 +185,13 @@ class BucketReducer:
         HIP-event time on the compute stream with RCCL, host wall time of the waits with a host-side backend (there it
         also contains whatever backward work was still queued on the device).  ~0 when the exchange hid behind the backward
         pass; None when no multi-rank step was measured.  Call after a device synchronisation."""
-        n = len(self._pairs) + self._host_n
+        n = len(self._pairs) + self._dev_n + self._host_n
         if n == 0:
             return None
-        total = sum(a.elapsed_time(b) for a, b in self._pairs) + 1e3 * self._host_s
+        total = sum(a.elapsed_time(b) for a, b in self._pairs) + self._dev_ms + 1e3 * self._host_s
         if reset:
-            self._pairs, self._host_s, self._host_n = [], 0.0, 0
+            self._pairs.clear()
+            self._host_s, self._host_n, self._dev_ms, self._dev_n = 0.0, 0, 0.0, 0
         return max(total / n, 0.0)
 
 

@@ -1003,6 +1003,8 @@ class X3D:
         merge_rc = os.environ.get("X3D_PW_BWD_RC_MERGE", "1") != "0"
         pending_fin = {"job": None}
 
+        pending_mark = {"stage": None}
+
         def rec_bn_bwd_finalize(bn, count, gamma, dgamma, dbeta, c, prep=None):
             fin, pending_fin["job"] = pending_fin["job"], None
             if prep is None and fin is None:
@@ -1012,6 +1014,10 @@ class X3D:
             f_ = fin if fin is not None else (None, None, None, None, 0, 0)
             pl.rec(Bk, "x3d_bn_bwd_finalize_rc", ("acc", bn.bsums), float(count), bn.mi, gamma, bn.coef, dgamma, dbeta, c,
                    w_, panel_, c0_, cin_, ("acc", f_[0]) if f_[0] is not None else None, f_[1], f_[2], f_[3], f_[4], f_[5], dt)
+            if fin is not None and pending_mark["stage"] is not None:
+                # this launch finished the dW of the FIRST block of a stage (its `a` conv's pending job): only now is every
+                # gradient of that stage final -- the stage's all-reduce bucket may start behind it, not before
+                pl.bwd_stage_marks[pending_mark["stage"]], pending_mark["stage"] = len(Bk), None
 
         for bi in range(len(pl.blocks) - 1, -1, -1):
             B = pl.blocks[bi]
@@ -1186,7 +1192,10 @@ class X3D:
             dy = nxt
             if b.index == 0:
                 pl.rec_join(Bk)
-                pl.bwd_stage_marks[b.stage] = len(Bk)   # every gradient of stages >= b.stage is final
+                if pending_fin["job"] is not None:      # the dW of this block's `a` conv rides on the NEXT finalize launch:
+                    pending_mark["stage"] = b.stage     # the mark is set there (rec_bn_bwd_finalize)
+                else:
+                    pl.bwd_stage_marks[b.stage] = len(Bk)   # every gradient of stages >= b.stage is final
 
         # ---- stem ------------------------------------------------------------------------------
         b1 = pl.bn1
@@ -1196,7 +1205,7 @@ class X3D:
         if not getattr(pl, "stem_bwd_folded", False):
             pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
         rec_bn_bwd_finalize(b1, n * P1, p["conv1/bn/gamma"], g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
-        assert pending_fin["job"] is None
+        assert pending_fin["job"] is None and pending_mark["stage"] is None
         pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
         pl.input_slots.append((Bk, len(Bk)))
