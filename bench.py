@@ -13,8 +13,11 @@ boundary, already resident in HBM), random-init weights; weak scaling (per-GPU b
 Extra objects on the JSON line:
   roofline      dominant depthwise kernel instantiation: algorithmic bytes per launch (SURVEY 8d:
                 fwd e*(X + Y), fused bwd e*(X + dY + dX)) / average launch duration measured with HIP
-                events on the launch stream inside the timed region; peak 8 TB/s.
-  kernels       the same figure for every depthwise instantiation launched.
+                events on the launch stream inside the timed region; peak 8 TB/s.  Only THAT instantiation's
+                launches (two per step) carry events in the timed region: which one dominates is found in two
+                untimed probe steps after the warm-up.
+  kernels       the same figure for every depthwise instantiation launched, from two steps AFTER the timed region
+                (52 event pairs per step stay out of `value`).
   roofline_model  BASELINE.md's whole-step figure: clips/s * 1.262 GB / 8 TB/s.
   mfma_util     MFMA utilisation of the pointwise convs (north_star's second figure): their FLOPs over their HIP-event
                 time in three extra steps after the timed region, against the dense 16-bit matrix-core peak.
@@ -89,7 +92,7 @@ class KernelTimer:
             for i in range(start, stop_):
                 name, fn, args = lst[i]
                 slot = marks.get((lname, i)) if timer.enabled else None
-                if slot is not None:
+                if slot is not None and (timer.only is None or slot[3] in timer.only):
                     e0 = torch.cuda.Event(enable_timing=True)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -102,7 +105,11 @@ class KernelTimer:
                     from x3d_tf_amd import hip
                     hip.check(st, name)
         self.enabled = False
+        self.only = None      # None: every depthwise launch; a set of instantiation names: those launches only
         pl.run = run
+
+    def reset(self):
+        self.events = []
 
     def summary(self):
         agg = {}
@@ -274,6 +281,13 @@ def main():
     timer = KernelTimer(model, pl, 2 if dtype == torch.bfloat16 else 4)
     timer.wrap(pl)
     timer.enabled = True
+    for _ in range(2):                # untimed probe: which depthwise instantiation has the largest total
+        pl = trainer.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    probe = timer.summary()
+    timer.reset()
+    timer.only = {probe[0]["kernel"]} if probe else set()
+    trainer.reducer.exposed_ms()
 
     barrier()
     torch.cuda.synchronize()
@@ -286,12 +300,20 @@ def main():
     per_rank = xdist.gather_over_ranks(elapsed, device)      # every rank's own clock around the same K steps
     elapsed = max(per_rank)
     loss = float(trainer.loss(pl).item())
+    coll = trainer.collective_stats()     # (exposed_ms over the timed steps only)
+    dominant = timer.summary()        # the dominant instantiation, HIP events inside the timed region
+    timer.reset()
+    timer.only = None
+    for _ in range(2):                # every depthwise instantiation, after the timed region
+        trainer.step(clips, labels, lr)
+    torch.cuda.synchronize()
+    timer.enabled = False
     mfma = mfma_utilisation(model, pl, trainer, clips, labels, lr) if (world == 1 and rank == 0) else None
 
     if rank == 0:
         clips_s = args.steps * B * world / elapsed
         kernels = timer.summary()
-        dom = kernels[0] if kernels else None
+        dom = dominant[0] if dominant else None
         w = A.workload(model.arch, t, s, s)
         eb = 2 if dtype == torch.bfloat16 else 4
         step_bytes_per_clip = 3 * w["total_elements"] * eb
@@ -319,7 +341,7 @@ def main():
                                    f"{args.dtype} activation storage / fp32 accumulation (matrix-core operands in {args.dtype}), random-init weights",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": loss,
-            "collectives": trainer.collective_stats(),
+            "collectives": coll,
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,

@@ -32,9 +32,9 @@ def _setup(name, overrides=None):
     return cfg, arch, params
 
 
-def _model(cfg, params, dtype, gpu):
+def _model(cfg, params, dtype, gpu, options=None):
     from x3d_tf_amd.model import X3D
-    m = X3D(cfg, dtype=dtype, device=gpu, seed=0)
+    m = X3D(cfg, dtype=dtype, device=gpu, seed=0, options=options)
     m.load_state_dict(params)
     return m
 
@@ -93,9 +93,8 @@ def test_forward_matches_committed_golden_vector(gpu):
 def test_input_batch_is_read_where_it_lies(gpu):
     """16-bit storage: the stem reads the caller's channels-last batch in place (x3d_hip.h K1, X3D_LAYOUT_NTHWC).  The same
     clips handed over as a fresh tensor, as a 2-byte-offset view (copied once: the kernels need 16-byte alignment), in fp32
-    (converted once) and through the planar fallback (X3D_NO_STEM_NTHWC) give the same probabilities bit for bit; the plan
+    (converted once) and through the planar fallback (options stem_nthwc = False) give the same probabilities bit for bit; the plan
     holds no planar copy of the batch."""
-    import os
     cfg, arch, params = _setup("XS", ["TEST.NUM_TEMPORAL_VIEWS", 2, "TEST.NUM_SPATIAL_CROPS", 1])
     torch.manual_seed(5)
     x = torch.randn(2, 4, 64, 64, 3).to(torch.bfloat16)
@@ -109,13 +108,9 @@ def test_input_batch_is_read_where_it_lies(gpu):
     assert off.data_ptr() % 16 != 0
     assert torch.equal(m(off, training=False), ref)
     assert torch.equal(m(x.float().to(gpu), training=False), ref)
-    os.environ["X3D_NO_STEM_NTHWC"] = "1"
-    try:
-        m2 = _model(cfg, params, torch.bfloat16, gpu)
-        out2 = m2(x.to(gpu), training=False)
-        assert not m2._plans[(2, 4, 64, 64, False)].x_cl
-    finally:
-        del os.environ["X3D_NO_STEM_NTHWC"]
+    m2 = _model(cfg, params, torch.bfloat16, gpu, options={"stem_nthwc": False})
+    out2 = m2(x.to(gpu), training=False)
+    assert not m2._plans[(2, 4, 64, 64, False)].x_cl
     assert torch.equal(out2, ref)
 
 

@@ -5,7 +5,6 @@ kernel's distance from the HBM roofline is visible layer by layer.
     python tools/bench_layers.py [variant] [batch] [dtype]      (on the GPU box)
 """
 import os
-os.environ["X3D_SIDE_WGRAD"] = "0"   # per-launch timing: everything on one stream
 import statistics
 import sys
 

@@ -25,19 +25,6 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const x3d_bn_fold f, in
   bn_coefs(f, cc, s1, s2, ga, be, r == 0 && c < C, sc, sh);
 }
 
-__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ mmean, const float* __restrict__ mvar,
-                                    float eps, float* ss, float* mi, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float invstd = 1.0f / sqrtf(mvar[c] + eps);
-  const float sc = gamma[c] * invstd;
-  ss[c * 2] = sc;
-  ss[c * 2 + 1] = beta[c] - mmean[c] * sc;
-  mi[c * 2] = mmean[c];
-  mi[c * 2 + 1] = invstd;
-}
-
 // dY = k1*(g - dbeta/M - xhat*dgamma/M), k1 = gamma*invstd, xhat = (y-mean)*invstd
 //    = A*g + B*y + C with A = k1, B = -k1*invstd*dgamma/M, C = -k1*dbeta/M - B*mean
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
@@ -72,16 +59,6 @@ extern "C" int x3d_bn_finalize(const double* stats, double count, const float* g
   f.eps = eps; f.momentum = momentum; f.update_moving = update_moving; f.scale_shift = scale_shift; f.mean_invstd = mean_invstd;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 2)), dim3(64), 0, (hipStream_t)stream, f, C);
   X3D_LAUNCH_CHECK("bn_finalize");
-  return X3D_OK;
-}
-
-extern "C" int x3d_bn_eval_coef(const float* gamma, const float* beta, const float* moving_mean,
-                                const float* moving_var, float eps, float* scale_shift,
-                                float* mean_invstd, int C, void* stream) {
-  X3D_REQUIRE(gamma && beta && moving_mean && moving_var && scale_shift && mean_invstd && C > 0, "bn_eval_coef: bad args");
-  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
-                     moving_mean, moving_var, eps, scale_shift, mean_invstd, C);
-  X3D_LAUNCH_CHECK("bn_eval_coef");
   return X3D_OK;
 }
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 127   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 128   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -45,16 +45,6 @@ class PwBwdArgs(C.Structure):
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
                 ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp),
                 ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp), ("x_stride", _i), ("xH", _i), ("xW", _i)]
-
-
-class PwGramArgs(C.Structure):
-    _fields_ = [("x", _vp), ("raw", _vp), ("raw_scale_shift", _vp), ("add", _vp), ("add_scale_shift", _vp), ("gram", _vp),
-                ("N", _i), ("Cin", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i)]
-
-
-class AbFwdArgs(C.Structure):
-    _fields_ = [("x", _vp), ("a_w", _vp), ("a_scale_shift", _vp), ("b_w", _vp), ("y", _vp), ("stats", _vp), ("pool", _vp),
-                ("N", _i), ("Cin", _i), ("C", _i), ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
 
 
 class EvalViewsArgs(C.Structure):
@@ -119,7 +109,6 @@ _SIGS = {
     "x3d_stats_replicas": ([], _i),
     "x3d_stats_stride": ([_i], _ll),
     "x3d_bn_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
-    "x3d_bn_eval_coef": ([_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], _i),
     "x3d_bn_eval_coef_batched": ([_vp, _i, _f, _vp], _i),
     "x3d_bn_bwd_finalize": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "x3d_pw_fwd": ([C.POINTER(PwFwdArgs), _vp], _i),
@@ -133,13 +122,6 @@ _SIGS = {
     "x3d_pw_bwd_rc_prepare": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_pw_bwd_rc_finish": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_bn_bwd_finalize_rc": ([_vp, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
-    "x3d_pw_gram_elems": ([_i], _ll),
-    "x3d_pw_gram_replicas": ([], _i),
-    "x3d_pw_gram_supported": ([C.POINTER(PwGramArgs)], _i),
-    "x3d_pw_gram": ([C.POINTER(PwGramArgs), _vp], _i),
-    "x3d_bn_finalize_gram": ([_vp, _vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _i, _i, _vp], _i),
-    "x3d_ab_fwd_supported": ([C.POINTER(AbFwdArgs)], _i),
-    "x3d_ab_fwd": ([C.POINTER(AbFwdArgs), _vp], _i),
     "x3d_pw_kernel_name": ([C.POINTER(PwFwdArgs), C.POINTER(PwDgradArgs), C.POINTER(PwWgradArgs), C.POINTER(PwBwdArgs),
                             C.c_char_p, _i], _i),
     "x3d_pw_panel_elems": ([_i, _i], _ll),

@@ -10,8 +10,12 @@ passes (they are folded into the prologue of the consuming conv and the epilogue
 one), and the backward pass is written out explicitly instead of taped.
 
 Execution model: for one (batch, clip shape, mode) a ``_Plan`` allocates every buffer once and records
-the kernel launches as pre-bound C calls; a step replays the list on the current HIP stream (and can
-be captured into a hipGraph with torch.cuda.CUDAGraph, since nothing allocates or synchronises).
+the kernel launches as pre-bound C calls; a step replays the list on the current HIP stream.  Nothing in a
+replay allocates or synchronises, but a replay is NOT capture-safe as it stands: with 16-bit storage the stem
+launches are re-bound to the CALLER's batch on every call (`_bind_input`: the clips are read in place, forward
+AND backward -- `stem_s_wgrad` reads them again, so the caller must not overwrite the batch between the two), a
+captured graph would bake that pointer in.  `options={"stem_nthwc": False}` restores the static planar input
+buffer (one conversion pass per step) for graph capture; replaying as a hipGraph measured no gain.
 """
 import ctypes as C
 import math
@@ -100,6 +104,40 @@ class _Sequential(list):
 
 
 # ------------------------------------------------------------------------------------------------
+# Plan options: which of several launch lists -- each covered by the GPU tests -- a plan records.  The defaults are the product;
+# the others document what was measured against them and serve the differential tests (X3D(cfg, options=...)).
+# They are constructor arguments, not environment switches: the product path reads no X3D_* variable.  Only with
+# X3D_EXPERIMENTS=1 (the A/B tools under tools/) are the historical variable names mapped onto them.
+PLAN_DEFAULTS = {
+    "fused_pw_bwd": True,      # x3d_pw_bwd (data + weight gradient in one launch) where it applies; False: x3d_pw_dgrad + x3d_pw_wgrad
+    "pw_bwd_rc": True,         # ... in the form that recomputes the conv output algebraically instead of reading a_raw / r_raw
+    "pw_bwd_rc_merge": True,   # its prepare / finish jobs ride on the BatchNorm-backward finalize launches
+    "pw_bwd_rc_wide": True,    # ... also for the 48 -> 216 layer
+    "stem_nthwc": True,        # the stem reads the caller's channels-last batch in place (16-bit storage)
+    "infer_train_plan": False,  # training-shaped launch list at inference
+    "bn_fold": False,          # BatchNorm finalize inside the depthwise / tail consumer (x3d_bn_fold)
+    "tail_fwd_fold": True,     # residual tail built on load by the next block's `a` conv
+    "tail_fold_wst": True,     # ... also where that conv runs the weights-stationary kernel (stages 4 / 5)
+    "tail_bwd_fold": True,     # Add + ReLU backward in the epilogue of the kernel that produces dy
+    "stem_bwd_fold": True,     # the stem BatchNorm's backward sums in the first block's `a` backward
+    "side_wgrad": False,       # unfused weight-gradient GEMMs on a side stream
+}
+_ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-default setting selects)
+    "X3D_NO_FUSED_PW_BWD": ("fused_pw_bwd", "1", False), "X3D_PW_BWD_RC": ("pw_bwd_rc", "0", False),
+    "X3D_PW_BWD_RC_MERGE": ("pw_bwd_rc_merge", "0", False), "X3D_PW_BWD_RC_WIDE": ("pw_bwd_rc_wide", "0", False),
+    "X3D_NO_STEM_NTHWC": ("stem_nthwc", "1", False), "X3D_INFER_TRAIN_PLAN": ("infer_train_plan", "1", True),
+    "X3D_BN_FOLD": ("bn_fold", "1", True), "X3D_NO_TAIL_FWD_FOLD": ("tail_fwd_fold", "1", False),
+    "X3D_NO_TAIL_FOLD_WST": ("tail_fold_wst", "1", False), "X3D_NO_TAIL_FOLD": ("tail_bwd_fold", "1", False),
+    "X3D_NO_STEM_BWD_FOLD": ("stem_bwd_fold", "1", False), "X3D_SIDE_WGRAD": ("side_wgrad", "1", True),
+}
+
+
+def _experiment_options():
+    if os.environ.get("X3D_EXPERIMENTS") != "1":
+        return {}
+    return {opt: val for var, (opt, trigger, val) in _ENV_OPTIONS.items() if os.environ.get(var) == trigger}
+
+
 class _FakeBuf:
     """Stand-in for a device buffer in a DRY plan (X3D(..., device="dry")): an address range that is never touched.
     Dry plans exist so that the launch list of a full-size configuration -- and, through x3d_pw_kernel_name /
@@ -149,11 +187,11 @@ class _Plan:
         self._zero_views: List = []
         self.bwd_stage_marks: Dict[int, int] = {}
         self.structs: Dict = {}
-        # experiment switch X3D_SIDE_WGRAD=1: the weight-gradient GEMMs that have no consumer before the optimizer run on
+        # option side_wgrad: the weight-gradient GEMMs that have no consumer before the optimizer run on
         # a SIDE stream, concurrently with the data-gradient chain (see X3D._record_backward).  Measured on X3D-M B=64
         # (r01i): 27.03 ms/step on one stream, 27.4 ms with the side stream -- the kernels already compete for the same
         # CUs and HBM, so the default is one stream.
-        self.side_on = training and os.environ.get("X3D_SIDE_WGRAD") == "1"
+        self.side_on = training and model.opt["side_wgrad"]
         self.side_entries = set()      # (id(list), index) of launches that go to the side stream
         self.input_slots = []          # (list, index) of the launches whose first argument is the input batch
         self.x_cl = False              # those launches read the caller's channels-last batch in place (no planar copy)
@@ -277,10 +315,16 @@ class X3D:
             the host with address-only stand-ins for the activation buffers, plans can be RECORDED (to enumerate
             launches and their kernel instantiations, x3d_tf_amd/dispatch.py) and every attempt to run one raises.
         seed: seed of the Glorot-uniform initialisation.
+        options: overrides of PLAN_DEFAULTS (which launch list a plan records; differential tests and A/B tools).
     """
 
-    def __init__(self, cfg, dtype=torch.float32, device="cuda", seed: int = 0, in_channels: int = 3):
+    def __init__(self, cfg, dtype=torch.float32, device="cuda", seed: int = 0, in_channels: int = 3, options: Optional[dict] = None):
         self.cfg = cfg
+        self.opt = dict(PLAN_DEFAULTS, **_experiment_options())
+        for k, v in (options or {}).items():
+            if k not in PLAN_DEFAULTS:
+                raise ValueError(f"unknown plan option {k!r} (known: {sorted(PLAN_DEFAULTS)})")
+            self.opt[k] = bool(v)
         self.arch: Arch = build_arch(cfg)
         self.num_classes = self.arch.num_classes
         self._num_preds = self.arch.num_preds
@@ -302,11 +346,8 @@ class X3D:
         self._build_layers()
         self._dropout_mask_override = None
         self.last_loss = None
-        # fused dgrad + wgrad of the pointwise convs (x3d_pw_bwd) where it applies; X3D_NO_FUSED_PW_BWD=1 records
-        # the separate kernels instead (A/B measurements)
-        self._fuse_pw_bwd = os.environ.get("X3D_NO_FUSED_PW_BWD", "0") != "1"
-        # ... in the form that recomputes the `a` conv's output algebraically instead of reading a_raw (X3D_PW_BWD_RC=0: A/B)
-        self._rc_pw_bwd = os.environ.get("X3D_PW_BWD_RC", "1") != "0"
+        self._fuse_pw_bwd = self.opt["fused_pw_bwd"]
+        self._rc_pw_bwd = self.opt["pw_bwd_rc"]
         self._stats_r = int(hip.load().x3d_stats_replicas())
 
     # ---------------------------------------------------------------------------------------------
@@ -586,7 +627,7 @@ class X3D:
         # ---- input + stem ------------------------------------------------------------------------------------------
         pl.x_in = None
         # 16-bit storage: the stem's matrix-core kernels read the caller's channels-last batch in place (x3d_hip.h K1)
-        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and os.environ.get("X3D_NO_STEM_NTHWC") != "1"   # (A/B switch)
+        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and self.opt["stem_nthwc"]
         pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
         pl.s_raw = view(abuf, n, a.c1, t, h1, w1)     # conv_s output: dead once conv_t has run, shares the `a` scratch
         pl.y0 = view(ybuf[0], n, a.c1, t, h1, w1)
@@ -682,7 +723,7 @@ class X3D:
         return pl
 
     def _make_plan(self, n, t, h, w, training) -> _Plan:
-        if not training and os.environ.get("X3D_INFER_TRAIN_PLAN") != "1":   # (A/B: =1 replays the training-shaped list)
+        if not training and not self.opt["infer_train_plan"]:
             return self._make_infer_plan(n, t, h, w)
         a, p = self.arch, self.params
         pl = _Plan(self, n, t, h, w, training)
@@ -714,11 +755,11 @@ class X3D:
             else:   # inference: every layer's coefficients in ONE launch at the head of the forward list (below)
                 pl.bn_eval_items.append(hip.BnEvalItem(_p(g), _p(be), _p(mm), _p(mv), _p(b.ss), _p(b.mi), b.c))
 
-        # experiment switch X3D_BN_FOLD=1 (training): the finalize of a BatchNorm whose consumer has one channel per
+        # option bn_fold (training): the finalize of a BatchNorm whose consumer has one channel per
         # workgroup (depthwise conv, residual tail) runs inside that consumer (x3d_bn_fold) -- 57 launches fewer per
         # X3D-M step, worth 0.08 ms with single-copy statistics.  With the replicated accumulators every consumer
         # workgroup would have to sum 32 copies first, so the separate x3d_bn_finalize launches are the default.
-        fold_on = training and os.environ.get("X3D_BN_FOLD") == "1"
+        fold_on = training and self.opt["bn_fold"]
         pl.folds = []
 
         def bn_fold(b, count):
@@ -735,7 +776,7 @@ class X3D:
         # ---- input + stem --------------------------------------------------------------------
         pl.x_in = None  # bound at run time (NTHWC user tensor)
         # 16-bit storage: the stem's matrix-core kernels read the caller's channels-last batch in place (x3d_hip.h K1)
-        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and os.environ.get("X3D_NO_STEM_NTHWC") != "1"   # (A/B switch)
+        pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and self.opt["stem_nthwc"]
         pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
         h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         pl.s_raw = pl.act(n, a.c1, t, h1, w1)
@@ -759,7 +800,7 @@ class X3D:
         pending = {"tail": None if fold_on or not training else stem_tail}
         if not training and not fold_on:
             pl.rec(F, "x3d_tail_fwd", pl.t_raw, pl.bn1.ss, None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
-        fold_fwd = training and not fold_on and os.environ.get("X3D_NO_TAIL_FWD_FOLD") != "1"
+        fold_fwd = training and not fold_on and self.opt["tail_fwd_fold"]
 
         def fold_pending_tail(st):
             """st: the x3d_pw_fwd arguments of the conv that reads the pending block output first."""
@@ -773,7 +814,7 @@ class X3D:
             # the prologue itself -- x3d_pw_kernel_name of the folded form says which kernel it gets)
             if (fold_fwd and st.stride == 1 and pl.lib.x3d_pw_fwd_tail_supported(C.byref(ft))
                     and (not hip.pw_kernel_name(st).startswith(("pw_gemm_wst", "pw_gemm_ws_kernel"))
-                         or (hip.pw_kernel_name(ft).startswith("pw_gemm_wst") and os.environ.get("X3D_NO_TAIL_FOLD_WST") != "1"))):
+                         or (hip.pw_kernel_name(ft).startswith("pw_gemm_wst") and self.opt["tail_fold_wst"]))):
                 if pl.blocks:
                     pl.blocks[-1].tail_fwd_folded = True
                 else:
@@ -995,12 +1036,12 @@ class X3D:
         # ---- residual blocks, last to first ----------------------------------------------------
         # The Add + ReLU backward of a block (g = dy * [y > 0] with the BN_c / BN_r backward sums) is applied by the kernel that
         # PRODUCES dy -- the `a`-conv backward of the next block, whose conv input is this block's y -- wherever the fused
-        # x3d_pw_bwd covers that layer with its tail epilogue; x3d_tail_bwd remains for the other blocks (and X3D_NO_TAIL_FOLD=1)
-        fold_tail = self._fuse_pw_bwd and os.environ.get("X3D_NO_TAIL_FOLD") != "1"
+        # x3d_pw_bwd covers that layer with its tail epilogue; x3d_tail_bwd remains for the other blocks (and tail_bwd_fold = False)
+        fold_tail = self._fuse_pw_bwd and self.opt["tail_bwd_fold"]
         # The per-step operands of the recomputed-output `a` backward ride on the BatchNorm-backward finalize launches that
         # are on the critical path anyway (x3d_bn_bwd_finalize_rc): the panel of a layer with ITS bn_a finalize, the dW of a
-        # layer with the NEXT finalize recorded after its x3d_pw_bwd (X3D_PW_BWD_RC_MERGE=0: separate launches, A/B).
-        merge_rc = os.environ.get("X3D_PW_BWD_RC_MERGE", "1") != "0"
+        # layer with the NEXT finalize recorded after its x3d_pw_bwd (pw_bwd_rc_merge = False: separate launches).
+        merge_rc = self.opt["pw_bwd_rc_merge"]
         pending_fin = {"job": None}
 
         pending_mark = {"stage": None}
@@ -1129,7 +1170,7 @@ class X3D:
             rc = None
             pe = int(pl.lib.x3d_pw_bwd_rc_panel_elems(b.inner, b.cin)) if (self._fuse_pw_bwd and self._rc_pw_bwd and
                                                                             self.dtype != torch.float32) else 0
-            if b.inner > 127 and os.environ.get("X3D_PW_BWD_RC_WIDE") == "0":      # (A/B switch: the 48 -> 216 layer unfused as before)
+            if b.inner > 127 and not self.opt["pw_bwd_rc_wide"]:      # (the 48 -> 216 layer unfused as before)
                 pe = 0
             if pe:
                 rc = (pl.act(pe), pl.f32(b.cin), pl.acc64((int(pl.lib.x3d_pw_bwd_rc_sums_elems(b.inner, b.cin)) + 1) // 2))
@@ -1153,7 +1194,7 @@ class X3D:
                 if not supported(ft):
                     ft = None
             stem_ft = None
-            if fold_tail and prev is None and os.environ.get("X3D_NO_STEM_BWD_FOLD") != "1":
+            if fold_tail and prev is None and self.opt["stem_bwd_fold"]:
                 # B.x is the stem output y0 = relu(bn(t_raw)): the same epilogue masks dx with [y0 > 0] and takes the stem
                 # BatchNorm's backward sums (sum dx, sum dx * t_raw) -- the x3d_relu_bn_bwd_reduce pass over dy0 / t_raw goes
                 stem_ft = a_bwd_args(_p(pl.t_raw), None)
