@@ -207,6 +207,7 @@ MODEL_TRAIN_FP32 = [
     ("XS", 2, 4, 78),     # odd extents end to end: 78 -> 39 -> 20 -> 10 -> 5 -> 3 (X3D-L's 39 -> 20 TF-SAME pads, odd stride-2 planes)
     ("M", 2, 16, 112),    # T = 16 and 56 / 28 / 14 / 7 planes: the deep-prefetch depthwise variants (dw_pd.hip) inside the model
     ("S", 1, 2, 160),     # BASELINE config 2's real planes (80 / 40 / 20 / 10 / 5)
+    ("S", 8, 13, 160),    # BASELINE config 2 at its real clip size (13 x 160^2), a quarter of its batch: the CPU oracle takes ~10 s
 ]
 MODEL_TRAIN_HALF = [     # teacher-forced block by block, bf16 and fp16 storage
     ("S", 3, 5, 96),      # odd point counts: scalar / generic kernel paths

@@ -18,6 +18,7 @@ import torch
 
 from tests import shapes as S
 from tests.util import hip_relu_masks, rel_l2, relu_mask_mismatch, report
+from x3d_tf_amd.arch import block_prefix
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -221,7 +222,8 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     x = torch.randn(n, t, s, s, 3).to(dtype).float()
     labels = torch.randint(0, arch.num_classes, (n,))
     mask = (torch.rand(n, arch.fc1_out) >= arch.dropout_rate).float()
-    m = _model(cfg, params, dtype, gpu)
+    # (X3D_TEST_RC=0: the same test over the stored-output backward -- the seed sweeps under profiles/ run both)
+    m = _model(cfg, params, dtype, gpu, options={"pw_bwd_rc": False} if os.environ.get("X3D_TEST_RC") == "0" else None)
     m.set_dropout_mask(mask)
     # fp16 gradients get the reference's loss scaling (LossScaleOptimizer, train.py:99-100): a power of two, so the oracle
     # replay -- fed the device's own (scaled) upstream gradient per block -- rounds exactly as the device does
@@ -309,6 +311,108 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     bad = {k: e for k, e in errs.items() if e > (lim_se if k.endswith(("/se_fc1/bias", "/se_fc2/bias")) else lim)}
     assert not bad, f"relative L2 error beyond {lim} ({lim_se} for the SE biases) (teacher-forced, {dtype}): {bad}"
     assert sorted(errs.values())[len(errs) // 2] < med        # median
+
+
+# Limits of the differential test below, per storage type: (tensors no recomputed-output launch can reach, every other
+# tensor, the SE biases / BatchNorm gammas that are cancelling sums).  The first is fp32 atomic summation order only.  The
+# second is what the fold's two extra operand roundings allow: the panel [W^T A | W^T B W] is rounded to the storage type
+# once per step (2^-9 relative in bf16, 2^-12 in fp16 -- test_pw_bwd_rc bounds the resulting dx error at 2e-2 / 3e-3 of the
+# tensor maximum), and every gradient downstream of such a dx inherits it LINEARLY (the forward state is shared, so the
+# backward pass is a linear map of the upstream gradient: nothing amplifies).
+RC_DIFF_LIMITS = {torch.bfloat16: (2e-5, 1.5e-2, 3e-2), torch.float16: (2e-5, 2.5e-3, 5e-3)}
+
+
+@pytest.mark.parametrize("dtype", S.HALF_DTYPES)
+@pytest.mark.parametrize("name,n,t,s", [("M", 1, 4, 224), ("L", 1, 2, 312)])
+def test_recomputed_output_backward_against_the_stored_output_backward(gpu, name, n, t, s, dtype):
+    """The WIRING of the recomputed-output `a` / shortcut backward (pw_bwd_rc.hip) inside a plan, pinned differentially:
+    the same plan, the same forward state, the backward list recorded twice -- plan option pw_bwd_rc on (the product) and
+    off (the round-3 kernels that read a_raw / r_raw) -- on the headline's planes (X3D-M 224^2) and config 4's (X3D-L 312^2).
+    What the kernel tests cannot see and the teacher-forced test sees only at 6.5e-2: which coefficient table and which
+    rc_sums buffer a launch is handed, x3d_bn_bwd_finalize_rc finishing an EARLIER layer's dW on a LATER launch, the panel
+    rebuilt per step (the second round below runs after the weights changed: a panel left over from the first step would be
+    an O(1) error).  Gradients no recomputed-output launch can reach agree to fp32 summation order; all others to the
+    operand-rounding bound stated at RC_DIFF_LIMITS."""
+    from tests.util import record_alternate_backward
+    from x3d_tf_amd import hip
+    cfg, arch, params = _setup(name)
+    torch.manual_seed(int(os.environ.get("X3D_TEST_SEED", "2")))
+    x = torch.randn(n, t, s, s, 3).to(dtype)
+    labels = torch.randint(0, arch.num_classes, (n,))
+    mask = (torch.rand(n, arch.fc1_out) >= arch.dropout_rate).float()
+    m = _model(cfg, params, dtype, gpu)
+    m.set_dropout_mask(mask)
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    xg = x.to(gpu)
+    pl = m.forward_backward(xg, labels.to(gpu), loss_scale=ls)          # builds the plan
+    torch.cuda.synchronize()
+    assert any(getattr(B, "a_bwd_rc", False) for B in pl.blocks), "no recomputed-output launch in this plan: nothing to compare"
+    alt = record_alternate_backward(m, pl, xg, pw_bwd_rc=False)
+    assert not any(alt.info["a_bwd_rc"])
+    names_rc = {i for i, (nm, fn, a_) in enumerate(pl.bwd) if nm == "x3d_bn_bwd_finalize_rc"}
+    assert names_rc and not any(nm in ("x3d_bn_bwd_finalize_rc", "x3d_pw_bwd_rc_prepare", "x3d_pw_bwd_rc_finish") for nm, _, _ in alt.lst)
+
+    # which gradients can a recomputed-output launch reach?  Walk the blocks in backward order: everything recorded before the
+    # first such launch is out of reach; from there on every dx -- and every gradient computed from it -- is downstream.
+    reach, seen = {}, False
+    for B in reversed(pl.blocks):
+        pre = block_prefix(B.spec)
+        for k in m.grads:
+            if k.startswith(pre + "/"):
+                reach[k] = seen
+        if getattr(B, "r_bwd_rc", False):
+            reach[pre + "/residual/kernel"] = True
+            seen = True
+        if getattr(B, "a_bwd_rc", False):
+            reach[pre + "/bottleneck/a/kernel"] = True
+            seen = True
+    for k in m.grads:
+        reach.setdefault(k, seen if k.startswith("conv1/") else False)      # the stem is last, the head first
+    assert any(reach.values()) and not all(reach.values())
+
+    def one_round(tag):
+        m._pack_panels()
+        pl.zero_buf.zero_()
+        pl.run(pl.fwd, 0, pl.grad_scale_slot)
+        hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
+                 pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), ls / n, n, arch.num_classes)
+        snap = pl.zero_buf.clone()
+        out = []
+        for runner in (lambda: pl.run(pl.bwd), alt.run, lambda: pl.run(pl.bwd)):
+            pl.zero_buf.copy_(snap)
+            m.flat_grads.zero_()
+            runner()
+            torch.cuda.synchronize()
+            assert torch.isfinite(m.flat_grads).all()
+            out.append({k: g.detach().double().cpu().clone() for k, g in m.grads.items()})
+        g1, g0, g1b = out
+        lim_same, lim, lim_c = RC_DIFF_LIMITS[dtype]
+        errs = {}
+        for B in pl.blocks + [None]:
+            ks = [k for k in g1 if (k.startswith(block_prefix(B.spec) + "/") if B is not None else not k.startswith("stages/"))]
+            rms = sorted(g0[k].norm().item() / g0[k].numel() ** 0.5 for k in ks)
+            floor_rms = 0.05 * rms[len(rms) // 2]           # (cancelling sums: as in the teacher-forced test)
+            for k in ks:
+                den = max(g0[k].norm().item(), floor_rms * g0[k].numel() ** 0.5) + 1e-30
+                errs[k] = ((g1[k] - g0[k]).norm().item() / den, (g1[k] - g1b[k]).norm().item() / den)
+        worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:4]
+        print(f"rc differential {tag}:", name, dtype, "worst (rc vs stored, rc vs rc again):", worst,
+              "out of reach:", sum(1 for v in reach.values() if not v), "of", len(reach))
+        bad = {}
+        for k, (e, e_same) in errs.items():
+            cancelling = k.endswith(("/se_fc1/bias", "/se_fc2/bias", "/gamma"))
+            limit = lim_same if not reach[k] else (lim_c if cancelling else lim)
+            if e > limit or e_same > lim_same * (1 if not reach[k] else 50):
+                bad[k] = (e, e_same, limit)
+        assert not bad, f"{tag}: recomputed-output backward vs stored-output backward beyond the limits: {bad}"
+
+    one_round("step 1")
+    # other weights, same plan: the per-step operands (panel, c0, coefficient tables) must follow
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    nt = m.n_trainable_flat
+    m.flat_params[:nt].mul_((1.0 + 0.25 * torch.randn(nt, generator=g)).to(gpu))
+    one_round("step 2 (perturbed weights)")
 
 
 def test_train_step_bf16_end_to_end_sanity(gpu):

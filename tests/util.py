@@ -88,3 +88,62 @@ def rnd(shape, dtype, gen, scale=1.0):
     """random tensor representable in `dtype`, returned as (device-dtype tensor on cpu, fp64 copy)"""
     t = (torch.randn(shape, generator=gen, dtype=torch.float32) * scale).to(dtype)
     return t, t.double()
+
+
+class AltBackward:
+    """A second backward launch list recorded over the SAME forward buffers of a training plan with other plan options
+    (record_alternate_backward).  run() replays it from the forward state `snapshot` captured."""
+
+    def __init__(self, model, pl, lst, extra):
+        self.model, self.pl, self.lst, self.extra = model, pl, lst, extra
+
+    def run(self):
+        self.extra.zero_()
+        self.pl.run(self.lst)
+
+
+def record_alternate_backward(model, pl, x, **options):
+    """Differential tests: record the backward pass of `pl` AGAIN with `options` overriding the model's plan options, against
+    the forward tensors the plan already owns -- so that two backward variants (e.g. pw_bwd_rc on / off) can be compared on
+    bit-identical forward state, where the backward pass is a LINEAR map of the upstream gradient and differences do not
+    amplify.  New fp64 accumulators of the second list live in their own zeroed buffer; x = the bound input batch (the
+    stem's weight-gradient launch of the new list is bound to it).  Test-side only: pokes at plan internals."""
+    import torch
+    from x3d_tf_amd.model import PLAN_DEFAULTS, X3D
+    assert all(k in PLAN_DEFAULTS for k in options)
+    saved_opt, saved_fuse, saved_rc = model.opt, model._fuse_pw_bwd, model._rc_pw_bwd
+    saved_bwd, saved_marks = pl.bwd, dict(pl.bwd_stage_marks)
+    saved_pl = {k: getattr(pl, k, None) for k in ("gbuf", "dv", "ga", "rtmp", "coef_nc", "se_scratch", "g5", "dh1", "dpooled",
+                                                  "ds", "stem_bwd_folded")}
+    saved_b = [{k: getattr(B, k, None) for k in ("bwd_start", "bwd_stop", "dy_view", "dx_view", "tail_folded", "a_bwd_rc",
+                                                 "r_bwd_rc", "db", "nc_sums")} for B in pl.blocks]
+    try:
+        model.opt = dict(model.opt, **{k: bool(v) for k, v in options.items()})
+        model._fuse_pw_bwd, model._rc_pw_bwd = model.opt["fused_pw_bwd"], model.opt["pw_bwd_rc"]
+        for B in pl.blocks:
+            B.tail_folded = False
+        pl.bwd, pl.bwd_stage_marks = [], {}
+        n0 = len(pl._zero_chunks)
+        model._record_backward(pl)
+        alt = pl.bwd
+        new = pl._zero_chunks[n0:]
+        extra = torch.zeros(max(sum(c[0] for c in new), 1), dtype=torch.float64, device=model.device)
+        off = 0
+        for numel, shape in new:
+            pl._zero_views.append(extra[off:off + numel].view(shape))
+            off += numel
+        X3D._resolve(pl, alt)
+        info = dict(tail_folded=[bool(B.tail_folded) for B in pl.blocks], a_bwd_rc=[bool(getattr(B, "a_bwd_rc", False)) for B in pl.blocks],
+                    stem_bwd_folded=bool(getattr(pl, "stem_bwd_folded", False)))
+    finally:
+        model.opt, model._fuse_pw_bwd, model._rc_pw_bwd = saved_opt, saved_fuse, saved_rc
+        pl.bwd, pl.bwd_stage_marks = saved_bwd, saved_marks
+        for k, v in saved_pl.items():
+            setattr(pl, k, v)
+        for B, d in zip(pl.blocks, saved_b):
+            for k, v in d.items():
+                setattr(B, k, v)
+    model._bind_input(pl, x)          # (the input slots include the new list's stem launch)
+    ab = AltBackward(model, pl, alt, extra)
+    ab.info = info
+    return ab
