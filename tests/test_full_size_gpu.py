@@ -130,7 +130,9 @@ def test_block0_a_backward_recomputed_output_full_size(gpu, dtype):
             for j, rf in refs:
                 worst_dx = max(worst_dx, _check(f"dx[{j}:{j + CH}]", dx[j:j + CH], rf, rt, at * max(scale, 1e-30)))
             refs = []
-    tol = _wtol(dtype)
+    # (measured: 2.5e-6 / 1.9e-6 of the maximum -- profiles/r05_full_size_fp64_checks.txt -- although the sum cancels to 1e-3 of
+    # its terms; the kernel tests' limit for this quantity is 1e-3 / 4e-4, here a tenth of it)
+    tol = 0.1 * _wtol(dtype)
     e_dw = _check("dw", dw.double() - 0.5, dw_ref, tol, tol * dw_ref.abs().max().item())
     st = 3e-3 if dtype == torch.bfloat16 else 5e-4
     sref = torch.stack([ts1, ts2], 1)
@@ -171,7 +173,7 @@ def test_stage5_weight_gradient_full_size(gpu, dtype, which):
     dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)
     ops.pw_wgrad(g, yraw, coef, x, dw, in_ss=ss, in_gate=gate, in_act=act)
     torch.cuda.synchronize()
-    tol = _wtol(dtype)
+    tol = 0.3 * _wtol(dtype)        # (measured 6.3e-5 / 1.4e-5 of the maximum)
     e = _check("dw", dw.double() - 0.5, ref, tol, tol * ref.abs().max().item())
     print(f"full-size stage-5 `{which}` weight gradient {dtype}: err {e:.2e} of max (limit {tol:.0e})")
 
@@ -228,7 +230,7 @@ def test_depthwise_56_backward_full_size(gpu, dtype):
         s1 += gs.sum((0, 2, 3, 4))
         s2 += (gs * araw[i:i + CH].double()).sum((0, 2, 3, 4))
         del dB, z, act, pa, pb, dA, ref, gs
-    wtol = _wtol(dtype) if mx else 2e-4
+    wtol = _wtol(dtype) if mx else 2e-5        # (vector kernel, fp32 products: measured 5.6e-7 of the maximum)
     e = _check("dw", dw.double().view(c, 3, 3, 3) - 0.25, dw_ref, wtol, wtol * dw_ref.abs().max().item())
     st = 3e-3 if dtype == torch.bfloat16 else 5e-4
     sref = torch.stack([s1, s2], 1)
