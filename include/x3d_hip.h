@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 128
+#define X3D_ABI_VERSION 129
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -246,9 +246,25 @@ typedef struct {
    * the gradient at the SAMPLED pixels, the operand of the `a` backward's X3D_EPI_ADD_STRIDED): x_stride = 2, x is the block
    * input [N][Cin][T][xH][xW] with H = ceil(xH / 2), W = ceil(xW / 2).  x_stride = 0 / 1: dense (x [N][Cin][T][H][W]). */
   int x_stride, xH, xW;
+  /* PARTIAL weight-gradient slabs instead of fp32 atomics (dw_slab == NULL: off, dw += by atomics).  The persistent
+   * weights-stationary kernels (one workgroup per CU, each with its own [Cout][Cin] partial sum) end in a flush of
+   * workgroups x Cout x Cin floats; as device-scope atomics that runs at ~1.3 TB/s whatever the schedule (measured: 13-24 us of
+   * a 85-105 us launch), as plain stores into a slab per workgroup at the store rate.  With dw_slab the launch writes
+   * x3d_pw_bwd_dw_parts(a) slabs of Cout * Cin floats (dw is not touched) and a LATER launch adds them up in a fixed order:
+   * x3d_dw_slab_reduce, or the two reduce slots of x3d_se_bnb_bwd (a small launch that is on the critical path anyway).
+   * x3d_pw_bwd_dw_parts() == 0: the kernel behind this call has no slab form (leave dw_slab NULL). */
+  float* dw_slab;              /* x3d_pw_bwd_dw_parts(a) * Cout * Cin floats, 16-byte aligned */
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
+int x3d_pw_bwd_dw_parts(const x3d_pw_bwd_args* a);
+/* dw [elems] += sum over `parts` slabs of [elems] floats, parts in ascending order per element (deterministic) */
+typedef struct {
+  const float* slab;           /* NULL: no job */
+  float* dw;
+  int parts, elems;
+} x3d_dw_reduce_job;
+int x3d_dw_slab_reduce(const x3d_dw_reduce_job* jobs, int n_jobs, void* stream);
 /* the per-step operands of the recomputed-output form.  panel_elems == 0: the layer shape is not covered (covered: Cin <= 32
  * with Cout <= 127; Cin 33..48 with Cout 65..127 or 193..223 -- the X3D stage-3 `a` convs and the first one of stage 4).  prepare: after x3d_bn_bwd_finalize produced `coef` [Cout][4]; finish: after x3d_pw_bwd, dw [Cout][Cin] +=. */
 long long x3d_pw_bwd_rc_panel_elems(int Cout, int Cin);
@@ -375,6 +391,7 @@ typedef struct {
   float* coef_nc;              /* out [N][C][4] */
   float* scratch;              /* N*(2*C + Wd) floats: dpool [N][C] | dz2 [N][C] | dz1 [N][Wd] */
   int N, C, Wd;
+  x3d_dw_reduce_job reduce[2]; /* weight-gradient slabs of earlier x3d_pw_bwd launches, added up by extra workgroups of this launch */
 } x3d_se_bnb_bwd_args;
 int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream);
 

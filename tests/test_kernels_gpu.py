@@ -22,6 +22,11 @@ def _ops():
     return ops
 
 
+def hip_lib():
+    from x3d_tf_amd import hip
+    return hip.load()
+
+
 def _oracle():
     from oracle import x3d_oracle as O
     return O
@@ -217,13 +222,18 @@ def _wtol(dtype):
     return 2e-4 if dtype == torch.float32 else (1e-3 if dtype == torch.bfloat16 else 4e-4)
 
 
+@pytest.mark.parametrize("slab", [False, True])
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD)
-def test_pw_bwd_oracle(gpu, dtype, shape):
+def test_pw_bwd_oracle(gpu, dtype, shape, slab):
     """x3d_pw_bwd (fused data + weight gradient, one pass over dY) against an fp64 restatement of both gradients --
-    directly, not through the unfused kernels (test_pw_bwd_fused below keeps the bit-for-bit comparison with those)."""
+    directly, not through the unfused kernels (test_pw_bwd_fused below keeps the bit-for-bit comparison with those).
+    slab: the weight gradient through per-workgroup partial slabs + x3d_dw_slab_reduce (x3d_hip.h dw_slab) -- the form the
+    plans use where the kernel behind the call has it (the persistent weights-stationary kernels)."""
     ops = _ops()
     n, cin, cout, t, h, w, epi = shape
+    if slab and not hip_lib().x3d_pw_bwd_dw_parts(S.pw_bwd_struct(shape, dtype)):
+        pytest.skip("no slab form behind this call")
     g_ = _gen(31)
     gy, gyd = rnd((n, cout, t, h, w), dtype, g_)
     yraw, yrd = rnd((n, cout, t, h, w), dtype, g_)
@@ -245,7 +255,7 @@ def test_pw_bwd_oracle(gpu, dtype, shape):
         xin = round_to(_affine(braw.float(), bss, gate, 2), dtype)       # the conv input: swish(gate * bn_b(braw))
         ncs = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
         ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, ops.EPI_SWISH_BWD, braw=dev(braw), b_ss=dev(bss),
-                        gate=dev(gate), nc_sums=ncs)
+                        gate=dev(gate), nc_sums=ncs, slab=slab)
     else:
         x, xd = rnd((n, cin, t, h, w), dtype, g_)
         xin = xd
@@ -259,7 +269,7 @@ def test_pw_bwd_oracle(gpu, dtype, shape):
             up[:, :, :, ::2, ::2] = addd
             dx_ref = dx_ref + up
             e = ops.EPI_ADD_STRIDED
-        ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, e, x=dev(x), add=dev(add))
+        ok = ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx, dw, e, x=dev(x), add=dev(add), slab=slab)
     torch.cuda.synchronize()
     assert ok, "fused kernel should cover this shape"
     rt, at = tol_gemm(dtype)
@@ -490,6 +500,15 @@ def test_pw_bwd_tail(gpu, dtype, shape):
         report("tail_sums_r", sr, ref_r, st, st * max(1.0, ref_r.abs().max().item()))
     else:
         assert float((sr - 0.25).abs().max()) == 0.0
+    # the weight gradient through partial slabs (x3d_hip.h dw_slab; what the plans record where the kernel has the form)
+    if hip_lib().x3d_pw_bwd_dw_parts(S.pw_bwd_struct(shape, dtype)):
+        dx3 = torch.empty_like(dx)
+        dw3 = torch.full_like(dw, 0.5)
+        sc3 = torch.full_like(sc, 0.25)
+        assert ops.pw_bwd(dev(gy), dev(yraw), dev(coef), dp, dx3, dw3, e, x=dev(x), add=dev(add), tail_c=dev(tc), tail_sums_c=sc3, slab=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dx3, dx)
+        report("dw (slabs)", dw3, dw_ref + 0.5, _wtol(dtype), _wtol(dtype) * dw_ref.abs().max().item())
     # the same launch without the fold followed by x3d_tail_bwd gives the same masked gradient bit for bit
     dx2 = torch.empty_like(dx)
     dw2 = torch.zeros_like(dw)
@@ -1028,13 +1047,21 @@ def test_se(gpu):
     report("gate", gate, gr, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("jobs", [0, 1, 2])
 @pytest.mark.parametrize("dims", [(3, 12, 8), (70, 40, 16)])
 @pytest.mark.parametrize("has_se", [True, False])
-def test_se_bnb_bwd(gpu, has_se, dims):
+def test_se_bnb_bwd(gpu, has_se, dims, jobs):
     """Composite check: u = bn_b(braw) [train stats] -> (SE gate) -> v ; L = sum(dv * v).  The kernel sees only the
-    per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients."""
+    per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients.
+    jobs: weight-gradient slab reductions riding on the launch (x3d_hip.h `reduce`): dw += the sum of its partial slabs, parts
+    in ascending order -- compared with the fp64 sum and, bit for bit, with x3d_dw_slab_reduce on the same slabs."""
     ops = _ops()
     n, c, wd = dims
+    gj = _gen(90 + jobs)
+    red = []
+    for parts, elems in [(251, 96 * 216), (7, 20 * 12)][:jobs]:
+        slab = torch.randn((parts * elems,), generator=gj).to(gpu)
+        red.append((slab, torch.full((elems,), 0.5, device=gpu), parts))
     T, H, W = 2, 3, 4
     P = T * H * W
     g_ = _gen(9)
@@ -1076,8 +1103,15 @@ def test_se_bnb_bwd(gpu, has_se, dims):
                   dw2=torch.zeros((c, wd), device=gpu), db2=torch.zeros(c, device=gpu),
                   scratch=torch.empty(n * (2 * c + wd), device=gpu))
     ops.se_bnb_bwd(nc_sums, pool_sums if has_se else None, P, f32(bss), f32(bmi), f32(gamma), dgam, dbet, coef_nc,
-                   n, c, **kw)
+                   n, c, reduce=red, **kw)
     torch.cuda.synchronize()
+    for slab, dwj, parts in red:
+        ref = slab.double().view(parts, -1).sum(0) + 0.5
+        report("slab sum", dwj, ref, 1e-6, 2e-6 * ref.abs().max().item())
+        alone = torch.full_like(dwj, 0.5)
+        ops.dw_slab_reduce([(slab, alone, parts)])
+        torch.cuda.synchronize()
+        assert torch.equal(alone, dwj), "the reduce slots of x3d_se_bnb_bwd and x3d_dw_slab_reduce add in the same order"
     cf = coef_nc.cpu().double()
     dB = cf[:, :, 0, None, None, None] * dv + cf[:, :, 1, None, None, None] * braw + cf[:, :, 2, None, None, None]
     report("dbraw", dB, grads[0], 2e-4, 2e-5)

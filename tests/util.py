@@ -135,6 +135,9 @@ def record_alternate_backward(model, pl, x, **options):
         X3D._resolve(pl, alt)
         info = dict(tail_folded=[bool(B.tail_folded) for B in pl.blocks], a_bwd_rc=[bool(getattr(B, "a_bwd_rc", False)) for B in pl.blocks],
                     stem_bwd_folded=bool(getattr(pl, "stem_bwd_folded", False)))
+        # the scratch buffers of the new list are referenced from argument structs by ADDRESS only (the plan keeps them alive as
+        # attributes, which are restored to the first list's below): hold them here, or the allocator hands their memory out again
+        owned = [getattr(pl, k, None) for k in saved_pl] + [extra]
     finally:
         model.opt, model._fuse_pw_bwd, model._rc_pw_bwd = saved_opt, saved_fuse, saved_rc
         pl.bwd, pl.bwd_stage_marks = saved_bwd, saved_marks
@@ -145,5 +148,5 @@ def record_alternate_backward(model, pl, x, **options):
                 setattr(B, k, v)
     model._bind_input(pl, x)          # (the input slots include the new list's stem launch)
     ab = AltBackward(model, pl, alt, extra)
-    ab.info = info
+    ab.info, ab.owned = info, owned
     return ab

@@ -317,6 +317,29 @@ static inline bool xcd_pad_enabled() {
   return x3d_env_int("X3D_XCD_PAD", 1) != 0;
 }
 
+// CUs of the current device (256 on MI355X; also the answer without a device: dry-run dispatch / x3d_pw_bwd_dw_parts on a
+// build host).  The persistent one-workgroup-per-CU kernels size their grids from it.
+static inline int x3d_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipGetDevice(&dev) == hipSuccess &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+    (void)hipGetLastError();
+  }
+  return cus;
+}
+// grid of a persistent kernel over `total` work items on `cus` CUs: an equal share per workgroup, no empty workgroup
+static inline void x3d_persistent_grid(long long total, int cus, long long* per_block, long long* grid) {
+  *per_block = (total + cus - 1) / cus;
+  if (*per_block < 1) *per_block = 1;
+  *grid = (total + *per_block - 1) / *per_block;
+}
+
 #define STATS_R 32
 __host__ __device__ __forceinline__ long long stats_stride(int C) {
   const long long need = ((long long)C * 2 + 63) & ~63ll;

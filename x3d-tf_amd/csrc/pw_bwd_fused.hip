@@ -605,9 +605,11 @@ static int fb_pick(PwBwdArgs& a, hipStream_t st) {
 // the weights-stationary fused backward of the stage-4 `c` conv (pw_bwd_wst.hip)
 bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b);
 int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st);
+int pw_bwd_wst_dw_parts(const x3d_pw_bwd_args* b);
 // ... and of the stage-4 `a` conv (pw_bwd_wsta.hip)
 bool pw_bwd_wsta_applies(const x3d_pw_bwd_args* b);
 int pw_bwd_wsta(const x3d_pw_bwd_args* b, hipStream_t st);
+int pw_bwd_wsta_dw_parts(const x3d_pw_bwd_args* b);
 
 // ... and the form that recomputes the conv output instead of reading it (pw_bwd_rc.hip; rc_panel != NULL)
 bool pw_bwd_rc_supported(const x3d_pw_bwd_args* b);
@@ -643,9 +645,19 @@ static bool fb_supported(const x3d_pw_bwd_args* b) {
 
 extern "C" int x3d_pw_bwd_supported(const x3d_pw_bwd_args* b) { return (b && fb_supported(b)) ? 1 : 0; }
 
+// partial-slab form of the weight-gradient flush (x3d_hip.h dw_slab): the persistent weights-stationary kernels only
+extern "C" int x3d_pw_bwd_dw_parts(const x3d_pw_bwd_args* b) {
+  if (!b || b->rc_panel || b->N <= 0 || b->T <= 0 || b->H <= 0 || b->W <= 0) return 0;
+  if (pw_bwd_wst_applies(b)) return pw_bwd_wst_dw_parts(b);
+  if (pw_bwd_wsta_applies(b)) return pw_bwd_wsta_dw_parts(b);
+  return 0;
+}
+
 extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   X3D_REQUIRE(b && b->g && b->dx, "pw_bwd: null pointer");
   X3D_REQUIRE(b->N > 0 && b->Cin > 0 && b->Cout > 0 && b->T > 0 && b->H > 0 && b->W > 0, "pw_bwd: bad extents");
+  X3D_REQUIRE(!b->dw_slab || (x3d_pw_bwd_dw_parts(b) > 0 && ((uintptr_t)b->dw_slab % 16) == 0),
+              "pw_bwd: dw_slab given but the kernel behind this call has no slab form (x3d_pw_bwd_dw_parts() == 0)");
   if (b->rc_panel) return pw_bwd_rc(b, (hipStream_t)stream);
   X3D_REQUIRE(b->yraw && b->coef && b->dw, "pw_bwd: null pointer");
   X3D_REQUIRE(fb_supported(b), "pw_bwd: shape / alignment / epilogue not covered by the fused kernel "

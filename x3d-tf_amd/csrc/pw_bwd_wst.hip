@@ -28,6 +28,8 @@ struct PwBwdWstArgs {
   int N, Co, Ci;
   long long P;
   int tiles_per_block;
+  float* slab;                                          // NULL | per-workgroup partial dW slabs [gridDim.x][Co][Ci] (plain stores)
+  int noflush;                                          // experiments build only (X3D_PW_BWD_NOFLUSH=1): timing without the dW flush
 };
 
 #define BW_YRP 40    // pitch (elements) of the row-read dY copy and of the Xh tile: 80 B = 5 units, odd -> b128 rows conflict-free
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   const int total_tiles = tiles_per_n * a.N;
   const int tile_begin = blockIdx.x * a.tiles_per_block;
   const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
-  if (tile_begin >= tile_end) return;
+  if (tile_begin >= tile_end) return;                  // (never: the grid has no empty workgroup -- a slab would stay unwritten)
   float* myOs = Os + wid * 32 * OP;
   const bool mw = wid < NW && wid < mt;                // this wave owns a row block of input channels
 
@@ -260,15 +262,21 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   }
   flush_sums(n_prev);
 
-  // ---- dW partial -> global (fp32 atomics)
-  if (mw) {
+  // ---- dW partial -> this workgroup's slab (plain stores, added up by a later launch: x3d_hip.h dw_slab), or -> dw by fp32
+  // atomics.  256 workgroups x 83 KB of device-scope atomics take 17-24 us of this ~100 us launch whatever the schedule
+  // (they execute at the memory side at ~1.3 TB/s chip-wide); the same bytes as stores ~4 us.
+  if (mw && !a.noflush) {
     const int ci = wid * 32 + r;
+    float* slab = a.slab ? a.slab + (long long)blockIdx.x * a.Co * a.Ci : nullptr;
 #pragma unroll
     for (int s = 0; s < CT; s++)
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int co = s * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (co < a.Co && ci < a.Ci) atomicAdd(&a.dw[(long long)co * a.Ci + ci], acc_dw[s][e]);
+        if (co < a.Co && ci < a.Ci) {
+          if (slab) slab[(long long)co * a.Ci + ci] = acc_dw[s][e];
+          else atomicAdd(&a.dw[(long long)co * a.Ci + ci], acc_dw[s][e]);
+        }
       }
   }
 }
@@ -299,19 +307,16 @@ static int bw_launch(PwBwdWstArgs& a, hipStream_t st) {
   X3D_DESCRIBE("pw_bwd_wst_kernel<%s, %d, %d, %d>", HV<H>::name, NW, KS, CT);
   auto kern = pw_bwd_wst_kernel<H, NW, KS, CT>;
   static bool attr_set = false;
-  static int cus = 256;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     attr_set = true;
   }
   const long long total_tiles = ceil_div_ll(a.P, 32) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_bwd_wst: too many tiles");
-  const long long tpb = ceil_div_ll(total_tiles, (long long)cus);
+  long long tpb, gx;
+  x3d_persistent_grid(total_tiles, x3d_device_cus(), &tpb, &gx);
   a.tiles_per_block = (int)tpb;
-  const long long gx = ceil_div_ll(total_tiles, tpb);
+  a.noflush = x3d_env_int("X3D_PW_BWD_NOFLUSH", 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_wst");
   return X3D_OK;
@@ -325,8 +330,15 @@ int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st) {
   a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
   a.wp = b->w_panel; a.wp_rows = (b->Cin + 31) & ~31;
   a.dx = b->dx; a.braw = b->braw; a.b_ss = b->b_scale_shift; a.egate = b->gate; a.nc_sums = b->nc_sums;
-  a.dw = b->dw;
+  a.dw = b->dw; a.slab = b->dw_slab;
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin;
   a.P = (long long)b->T * b->H * b->W;
   return b->dtype == X3D_F16 ? bw_launch<f16>(a, st) : bw_launch<bf16>(a, st);
+}
+
+// number of partial dW slabs a launch writes when given dw_slab (= its grid: x3d_hip.h)
+int pw_bwd_wst_dw_parts(const x3d_pw_bwd_args* b) {
+  long long tpb, gx;
+  x3d_persistent_grid(ceil_div_ll((long long)b->T * b->H * b->W, 32) * b->N, x3d_device_cus(), &tpb, &gx);
+  return (int)gx;
 }

@@ -30,6 +30,8 @@ struct PwBwdWstaArgs {
   int N, Co, Ci;
   long long P;
   int tiles_per_block;
+  float* slab;                                          // NULL | per-workgroup partial dW slabs [gridDim.x][Co][Ci] (plain stores)
+  int noflush;                                          // experiments build only (X3D_PW_BWD_NOFLUSH=1): timing without the dW flush
 };
 
 #define BWA_RP 40    // pitch (elements) of the row-read tiles: 80 B = 5 units, odd -> b128 rows conflict-free
@@ -268,15 +270,19 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wsta_kernel(const PwBwdWstaArgs
       }
     }
   }
-  // ---- dW partial -> global (fp32 atomics)
-  if (ww) {
+  // ---- dW partial -> this workgroup's slab (plain stores; pw_bwd_wst.hip), or -> dw by fp32 atomics
+  if (ww && !a.noflush) {
+    float* slab = a.slab ? a.slab + (long long)blockIdx.x * a.Co * a.Ci : nullptr;
 #pragma unroll
     for (int s = 0; s < NW; s++) {
       const int ci = s * 32 + r;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int co = wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (co < a.Co && ci < a.Ci) atomicAdd(&a.dw[(long long)co * a.Ci + ci], acc_dw[s][e]);
+        if (co < a.Co && ci < a.Ci) {
+          if (slab) slab[(long long)co * a.Ci + ci] = acc_dw[s][e];
+          else atomicAdd(&a.dw[(long long)co * a.Ci + ci], acc_dw[s][e]);
+        }
       }
     }
   }
@@ -312,19 +318,16 @@ static int bwa_launch(PwBwdWstaArgs& a, hipStream_t st) {
   X3D_DESCRIBE("pw_bwd_wsta_kernel<%s, %d, %d, %d, %d>", HV<H>::name, NW, KS, CT, TAIL);
   auto kern = pw_bwd_wsta_kernel<H, NW, KS, CT, TAIL>;
   static bool attr_set = false;
-  static int cus = 256;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     attr_set = true;
   }
   const long long total_tiles = ceil_div_ll(a.P, 32) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_bwd_wsta: too many tiles");
-  const long long tpb = ceil_div_ll(total_tiles, (long long)cus);
+  long long tpb, gx;
+  x3d_persistent_grid(total_tiles, x3d_device_cus(), &tpb, &gx);
   a.tiles_per_block = (int)tpb;
-  const long long gx = ceil_div_ll(total_tiles, tpb);
+  a.noflush = x3d_env_int("X3D_PW_BWD_NOFLUSH", 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_wsta");
   return X3D_OK;
@@ -337,11 +340,17 @@ int pw_bwd_wsta(const x3d_pw_bwd_args* b, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
   a.wp = b->w_panel; a.wp_rows = (b->Cin + 31) & ~31;
-  a.dx = b->dx; a.add = b->add; a.x = b->x; a.dw = b->dw;
+  a.dx = b->dx; a.add = b->add; a.x = b->x; a.dw = b->dw; a.slab = b->dw_slab;
   a.tail_c = b->tail_c; a.tail_r = b->tail_r; a.tail_sums_c = b->tail_sums_c; a.tail_sums_r = b->tail_sums_r;
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin;
   a.P = (long long)b->T * b->H * b->W;
   const bool tail = b->tail_c != nullptr;
   if (b->dtype == X3D_F16) return tail ? bwa_launch<f16, 1>(a, st) : bwa_launch<f16, 0>(a, st);
   return tail ? bwa_launch<bf16, 1>(a, st) : bwa_launch<bf16, 0>(a, st);
+}
+
+int pw_bwd_wsta_dw_parts(const x3d_pw_bwd_args* b) {
+  long long tpb, gx;
+  x3d_persistent_grid(ceil_div_ll((long long)b->T * b->H * b->W, 32) * b->N, x3d_device_cus(), &tpb, &gx);
+  return (int)gx;
 }

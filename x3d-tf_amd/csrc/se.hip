@@ -73,6 +73,64 @@ extern "C" int x3d_se_fwd(const double* pool_sums, double P, const float* b_scal
   return X3D_OK;
 }
 
+// Weight-gradient slabs (x3d_hip.h dw_slab): dw[e] += sum_p slab[p][e], p ascending -- a fixed order, so the result does not
+// depend on timing.  A 256-thread workgroup owns 64 consecutive elements: thread (q = tid & 15, pg = tid >> 4) loads the float4
+// q of the parts pg, pg + 16, ... (16 loads in flight for 256 parts, 256 contiguous bytes per part and 16 lanes), the sixteen
+// part groups meet in LDS.  Read once from L2 / the Infinity Cache right after the producer wrote them: ~20 MB in a few us,
+// hidden behind the small launch that carries it.
+#define DWR_EPB 64        // elements per workgroup
+__device__ __forceinline__ void dw_slab_reduce_block(const x3d_dw_reduce_job& j, int blk, float (*part)[16][4]) {
+  const int tid = threadIdx.x, q = tid & 15, pg = tid >> 4;
+  const long long e0 = (long long)blk * DWR_EPB + q * 4;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const bool full = e0 + 4 <= j.elems;      // elems % 4 == 0 is required: a float4 is inside or outside
+  if (full) {
+    const float* src = j.slab + e0;
+    int p = pg;
+    for (; p + 48 < j.parts; p += 64) {      // four independent chains
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] += *(const f32x4*)(src + (long long)(p + 16 * u) * j.elems);
+    }
+    for (; p < j.parts; p += 16) acc[0] += *(const f32x4*)(src + (long long)p * j.elems);
+  }
+  const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int c = 0; c < 4; c++) part[pg][q][c] = t[c];
+  __syncthreads();
+  if (tid < 64) {                            // element tid of the block: the sixteen part groups in a fixed order
+    const int qq = tid >> 2, c = tid & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) v += part[g][qq][c];
+    const long long e = (long long)blk * DWR_EPB + tid;
+    if (e < j.elems) j.dw[e] += v;
+  }
+}
+static inline int dw_reduce_blocks(const x3d_dw_reduce_job& j) { return j.slab ? ceil_div(j.elems, DWR_EPB) : 0; }
+static bool dw_reduce_job_ok(const x3d_dw_reduce_job& j) {
+  return !j.slab || (j.dw && j.parts > 0 && j.elems > 0 && (j.elems % 4) == 0 && ((uintptr_t)j.slab % 16) == 0);
+}
+
+__global__ __launch_bounds__(256) void dw_slab_reduce_kernel(x3d_dw_reduce_job j0, x3d_dw_reduce_job j1, int nb0) {
+  __shared__ float part[16][16][4];
+  const int b = blockIdx.x;
+  if (b < nb0) dw_slab_reduce_block(j0, b, part);
+  else dw_slab_reduce_block(j1, b - nb0, part);
+}
+
+extern "C" int x3d_dw_slab_reduce(const x3d_dw_reduce_job* jobs, int n_jobs, void* stream) {
+  X3D_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 2, "dw_slab_reduce: one or two jobs");
+  x3d_dw_reduce_job j0 = jobs[0], j1;
+  memset(&j1, 0, sizeof(j1));
+  if (n_jobs == 2) j1 = jobs[1];
+  X3D_REQUIRE(dw_reduce_job_ok(j0) && dw_reduce_job_ok(j1), "dw_slab_reduce: bad job (elems % 4 == 0, 16-byte aligned slab, dw)");
+  const int nb0 = dw_reduce_blocks(j0), nb1 = dw_reduce_blocks(j1);
+  if (nb0 + nb1 == 0) return X3D_OK;
+  hipLaunchKernelGGL(dw_slab_reduce_kernel, dim3(nb0 + nb1), dim3(256), 0, (hipStream_t)stream, j0, j1, nb0);
+  X3D_LAUNCH_CHECK("dw_slab_reduce");
+  return X3D_OK;
+}
+
 // stage 1 (one block per sample): gradient through gate -> fc2 -> ReLU -> fc1 -> pooled.  No atomics: the
 // per-sample vectors dz2 [N][C] (pre-sigmoid grad of fc2) and dz1 [N][Wd] (pre-ReLU grad of fc1) go to scratch
 // and stage 2 contracts them over the samples.  scratch = dpool [N][C] | dz2 [N][C] | dz1 [N][Wd].
@@ -140,8 +198,16 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const x3d_se_bnb_bwd_args a
 // Each gradient element has exactly one writer, so the += are plain read-modify-writes.
 // With SE the workgroup has FOUR waves: wave 0 does the BatchNorm part, and all four split the sequential pass over the samples
 // of the SE weight gradients (64 dependent rounds of loads in one wave were ~12 of the kernel's ~16 us on the 432-channel layers)
-__global__ __launch_bounds__(256) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se) {
+__global__ __launch_bounds__(256) void bnb_bwd_kernel(const x3d_se_bnb_bwd_args a, int has_se, int nb0) {
   __shared__ float part[4][3][64];
+  if ((int)blockIdx.x >= a.C) {        // extra workgroups: the weight-gradient slabs of earlier launches (a.reduce)
+    __shared__ float rpart[16][16][4];
+    const int b = (int)blockIdx.x - a.C;
+    if (b < nb0) dw_slab_reduce_block(a.reduce[0], b, rpart);
+    else dw_slab_reduce_block(a.reduce[1], b - nb0, rpart);
+    return;
+  }
+  if (blockDim.x == 256 && !has_se && threadIdx.x >= 64) return;   // (launched wide only for the reduce workgroups)
   const int c = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int C = a.C, N = a.N;
   if (wid == 0) {
@@ -227,7 +293,9 @@ extern "C" int x3d_se_bnb_bwd(const x3d_se_bnb_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(se_bwd_kernel, dim3(a->N), dim3(256), 0, st, *a);
     X3D_LAUNCH_CHECK("se_bwd");
   }
-  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(a->C), dim3(has_se ? 256 : 64), 0, st, *a, has_se);
+  X3D_REQUIRE(dw_reduce_job_ok(a->reduce[0]) && dw_reduce_job_ok(a->reduce[1]), "se_bnb_bwd: bad reduce job (elems % 4 == 0, 16-byte aligned slab, dw)");
+  const int nb0 = dw_reduce_blocks(a->reduce[0]), nb1 = dw_reduce_blocks(a->reduce[1]);
+  hipLaunchKernelGGL(bnb_bwd_kernel, dim3(a->C + nb0 + nb1), dim3((has_se || nb0 + nb1) ? 256 : 64), 0, st, *a, has_se, nb0);
   X3D_LAUNCH_CHECK("bnb_bwd");
   return X3D_OK;
 }

@@ -76,16 +76,32 @@ def kernel_set(rows) -> Dict[str, str]:
     return d
 
 
+def _struct_pointers(st, out):
+    for fname, ftype in st._fields_:
+        v = getattr(st, fname)
+        if ftype is C.c_void_p:
+            if isinstance(v, int) and v:
+                out.append(v)
+        elif isinstance(v, C.Structure):
+            _struct_pointers(v, out)
+        elif isinstance(v, C.Array):
+            for item in v:
+                if isinstance(item, C.Structure):
+                    _struct_pointers(item, out)
+
+
 def _pointer_values(args, st):
     """Every integer a recorded launch hands to the library that could be an address: its positional arguments and the
-    pointer fields of its argument struct."""
-    vals = [a for a in args if isinstance(a, int) and not isinstance(a, bool)]
+    pointer fields of its argument struct (nested structs and arrays of structs included: the reduce jobs of x3d_se_bnb_bwd)."""
+    vals = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and a]
+    for a in args:
+        if isinstance(a, C.Array):
+            for item in a:
+                if isinstance(item, C.Structure):
+                    _struct_pointers(item, vals)
     if st is not None:
-        for fname, ftype in st._fields_:
-            v = getattr(st, fname)
-            if isinstance(v, int) and not isinstance(v, bool) and ftype in (C.c_void_p,):
-                vals.append(v)
-    return [v for v in vals if v]
+        _struct_pointers(st, vals)
+    return vals
 
 
 def gradient_writes(model, pl) -> List[Tuple[int, str, str]]:

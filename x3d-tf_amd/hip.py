@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 128   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 129   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -44,7 +44,12 @@ class PwBwdArgs(C.Structure):
                 ("x", _vp), ("dw", _vp),
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
                 ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp),
-                ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp), ("x_stride", _i), ("xH", _i), ("xW", _i)]
+                ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp), ("x_stride", _i), ("xH", _i), ("xW", _i),
+                ("dw_slab", _vp)]
+
+
+class DwReduceJob(C.Structure):
+    _fields_ = [("slab", _vp), ("dw", _vp), ("parts", _i), ("elems", _i)]
 
 
 class EvalViewsArgs(C.Structure):
@@ -95,7 +100,7 @@ class SeBnbBwdArgs(C.Structure):
                 ("b_mean_invstd", _vp), ("gamma_b", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp),
                 ("b2", _vp), ("gate", _vp), ("hidden", _vp), ("dw1", _vp), ("db1", _vp), ("dw2", _vp),
                 ("db2", _vp), ("dgamma_b", _vp), ("dbeta_b", _vp), ("coef_nc", _vp), ("scratch", _vp),
-                ("N", _i), ("C", _i), ("Wd", _i)]
+                ("N", _i), ("C", _i), ("Wd", _i), ("reduce", DwReduceJob * 2)]
 
 
 _SIGS = {
@@ -117,6 +122,8 @@ _SIGS = {
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
     "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
+    "x3d_pw_bwd_dw_parts": ([C.POINTER(PwBwdArgs)], _i),
+    "x3d_dw_slab_reduce": ([C.POINTER(DwReduceJob), _i, _vp], _i),
     "x3d_pw_bwd_rc_panel_elems": ([_i, _i], _ll),
     "x3d_pw_bwd_rc_sums_elems": ([_i, _i], _ll),
     "x3d_pw_bwd_rc_prepare": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),

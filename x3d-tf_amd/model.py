@@ -121,6 +121,8 @@ PLAN_DEFAULTS = {
     "tail_bwd_fold": True,     # Add + ReLU backward in the epilogue of the kernel that produces dy
     "stem_bwd_fold": True,     # the stem BatchNorm's backward sums in the first block's `a` backward
     "side_wgrad": False,       # unfused weight-gradient GEMMs on a side stream
+    "dw_slab": True,           # persistent fused backward kernels store per-workgroup partial weight gradients (plain stores) that
+                               #   the next x3d_se_bnb_bwd launch adds up, instead of flushing them with fp32 atomics
 }
 _ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-default setting selects)
     "X3D_NO_FUSED_PW_BWD": ("fused_pw_bwd", "1", False), "X3D_PW_BWD_RC": ("pw_bwd_rc", "0", False),
@@ -129,6 +131,7 @@ _ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-defa
     "X3D_BN_FOLD": ("bn_fold", "1", True), "X3D_NO_TAIL_FWD_FOLD": ("tail_fwd_fold", "1", False),
     "X3D_NO_TAIL_FOLD_WST": ("tail_fold_wst", "1", False), "X3D_NO_TAIL_FOLD": ("tail_bwd_fold", "1", False),
     "X3D_NO_STEM_BWD_FOLD": ("stem_bwd_fold", "1", False), "X3D_SIDE_WGRAD": ("side_wgrad", "1", True),
+    "X3D_NO_DW_SLAB": ("dw_slab", "1", False),
 }
 
 
@@ -1043,6 +1046,35 @@ class X3D:
         # layer with the NEXT finalize recorded after its x3d_pw_bwd (pw_bwd_rc_merge = False: separate launches).
         merge_rc = self.opt["pw_bwd_rc_merge"]
         pending_fin = {"job": None}
+        # Weight-gradient SLABS (x3d_hip.h dw_slab): the persistent fused backward kernels of stage 4 end in a flush of 256
+        # workgroups x [Cout][Cin] floats -- as device-scope atomics 13-24 us of a 85-105 us launch (profiles/r05_noflush.txt), as
+        # plain stores into a slab per workgroup a few.  The slabs are added up by extra workgroups of the NEXT x3d_se_bnb_bwd
+        # launch (every block has one, 12 us of latency on the critical path anyway): the `c` conv's by its own block's, the `a`
+        # conv's by the block below's.  Two slab buffers per role, reused by every block (stream order).
+        slab_on = self.opt["dw_slab"] and self.dtype != torch.float32
+        slab_bufs = {}
+        pending_reduce = {"a": None}
+
+        def dw_slab_job(st, role, dw):
+            """st: the x3d_pw_bwd arguments about to be recorded; returns its reduce job (and points st at the slab) or None."""
+            parts = int(pl.lib.x3d_pw_bwd_dw_parts(C.byref(st))) if slab_on else 0
+            if parts <= 0:
+                return None
+            elems = st.Cout * st.Cin
+            buf = slab_bufs.get((role, parts * elems))
+            if buf is None:
+                buf = slab_bufs[(role, parts * elems)] = pl.f32(parts * elems)
+                pl.keep.append(buf)
+            st.dw_slab = _p(buf)
+            return hip.DwReduceJob(_p(buf), _p(dw), parts, elems)
+
+        def flush_pending_reduce():
+            """a slab nobody has added up yet, in front of a point where its gradient must be final: its own small launch"""
+            job, pending_reduce["a"] = pending_reduce["a"], None
+            if job is not None:
+                jobs = (hip.DwReduceJob * 1)(job)
+                pl.keep.append(jobs)
+                pl.rec(Bk, "x3d_dw_slab_reduce", jobs, 1)
 
         pending_mark = {"stage": None}
 
@@ -1088,7 +1120,9 @@ class X3D:
             fc = hip.PwBwdArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), dc.w_panel, _p(dvv), EPI_SWISH_BWD, None,
                                _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, None, _p(g[f"{q}/c/kernel"]), n, b.inner,
                                b.cout, t, B.ho, B.wo, dt)
+            c_job = None
             if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fc)):
+                c_job = dw_slab_job(fc, "c", g[f"{q}/c/kernel"])
                 pl.rec(Bk, "x3d_pw_bwd", ("field", fc, {"nc_sums": B.nc_sums}))
             else:
                 # Weight gradients feed nothing but the optimizer: they run on the side stream next to the data-gradient
@@ -1104,6 +1138,10 @@ class X3D:
                 _p(g.get(f"{q}/se_fc1/bias")), _p(g.get(f"{q}/se_fc2/kernel")), _p(g.get(f"{q}/se_fc2/bias")),
                 _p(g[f"{q}/bn_b/gamma"]), _p(g[f"{q}/bn_b/beta"]), _p(pl.coef_nc), _p(pl.se_scratch), n, b.inner,
                 b.se_width)
+            if c_job is not None:
+                se.reduce[0] = c_job
+            if pending_reduce["a"] is not None:      # the `a` conv of the block above (recorded just before this block)
+                se.reduce[1], pending_reduce["a"] = pending_reduce["a"], None
             pl.rec(Bk, "x3d_se_bnb_bwd", ("field", se, {"nc_sums": B.nc_sums, "pool_sums": B.pool}))
             # b (fused data + weight gradient), emits grad wrt BN_a output with the ReLU mask applied
             gaa = pl.ga[:B.a_raw.numel()]
@@ -1211,6 +1249,8 @@ class X3D:
                 rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
             if B.a_bwd_rc and not merge_rc:
                 pl.rec(Bk, "x3d_pw_bwd_rc_prepare", p[f"{q}/a/kernel"], B.bn_a.coef, rc[0], rc[1], b.inner, b.cin, dt)
+            if chosen is not None and rc is None:
+                pending_reduce["a"] = dw_slab_job(chosen, "a", g[f"{q}/a/kernel"])
             if ft is not None:
                 prev.tail_folded = True
                 pl.rec(Bk, "x3d_pw_bwd", ("field", ft, dict(fields, tail_sums_c=prev.bn_c.bsums,
@@ -1232,6 +1272,7 @@ class X3D:
             B.bwd_stop, B.dx_view = len(Bk), nxt.view(B.x.shape)
             dy = nxt
             if b.index == 0:
+                flush_pending_reduce()                  # (the next x3d_se_bnb_bwd belongs to the stage below: behind this stage's mark)
                 pl.rec_join(Bk)
                 if pending_fin["job"] is not None:      # the dW of this block's `a` conv rides on the NEXT finalize launch:
                     pending_mark["stage"] = b.stage     # the mark is set there (rec_bn_bwd_finalize)
@@ -1246,7 +1287,7 @@ class X3D:
         if not getattr(pl, "stem_bwd_folded", False):
             pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
         rec_bn_bwd_finalize(b1, n * P1, p["conv1/bn/gamma"], g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
-        assert pending_fin["job"] is None and pending_mark["stage"] is None
+        assert pending_fin["job"] is None and pending_mark["stage"] is None and pending_reduce["a"] is None
         pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
                g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
         pl.input_slots.append((Bk, len(Bk)))

@@ -201,9 +201,11 @@ def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None
 
 
 def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_ss=None, gate=None, nc_sums=None,
-           tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None):
+           tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None, slab=False):
     """Fused dgrad + wgrad (x3d_pw_bwd).  g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]; dw: [Cout,Cin] +=.
     tail_c (/ tail_r) + their [Cin, 2] fp64 sums: the folded Add + ReLU backward of the block whose output is x.
+    slab: the weight gradient through per-workgroup partial slabs + x3d_dw_slab_reduce instead of fp32 atomics (None is
+    returned when the kernel behind the call has no slab form).
     Returns False (nothing launched) when the fused kernel does not cover the call."""
     _chk(g, yraw, coef, w_panel, dx, dw, x, add, braw, b_ss, gate, nc_sums, tail_c, tail_r, tail_sums_c, tail_sums_r)
     n, cout, t, h, ww = g.shape
@@ -214,8 +216,33 @@ def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_s
     import ctypes as C
     if not hip.load().x3d_pw_bwd_supported(C.byref(a)):
         return False
+    if slab:
+        parts = int(hip.load().x3d_pw_bwd_dw_parts(C.byref(a)))
+        if parts <= 0:
+            return None
+        buf = torch.full((parts * cout * cin,), float("nan"), dtype=torch.float32, device=g.device)   # (every slab element must be written)
+        a.dw_slab = ptr(buf)
+        hip.call_struct("x3d_pw_bwd", a)
+        dw_slab_reduce([(buf, dw, parts)])
+        return True
     hip.call_struct("x3d_pw_bwd", a)
     return True
+
+
+def dw_reduce_jobs(jobs):
+    """[(slab [parts * elems] fp32, dw [elems...] fp32, parts), ...] -> a ctypes array of x3d_dw_reduce_job"""
+    arr = (hip.DwReduceJob * max(len(jobs), 1))()
+    for i, (slab_, dw_, parts) in enumerate(jobs):
+        _chk(slab_, dw_)
+        assert slab_.numel() == parts * dw_.numel()
+        arr[i] = hip.DwReduceJob(ptr(slab_), ptr(dw_), parts, dw_.numel())
+    return arr
+
+
+def dw_slab_reduce(jobs):
+    """dw += sum of its partial slabs (x3d_dw_slab_reduce): one or two jobs."""
+    arr = dw_reduce_jobs(jobs)
+    hip.call("x3d_dw_slab_reduce", arr, len(jobs))
 
 
 def pw_bwd_rc(g, x, w, coef, dx, dw, epi, add, tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None, x_stride=1):
@@ -303,13 +330,16 @@ def se_fwd(pool_sums, P, b_ss, w1, b1, w2, b2, gate, hidden):
 
 def se_bnb_bwd(nc_sums, pool_sums, P, b_ss, b_mi, gamma_b, dgamma_b, dbeta_b, coef_nc, N, C,
                w1=None, b1=None, w2=None, b2=None, gate=None, hidden=None, dw1=None, db1=None,
-               dw2=None, db2=None, scratch=None):
+               dw2=None, db2=None, scratch=None, reduce=()):
+    """reduce: up to two (slab, dw, parts) weight-gradient slab jobs added up by extra workgroups of the launch."""
     _chk(nc_sums, pool_sums, b_ss, b_mi, gamma_b, dgamma_b, dbeta_b, coef_nc, w1, b1, w2, b2, gate,
          hidden, dw1, db1, dw2, db2, scratch)
     a = hip.SeBnbBwdArgs(ptr(nc_sums), ptr(pool_sums), float(P), ptr(b_ss), ptr(b_mi), ptr(gamma_b),
                          ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), ptr(hidden), ptr(dw1),
                          ptr(db1), ptr(dw2), ptr(db2), ptr(dgamma_b), ptr(dbeta_b), ptr(coef_nc),
                          ptr(scratch), N, C, 0 if w1 is None else w1.shape[0])
+    for i, job in enumerate(dw_reduce_jobs(list(reduce))[:len(reduce)]):
+        a.reduce[i] = job
     hip.call_struct("x3d_se_bnb_bwd", a)
 
 
