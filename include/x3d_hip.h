@@ -311,8 +311,11 @@ typedef struct {
   int in_act;
   float* dw;                   /* [Cout][Cin] += */
   int N, Cin, Cout, T, H, W, stride, dtype; /* T,H,W: INPUT extents (as in fwd) */
+  float* dw_slab;              /* NULL | partial slabs instead of atomics, as x3d_pw_bwd_args.dw_slab: x3d_pw_wgrad_dw_parts(a) * Cout * Cin
+                                * floats, every one of them written (dw untouched); added up by x3d_dw_slab_reduce / x3d_se_bnb_bwd */
 } x3d_pw_wgrad_args;
 int x3d_pw_wgrad(const x3d_pw_wgrad_args* a, void* stream);
+int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* a);   /* 0: the kernel behind this call has no slab form */
 
 /* Which kernel instantiation a pointwise launch with these arguments runs ("pw_gemm_wst_kernel<1, 100, 6, 1, 27, 1>", ...),
  * without launching anything: the dispatch of x3d_pw_fwd / x3d_pw_dgrad / x3d_pw_wgrad / x3d_pw_bwd in dry-run mode (works

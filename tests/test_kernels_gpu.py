@@ -225,7 +225,7 @@ def _wtol(dtype):
 @pytest.mark.parametrize("slab", [False, True])
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD)
-def test_pw_bwd_oracle(gpu, dtype, shape, slab):
+def test_pw_bwd_oracle(gpu, dtype, shape, slab=False):
     """x3d_pw_bwd (fused data + weight gradient, one pass over dY) against an fp64 restatement of both gradients --
     directly, not through the unfused kernels (test_pw_bwd_fused below keeps the bit-for-bit comparison with those).
     slab: the weight gradient through per-workgroup partial slabs + x3d_dw_slab_reduce (x3d_hip.h dw_slab) -- the form the
@@ -736,11 +736,16 @@ def test_pw_dgrad(gpu, dtype, shape, epi, panel):
         report("nc_sums", ncs, sref, 10 * _stol(dtype), 10 * _stol(dtype) * max(1.0, sref.abs().max().item()))
 
 
+@pytest.mark.parametrize("slab", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", S.PW_WGRAD)   # N, Cin, Cout, T, H, W, stride, prologue
-def test_pw_wgrad(gpu, dtype, shape):
+def test_pw_wgrad(gpu, dtype, shape, slab=False):
+    """slab: through per-point-chunk partial slabs + x3d_dw_slab_reduce (x3d_hip.h dw_slab), where the kernel behind the call
+    has the form (the 12-tile groups: the stage-5 layers)."""
     ops = _ops()
     n, cin, cout, t, h, w, stride, pro = shape
+    if slab and not hip_lib().x3d_pw_wgrad_dw_parts(S.pw_wgrad_struct(shape, dtype)):
+        pytest.skip("no slab form behind this call")
     g_ = _gen(4)
     ho, wo = -(-h // stride), -(-w // stride)
     x, xd = rnd((n, cin, t, h, w), dtype, g_)
@@ -760,8 +765,8 @@ def test_pw_wgrad(gpu, dtype, shape):
         xin = xin[:, :, :, ::stride, ::stride]
     ref = torch.einsum("nothw,ncthw->oc", dyraw, xin)
     dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)   # += semantics
-    ops.pw_wgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), x.to(gpu), dw, in_ss=None if ss is None else ss.to(gpu),
-                 in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride)
+    assert ops.pw_wgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), x.to(gpu), dw, in_ss=None if ss is None else ss.to(gpu),
+                        in_gate=None if gate is None else gate.to(gpu), in_act=act, stride=stride, slab=slab)
     torch.cuda.synchronize()
     tol = _wtol(dtype)
     report("dw", dw, ref + 0.5, tol, tol * ref.abs().max().item())
@@ -1050,7 +1055,7 @@ def test_se(gpu):
 @pytest.mark.parametrize("jobs", [0, 1, 2])
 @pytest.mark.parametrize("dims", [(3, 12, 8), (70, 40, 16)])
 @pytest.mark.parametrize("has_se", [True, False])
-def test_se_bnb_bwd(gpu, has_se, dims, jobs):
+def test_se_bnb_bwd(gpu, has_se, dims, jobs=0):
     """Composite check: u = bn_b(braw) [train stats] -> (SE gate) -> v ; L = sum(dv * v).  The kernel sees only the
     per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients.
     jobs: weight-gradient slab reductions riding on the launch (x3d_hip.h `reduce`): dw += the sum of its partial slabs, parts

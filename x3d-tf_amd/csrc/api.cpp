@@ -15,6 +15,7 @@ void x3d_set_error(const char* fmt, ...) {
 
 struct X3dDescribe { char* out; int cap; };
 thread_local X3dDescribe x3d_describe = {nullptr, 0};
+thread_local int* x3d_parts_query = nullptr;   // x3d_pw_wgrad_dw_parts: the launcher reports its partial-slab count here instead of launching
 
 extern "C" const char* x3d_last_error(void) { return g_err; }
 extern "C" int x3d_version(void) { return X3D_ABI_VERSION; }   // history: include/x3d_hip.h

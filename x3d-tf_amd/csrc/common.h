@@ -130,6 +130,9 @@ void x3d_set_error(const char* fmt, ...);
 // but write the chosen instantiation's name here instead of launching it
 struct X3dDescribe { char* out; int cap; };
 extern thread_local X3dDescribe x3d_describe;
+// x3d_pw_wgrad_dw_parts(): with this set a weight-gradient launcher that has the partial-slab form stores the number of
+// slabs its launch would write (its point-chunk grid) and returns instead of launching; launchers without the form leave it
+extern thread_local int* x3d_parts_query;
 
 // dry-run dispatch (x3d_dw3d_kernel_name / x3d_pw_kernel_name): a launcher that reaches this line with the describe buffer
 // set writes the name of the instantiation it chose and returns instead of launching (no HIP call has been made)

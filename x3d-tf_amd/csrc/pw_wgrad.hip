@@ -16,6 +16,7 @@ struct PwWgradArgs {
   int steps_per_block;  // 32-point steps per block
   int noflush;          // X3D_PW_WG_NOFLUSH=1 (timing experiment only: the partial tiles are NOT added to dw)
   int ragged;           // 16-bit storage, P % 8 != 0, stride 1: the vector kernel with ragged row ends (pw_gemm.h)
+  float* slab;          // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
 };
 
 #include "pw_wgrad_bf16.h"
@@ -221,6 +222,8 @@ static int pw_wgrad_dispatch(PwWgradArgs& a, int vec, bool xpro, hipStream_t st)
   return xpro ? pw_wgrad_tpw<T, 1, true, false>(a, st) : pw_wgrad_tpw<T, 1, false, false>(a, st);
 }
 
+extern "C" int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* w);
+
 extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(w && w->g && w->x && w->dw, "pw_wgrad: null pointer");
   X3D_REQUIRE((w->coef == nullptr) == (w->yraw == nullptr), "pw_wgrad: coef and yraw go together");
@@ -233,7 +236,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   memset(&a, 0, sizeof(a));
   a.g = w->g; a.yraw = w->yraw; a.coef = w->coef;
   a.x = w->x; a.xcoef = w->in_scale_shift; a.xgate = w->in_gate; a.xact = w->in_act;
-  a.dw = w->dw; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
+  a.dw = w->dw; a.slab = w->dw_slab; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
   a.stride = w->stride; a.H = w->H; a.W = w->W;
   a.Ho = ceil_div(w->H, w->stride); a.Wo = ceil_div(w->W, w->stride);
   a.Pin = (long long)w->T * w->H * w->W;
@@ -246,7 +249,14 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   a.ragged = (pw_ragged_rows(a.P, eb) &&
               (((uintptr_t)w->g | (uintptr_t)w->yraw | (uintptr_t)w->x) % 16) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
+  // dw_slab: only where the kernel behind the call has the form (x3d_pw_wgrad_dw_parts() > 0); a launcher without it would
+  // flush into dw and leave the slabs unwritten -- refused up front
+  if (w->dw_slab && !x3d_parts_query && !x3d_describe.out) {
+    X3D_REQUIRE(((uintptr_t)w->dw_slab % 16) == 0 && x3d_pw_wgrad_dw_parts(w) > 0,
+                "pw_wgrad: dw_slab given but the kernel behind this call has no slab form (x3d_pw_wgrad_dw_parts() == 0)");
+  }
   if (w->dtype == X3D_F32) {
+    if (x3d_parts_query) return X3D_OK;     // (no slab form in the fp32 kernels)
     if (a.stride == 1 && a.P >= 4 && x3d_env_int("X3D_PW_F32R", 1) != 0) {      // tile groups of <= 8, long double-buffered runs (pw_wgrad_f32r.h)
       PwWgradRArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -260,8 +270,22 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   // bf16 storage: bf16 matrix cores; v2 = aligned fast path, v1 = generic (odd point counts / widths)
   if (w->dtype == X3D_F16) {
     const int rc = pw_wgrad_v2_dispatch<f16>(a, vec, xpro, st);
+    if (rc < 0 && x3d_parts_query) return X3D_OK;       // (query mode: the generic kernel has no slab form)
     return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<f16>(a, vec, xpro, st);
   }
   const int rc = pw_wgrad_v2_dispatch<bf16>(a, vec, xpro, st);
+  if (rc < 0 && x3d_parts_query) return X3D_OK;
   return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<bf16>(a, vec, xpro, st);
+}
+
+// number of partial slabs x3d_pw_wgrad writes when given dw_slab (0: no slab form behind this call): the whole dispatch runs
+// in query mode -- the launcher reports its grid instead of launching
+extern "C" int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* w) {
+  if (!w || !w->g || !w->x || x3d_describe.out) return 0;
+  int parts = 0;
+  int* saved = x3d_parts_query;
+  x3d_parts_query = &parts;
+  const int rc = x3d_pw_wgrad(w, nullptr);
+  x3d_parts_query = saved;
+  return rc == X3D_OK ? parts : 0;
 }

@@ -435,13 +435,19 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
     int id = wid + NW * s;
     bool writer = true;
     if (nks > 1) { id = wid % ntiles; writer = wid < ntiles; }
-    if (id < ntiles && s_begin < s_end && writer && !a.noflush) {
+    if (id < ntiles && (s_begin < s_end || a.slab) && writer && !a.noflush) {
       const int mt = id / nt_here, nt = id - mt * nt_here;
       const int ci = ci0 + nt * 32 + r;
+      // partial slab of this point chunk (plain stores; EVERY chunk writes its tiles, a chunk without steps zeros: the sum
+      // over the slabs is taken by a later launch, x3d_hip.h dw_slab), or fp32 atomics into dw
+      float* slab = a.slab ? a.slab + (long long)blockIdx.x * a.Cout * a.Cin : nullptr;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int co = co0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+        if (co < a.Cout && ci < a.Cin) {
+          if (slab) slab[(long long)co * a.Cin + ci] = acc[s][j];
+          else atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+        }
       }
     }
   }
@@ -458,8 +464,15 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   X3D_REQUIRE(total_steps < (1ll << 31), "pw_wgrad: too many steps");
   const size_t lds = (size_t)(MG + NG) * 32 * ((NTHR == 512 ? 1 : 2) * 64 + 8) * 2;
   X3D_DESCRIBE("pw_wgrad_bf16_v2_kernel<%s, %d, %d, %d, %d, %d, %d>", HV<H>::name, MG, NG, (int)XPRO, STRIDED, NTHR, (int)RAG);
+  // Partial-slab form (x3d_hip.h dw_slab) for the 12-tile groups -- the stage-5 layers 192 <-> 432, whose fp32 atomic flush is
+  // 14-18 us of a 52-66 us launch (profiles/r05_noflush.txt).  Its grid must be known to the caller BEFORE the launch (and
+  // without a device: dry plans), so it is sized from the two workgroups per CU the launch bounds promise, not from the
+  // occupancy query.
+  constexpr bool SLAB_FORM = STRIDED == 0 && NTHR == 256 && MG * NG == 12 && !RAG;
+  if (x3d_parts_query && !SLAB_FORM) return X3D_OK;     // (query mode: no slab form here, the count stays 0)
+  if (a.slab && !SLAB_FORM) { x3d_set_error("pw_wgrad: dw_slab given to a kernel without the slab form"); return X3D_ERR_INVALID; }
   auto kern = pw_wgrad_bf16_v2_kernel<H, MG, NG, XPRO, STRIDED, NTHR, RAG>;
-  if (lds > 48 * 1024) {
+  if (lds > 48 * 1024 && !x3d_parts_query) {
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -469,14 +482,15 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   // one balanced round: as many workgroups as the chip holds at once (occupancy x CUs), the 64-point steps split
   // evenly among them.  A fixed steps-per-block left e.g. 1568 workgroups on 1280 slots: a second round at 22 %.
   static int slots = 0;
-  if (slots == 0) {
+  if (slots == 0 && !(SLAB_FORM && (a.slab || x3d_parts_query))) {
     int nb = 0, dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NTHR, lds) != hipSuccess || nb < 1) nb = NTHR == 256 ? 2 : 1;
     slots = nb * cus;
   }
-  long long gx_target = slots / (gy * gz);
+  const int slots_here = (SLAB_FORM && (a.slab || x3d_parts_query)) ? 2 * x3d_device_cus() : slots;
+  long long gx_target = slots_here / (gy * gz);
   if (gx_target < 1) gx_target = 1;
   long long spb = ceil_div_ll(total_steps, gx_target);
   if (spb < 8) spb = 8;      // keeps the atomic partial (<= 32 KB) below ~10 % of the streamed bytes
@@ -492,6 +506,7 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   a.noflush = x3d_env_int("X3D_PW_WG_NOFLUSH", 0) == 1 ? 1 : 0;   // result-changing timing experiment (the atomic flush's share): -DX3D_EXPERIMENTS builds only
   long long gx = ceil_div_ll(total_steps, spb);
   if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
+  if (x3d_parts_query) { *x3d_parts_query = (int)gx; return X3D_OK; }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(NTHR), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
   return X3D_OK;

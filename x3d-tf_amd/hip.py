@@ -75,7 +75,7 @@ class PwPackItem(C.Structure):
 class PwWgradArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("x", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("dw", _vp), ("N", _i), ("Cin", _i), ("Cout", _i),
-                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i)]
+                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("dw_slab", _vp)]
 
 
 class BnFold(C.Structure):
@@ -120,6 +120,7 @@ _SIGS = {
     "x3d_pw_fwd_tail_supported": ([C.POINTER(PwFwdArgs)], _i),
     "x3d_pw_dgrad": ([C.POINTER(PwDgradArgs), _vp], _i),
     "x3d_pw_wgrad": ([C.POINTER(PwWgradArgs), _vp], _i),
+    "x3d_pw_wgrad_dw_parts": ([C.POINTER(PwWgradArgs)], _i),
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
     "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
     "x3d_pw_bwd_dw_parts": ([C.POINTER(PwBwdArgs)], _i),

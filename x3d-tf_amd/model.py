@@ -1056,8 +1056,10 @@ class X3D:
         pending_reduce = {"a": None}
 
         def dw_slab_job(st, role, dw):
-            """st: the x3d_pw_bwd arguments about to be recorded; returns its reduce job (and points st at the slab) or None."""
-            parts = int(pl.lib.x3d_pw_bwd_dw_parts(C.byref(st))) if slab_on else 0
+            """st: the x3d_pw_bwd / x3d_pw_wgrad arguments about to be recorded; returns its reduce job (and points st at the
+            slab) or None."""
+            query = pl.lib.x3d_pw_wgrad_dw_parts if isinstance(st, hip.PwWgradArgs) else pl.lib.x3d_pw_bwd_dw_parts
+            parts = int(query(C.byref(st))) if slab_on else 0
             if parts <= 0:
                 return None
             elems = st.Cout * st.Cin
@@ -1128,6 +1130,8 @@ class X3D:
                 # Weight gradients feed nothing but the optimizer: they run on the side stream next to the data-gradient
                 # chain.  What they read (g, the raw conv outputs, the shared `ga` scratch) is next overwritten by the
                 # following depthwise backward / the block after it, and every depthwise backward is preceded by a join.
+                if not pl.side_on:
+                    c_job = dw_slab_job(wc, "c", g[f"{q}/c/kernel"])
                 pl.rec_side(Bk, "x3d_pw_wgrad", wc)
                 pl.rec(Bk, "x3d_pw_dgrad", ("field", dc, {"nc_sums": B.nc_sums}))
             # SE + BN_b backward from the per-(n,c) sums
@@ -1249,7 +1253,9 @@ class X3D:
                 rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
             if B.a_bwd_rc and not merge_rc:
                 pl.rec(Bk, "x3d_pw_bwd_rc_prepare", p[f"{q}/a/kernel"], B.bn_a.coef, rc[0], rc[1], b.inner, b.cin, dt)
-            if chosen is not None and rc is None:
+            # (the `a` conv's slab is added up by the NEXT block's x3d_se_bnb_bwd: not for the first block of a stage, whose
+            # gradient must be final at the stage mark -- a reduce launch of its own would cost what the slab saves)
+            if chosen is not None and rc is None and b.index != 0:
                 pending_reduce["a"] = dw_slab_job(chosen, "a", g[f"{q}/a/kernel"])
             if ft is not None:
                 prev.tail_folded = True
@@ -1260,6 +1266,8 @@ class X3D:
             elif chosen is not None:
                 pl.rec(Bk, "x3d_pw_bwd", ("field", fa, fields))
             else:
+                if not pl.side_on and b.index != 0:
+                    pending_reduce["a"] = dw_slab_job(wa, "a", g[f"{q}/a/kernel"])
                 pl.rec_side(Bk, "x3d_pw_wgrad", wa)
                 pl.rec(Bk, "x3d_pw_dgrad", da)
             if B.a_bwd_rc:

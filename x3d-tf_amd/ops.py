@@ -286,14 +286,26 @@ def bn_bwd_finalize_rc(sums, count, mi, gamma, coef, dgamma, dbeta, dtype, prep=
              0 if fw is None else fw.shape[0], 0 if fw is None else fw.shape[1], hip.dtype_code(dtype))
 
 
-def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1):
-    """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points."""
+def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, slab=False):
+    """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points.  slab: through partial slabs +
+    x3d_dw_slab_reduce (returns None, nothing launched, when the kernel behind the call has no slab form)."""
     _chk(g, yraw, coef, x, dw, in_ss, in_gate)
     n, cin, t, h, ww = x.shape
     cout = g.shape[1]
     a = hip.PwWgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(x), ptr(in_ss), ptr(in_gate), in_act, ptr(dw),
                         n, cin, cout, t, h, ww, stride, hip.dtype_code(x.dtype))
+    if slab:
+        import ctypes as C
+        parts = int(hip.load().x3d_pw_wgrad_dw_parts(C.byref(a)))
+        if parts <= 0:
+            return None
+        buf = torch.full((parts * cout * cin,), float("nan"), dtype=torch.float32, device=g.device)   # (every slab element must be written)
+        a.dw_slab = ptr(buf)
+        hip.call_struct("x3d_pw_wgrad", a)
+        dw_slab_reduce([(buf, dw, parts)])
+        return True
     hip.call_struct("x3d_pw_wgrad", a)
+    return True
 
 
 # ---- depthwise ----------------------------------------------------------------------------------
