@@ -44,6 +44,7 @@ def case_calls(rng: random.Random):
 
 def run_cases(gpu, cases: int, seed: int, log=None):
     """Runs `cases` fuzz cases; returns the list of failures as (name, args, message)."""
+    import inspect
     import traceback
     from tests import test_kernels_gpu as K
     rng = random.Random(seed)
@@ -51,7 +52,9 @@ def run_cases(gpu, cases: int, seed: int, log=None):
     for i in range(cases):
         for name, args in case_calls(rng):
             try:
-                getattr(K, name)(gpu, *args)
+                fn = getattr(K, name)
+                extra = {k: v for k, v in (("slab", False), ("jobs", 0)) if k in inspect.signature(fn).parameters}   # (parametrised switches)
+                fn(gpu, *args, **extra)
             except Exception as e:   # noqa: BLE001  (a failing case must not stop the sweep)
                 fails.append((name, args, f"{type(e).__name__}: {str(e)[:300]}"))
                 if log:

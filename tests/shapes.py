@@ -120,6 +120,9 @@ PW_BWD = [
     (1, 200, 40, 2, 8, 8, "add"), (1, 136, 72, 1, 8, 16, "add_strided"),   # sliced `a`-type layers, widths off the grid
     (2, 96, 216, 2, 14, 14, "add"), (24, 96, 216, 8, 14, 14, "add"), (3, 90, 210, 1, 10, 12, "add"),   # stage-4 `a` conv: pw_bwd_wsta.hip
     (1, 32, 72, 1, 16, 16, "add"), (1, 32, 72, 1, 16, 16, "add_strided"), (1, 72, 32, 1, 16, 16, "swish_bwd"),   # X3D-XL stage 2
+    # stage-5 `c` conv (432 <-> 192 on 7 x 7 planes): pw_bwd_wst.hip with two slices of seven row blocks over blockIdx.y
+    (2, 432, 192, 8, 7, 7, "swish_bwd"), (10, 432, 192, 16, 7, 7, "swish_bwd"), (3, 420, 180, 1, 10, 12, "swish_bwd"),
+    (2, 300, 192, 2, 8, 8, "swish_bwd"),       # ... a short second slice (ten row blocks: 7 + 3)
 ]
 
 # ... without the conv's raw output (pw_bwd_rc.hip: y = W x folded into the BatchNorm backward): N, Cin, Cout, T, H, W, epilogue, tail

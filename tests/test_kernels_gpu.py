@@ -225,7 +225,7 @@ def _wtol(dtype):
 @pytest.mark.parametrize("slab", [False, True])
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD)
-def test_pw_bwd_oracle(gpu, dtype, shape, slab=False):
+def test_pw_bwd_oracle(gpu, dtype, shape, slab):
     """x3d_pw_bwd (fused data + weight gradient, one pass over dY) against an fp64 restatement of both gradients --
     directly, not through the unfused kernels (test_pw_bwd_fused below keeps the bit-for-bit comparison with those).
     slab: the weight gradient through per-workgroup partial slabs + x3d_dw_slab_reduce (x3d_hip.h dw_slab) -- the form the
@@ -739,7 +739,7 @@ def test_pw_dgrad(gpu, dtype, shape, epi, panel):
 @pytest.mark.parametrize("slab", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", S.PW_WGRAD)   # N, Cin, Cout, T, H, W, stride, prologue
-def test_pw_wgrad(gpu, dtype, shape, slab=False):
+def test_pw_wgrad(gpu, dtype, shape, slab):
     """slab: through per-point-chunk partial slabs + x3d_dw_slab_reduce (x3d_hip.h dw_slab), where the kernel behind the call
     has the form (the 12-tile groups: the stage-5 layers)."""
     ops = _ops()
@@ -1055,7 +1055,7 @@ def test_se(gpu):
 @pytest.mark.parametrize("jobs", [0, 1, 2])
 @pytest.mark.parametrize("dims", [(3, 12, 8), (70, 40, 16)])
 @pytest.mark.parametrize("has_se", [True, False])
-def test_se_bnb_bwd(gpu, has_se, dims, jobs=0):
+def test_se_bnb_bwd(gpu, has_se, dims, jobs):
     """Composite check: u = bn_b(braw) [train stats] -> (SE gate) -> v ; L = sum(dv * v).  The kernel sees only the
     per-(n,c) sums; its coefficients must reproduce dL/dbraw, and the SE / BN parameter gradients.
     jobs: weight-gradient slab reductions riding on the launch (x3d_hip.h `reduce`): dw += the sum of its partial slabs, parts

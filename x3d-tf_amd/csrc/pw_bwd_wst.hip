@@ -56,7 +56,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   const int tile_end = min(tile_begin + a.tiles_per_block, total_tiles);
   if (tile_begin >= tile_end) return;                  // (never: the grid has no empty workgroup -- a slab would stay unwritten)
   float* myOs = Os + wid * 32 * OP;
-  const bool mw = wid < NW && wid < mt;                // this wave owns a row block of input channels
+  // input channels beyond NW row blocks: SLICES over blockIdx.y (stage 5: 432 = 2 x 7 row blocks), each slice a persistent
+  // workgroup set of its own that re-stages the dY tile (K = Co rows) for its NW x 32 input channels
+  const int rb = blockIdx.y * NW + wid;                // this wave's row block of input channels
+  const bool mw = wid < NW && rb < mt;                 // ... if it owns one
 
   // ---- one-time set-up: zero the row-read copies' padding rows (Kp.. CoP), the BN-backward coefficient table
   {
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   // ---- the stationary operand: W^T rows (input channels) 32 * wid .., all Kp output channels
   hx8 A[KS];
   if (mw) {
-    const H* wt = (const H*)a.wp + (long long)a.wp_rows * WP + ((long long)wid * KS * 64 + lane) * 8;
+    const H* wt = (const H*)a.wp + (long long)a.wp_rows * WP + ((long long)rb * KS * 64 + lane) * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) A[ks] = *(const hx8*)(wt + ks * 512);
   } else {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
 
   // ---- braw prefetch (one tile ahead): lane -> row lane >> 1 of this wave's block, points 16 * (lane & 1) .. + 15
   const int row = lane >> 1, c0 = 16 * (lane & 1);
-  const int m = wid * 32 + row;                        // this lane's input channel
+  const int m = rb * 32 + row;                         // this lane's input channel
   const bool mrow = mw && m < a.Ci;
   // Every load of the tile loop is UNCONDITIONAL (clamped address, value selected afterwards) and the SE gate travels with
   // braw: vmcnt retires in order, so a load issued behind the prefetches -- or a conditional one the compiler cannot
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   // atomics.  256 workgroups x 83 KB of device-scope atomics take 17-24 us of this ~100 us launch whatever the schedule
   // (they execute at the memory side at ~1.3 TB/s chip-wide); the same bytes as stores ~4 us.
   if (mw && !a.noflush) {
-    const int ci = wid * 32 + r;
+    const int ci = rb * 32 + r;
     float* slab = a.slab ? a.slab + (long long)blockIdx.x * a.Co * a.Ci : nullptr;
 #pragma unroll
     for (int s = 0; s < CT; s++)
@@ -292,7 +295,10 @@ static inline size_t bw_lds_bytes() {
 bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b) {
   if (x3d_env_int("X3D_PW_BWD_WST", 1) == 0) return false;   // A/B switch: 0 = off
   if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw || b->epi != X3D_EPI_SWISH_BWD || b->tail_c) return false;
-  if (b->Cin <= 128 || b->Cin > 224 || ((b->Cout + 15) >> 4) != 6) return false;   // (six k-steps: the panel's pitch is roundup(Co, 16) + 8)
+  // stage 4: 129..224 input channels, six k-steps (the panel's pitch is roundup(Co, 16) + 8); stage 5 (round 5): 225..448 input
+  // channels as two slices of seven row blocks, twelve k-steps (432 <-> 192)
+  const int ks = (b->Cout + 15) >> 4;
+  if (!((b->Cin > 128 && b->Cin <= 224 && ks == 6) || (b->Cin > 224 && b->Cin <= 448 && ks == 12 && x3d_env_int("X3D_PW_BWD_WST5", 1) != 0))) return false;
   const long long P = (long long)b->T * b->H * b->W;
   if (P % 8 || P >= (1ll << 31) || (long long)b->Cin * P * 2 >= (1ll << 31)) return false;   // (2 GB buffer-store window per sample)
   const void* ps[] = {b->g, b->yraw, b->dx, b->w_panel, b->braw};
@@ -300,9 +306,15 @@ bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b) {
   return true;
 }
 
-template <typename H>
+// slices over blockIdx.y and the persistent grid per slice (also what x3d_pw_bwd_dw_parts reports: one slab per blockIdx.x)
+static inline void bw_grid(int N, long long P, int Ci, long long* tpb, long long* gx, int* slices) {
+  *slices = ceil_div(ceil_div(Ci, 32), 7);
+  x3d_persistent_grid(ceil_div_ll(P, 32) * N, x3d_device_cus() / *slices, tpb, gx);
+}
+
+template <typename H, int KS, int CT>
 static int bw_launch(PwBwdWstArgs& a, hipStream_t st) {
-  constexpr int NW = 7, KS = 6, CT = 3;
+  constexpr int NW = 7;
   const size_t lds = bw_lds_bytes<NW, KS, CT>();
   X3D_DESCRIBE("pw_bwd_wst_kernel<%s, %d, %d, %d>", HV<H>::name, NW, KS, CT);
   auto kern = pw_bwd_wst_kernel<H, NW, KS, CT>;
@@ -314,10 +326,11 @@ static int bw_launch(PwBwdWstArgs& a, hipStream_t st) {
   const long long total_tiles = ceil_div_ll(a.P, 32) * a.N;
   X3D_REQUIRE(total_tiles < (1ll << 31), "pw_bwd_wst: too many tiles");
   long long tpb, gx;
-  x3d_persistent_grid(total_tiles, x3d_device_cus(), &tpb, &gx);
+  int slices;
+  bw_grid(a.N, a.P, a.Ci, &tpb, &gx, &slices);
   a.tiles_per_block = (int)tpb;
   a.noflush = x3d_env_int("X3D_PW_BWD_NOFLUSH", 0);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)slices), dim3(512), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_wst");
   return X3D_OK;
 }
@@ -333,12 +346,14 @@ int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st) {
   a.dw = b->dw; a.slab = b->dw_slab;
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin;
   a.P = (long long)b->T * b->H * b->W;
-  return b->dtype == X3D_F16 ? bw_launch<f16>(a, st) : bw_launch<bf16>(a, st);
+  if (((b->Cout + 15) >> 4) == 12) return b->dtype == X3D_F16 ? bw_launch<f16, 12, 6>(a, st) : bw_launch<bf16, 12, 6>(a, st);
+  return b->dtype == X3D_F16 ? bw_launch<f16, 6, 3>(a, st) : bw_launch<bf16, 6, 3>(a, st);
 }
 
 // number of partial dW slabs a launch writes when given dw_slab (= its grid: x3d_hip.h)
 int pw_bwd_wst_dw_parts(const x3d_pw_bwd_args* b) {
   long long tpb, gx;
-  x3d_persistent_grid(ceil_div_ll((long long)b->T * b->H * b->W, 32) * b->N, x3d_device_cus(), &tpb, &gx);
+  int slices;
+  bw_grid(b->N, (long long)b->T * b->H * b->W, b->Cin, &tpb, &gx, &slices);
   return (int)gx;
 }
