@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 129
+#define X3D_ABI_VERSION 130
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -182,6 +182,25 @@ typedef struct {
 int x3d_pw_fwd(const x3d_pw_fwd_args* a, void* stream);
 int x3d_pw_fwd_tail_supported(const x3d_pw_fwd_args* a);   /* 1: the in_add / in_store form covers this call */
 
+/* BatchNorm-backward finalize folded into its consumers (coef_fold of the three backward argument structs below; NULL: off).
+ * The coefficient table `coef` [C][4] of dYraw = A*g + B*yraw + C is x3d_bn_bwd_finalize's output: a ~6 us launch between
+ * the kernel that produced the sums and the kernel that needs the table.  With coef_fold set the consuming kernel derives the
+ * coefficients it needs from the sums itself, in its coefficient-table prologue (the same arithmetic, one definition:
+ * the same bits), and `coef` is not read.  dgamma / dbeta non-NULL: workgroup (0, 0, 0) of the launch also adds the channel's
+ * gamma / beta gradient (+=) and writes the table to coef_out -- exactly ONE launch per BatchNorm and step must be given them
+ * (a data- and a weight-gradient launch that share a BatchNorm: one of the two).  x3d_pw_coef_fold_supported(): whether the
+ * kernel behind a call takes it (the persistent weights-stationary kernels and the 16-bit weight-gradient kernel; the
+ * entry points refuse the field otherwise). */
+typedef struct {
+  const double* sums;          /* [C][2] as x3d_bn_bwd_finalize takes them */
+  double count;
+  const float* mean_invstd;    /* [C][2] */
+  const float* gamma;          /* [C] */
+  float* dgamma;               /* [C] += , or NULL */
+  float* dbeta;                /* [C] += , or NULL */
+  float* coef_out;             /* [C][4], or NULL (written with dgamma / dbeta) */
+} x3d_bn_bwd_fold;
+
 /* data gradient: dYraw = A*g + B*yraw + C on load (coef [Cout][4]; NULL coef: dYraw = g),
  * dx = W^T dYraw with one of the X3D_EPI_* epilogues. All tensors at the conv's OUTPUT points. */
 typedef struct {
@@ -198,6 +217,7 @@ typedef struct {
   double* nc_sums;             /* EPI_SWISH_BWD: [N][Cin][2] += (sum dv, sum dv*braw) */
   int N, Cin, Cout, T, H, W, dtype; /* T,H,W: extents of the P = T*H*W output points */
   const void* w_panel;         /* optional (bf16 path): dgrad panel from x3d_pw_pack_weights, else NULL */
+  const x3d_bn_bwd_fold* coef_fold; /* NULL | derive `coef` from the BatchNorm-backward sums (above) */
 } x3d_pw_dgrad_args;
 int x3d_pw_dgrad(const x3d_pw_dgrad_args* a, void* stream);
 
@@ -254,6 +274,7 @@ typedef struct {
    * x3d_dw_slab_reduce, or the two reduce slots of x3d_se_bnb_bwd (a small launch that is on the critical path anyway).
    * x3d_pw_bwd_dw_parts() == 0: the kernel behind this call has no slab form (leave dw_slab NULL). */
   float* dw_slab;              /* x3d_pw_bwd_dw_parts(a) * Cout * Cin floats, 16-byte aligned */
+  const x3d_bn_bwd_fold* coef_fold; /* NULL | derive `coef` from the BatchNorm-backward sums (x3d_bn_bwd_fold) */
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
 int x3d_pw_bwd(const x3d_pw_bwd_args* a, void* stream);
@@ -313,6 +334,7 @@ typedef struct {
   int N, Cin, Cout, T, H, W, stride, dtype; /* T,H,W: INPUT extents (as in fwd) */
   float* dw_slab;              /* NULL | partial slabs instead of atomics, as x3d_pw_bwd_args.dw_slab: x3d_pw_wgrad_dw_parts(a) * Cout * Cin
                                 * floats, every one of them written (dw untouched); added up by x3d_dw_slab_reduce / x3d_se_bnb_bwd */
+  const x3d_bn_bwd_fold* coef_fold; /* NULL | derive `coef` from the BatchNorm-backward sums (x3d_bn_bwd_fold) */
 } x3d_pw_wgrad_args;
 int x3d_pw_wgrad(const x3d_pw_wgrad_args* a, void* stream);
 int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* a);   /* 0: the kernel behind this call has no slab form */
@@ -323,6 +345,8 @@ int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* a);   /* 0: the kernel behind
  * test (every instantiation the BASELINE configurations launch has an oracle-parity case) and by the profiling tools. */
 int x3d_pw_kernel_name(const x3d_pw_fwd_args* fwd, const x3d_pw_dgrad_args* dgrad, const x3d_pw_wgrad_args* wgrad,
                        const x3d_pw_bwd_args* bwd, char* out, int cap);
+/* 1: the kernel this call dispatches to takes coef_fold (x3d_bn_bwd_fold).  Exactly one struct is non-NULL. */
+int x3d_pw_coef_fold_supported(const x3d_pw_dgrad_args* dgrad, const x3d_pw_wgrad_args* wgrad, const x3d_pw_bwd_args* bwd);
 
 /* ------------------------------------------------------------------------------------------
  * K6  channelwise Conv3D(k=(3,3,3), s=(1,s,s), padding='same', groups=C, no bias)

@@ -521,6 +521,90 @@ def test_pw_bwd_tail(gpu, dtype, shape):
     report("sums vs x3d_tail_bwd", sc - 0.25, s2c.cpu(), 1e-6, 1e-6 * max(1.0, ref_c.abs().max().item()))   # both sum the STORED gradient
 
 
+# the BatchNorm-backward finalize derived by its consumers (include/x3d_hip.h x3d_bn_bwd_fold): (N, Cin, Cout, T, H, W, kind)
+COEF_FOLD = [
+    (2, 216, 96, 2, 14, 14, "c"), (2, 432, 192, 8, 7, 7, "c"),           # pw_bwd_wst.hip: stage 4, stage 5 (two slices)
+    (2, 96, 216, 2, 14, 14, "a"), (2, 96, 216, 2, 14, 14, "a_tail"),      # pw_bwd_wsta.hip
+    (2, 192, 432, 8, 7, 7, "pair"), (2, 432, 192, 8, 7, 7, "pair_c"),     # x3d_pw_wgrad (12-tile groups) + x3d_pw_dgrad (stationary)
+]
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", COEF_FOLD)
+def test_pw_coef_fold(gpu, dtype, shape):
+    """coef_fold: a consumer that derives its coefficient table from the BatchNorm-backward sums gives the SAME bits as the
+    x3d_bn_bwd_finalize launch followed by the consumer reading the table -- dx, dW (through slabs: a fixed summation order),
+    the per-(n, c) sums -- and its publishing launch leaves dgamma, dbeta and the table exactly as the finalize launch does."""
+    ops = _ops()
+    n, cin, cout, t, h, w, kind = shape
+    g_ = _gen(71)
+    gy, _ = rnd((n, cout, t, h, w), dtype, g_)
+    yraw, _ = rnd((n, cout, t, h, w), dtype, g_)
+    wt = torch.randn((cout, cin), generator=g_) * 0.2
+    m_ = n * t * h * w
+    sums = torch.stack([torch.randn(cout, generator=g_, dtype=torch.float64) * m_ ** 0.5,
+                        torch.randn(cout, generator=g_, dtype=torch.float64) * m_ ** 0.5], 1).contiguous().to(gpu)
+    mi = torch.stack([0.3 * torch.randn(cout, generator=g_), 0.5 + torch.rand(cout, generator=g_)], 1).contiguous().to(gpu)
+    gamma = (1 + 0.3 * torch.randn(cout, generator=g_)).to(gpu)
+    coef = torch.empty((cout, 4), device=gpu)
+    dga_ref = torch.full((cout,), 0.25, device=gpu)
+    dbe_ref = torch.full((cout,), 0.25, device=gpu)
+    ops.bn_bwd_finalize(sums, float(m_), mi, gamma, coef, dga_ref, dbe_ref)
+    dp = _panels(ops, wt, dtype, gpu)[1]
+    dev = lambda v: None if v is None else v.to(gpu)
+    gyd, yrd, wtd = dev(gy), dev(yraw), dev(wt)
+    if kind in ("c", "pair_c"):
+        braw, _ = rnd((n, cin, t, h, w), dtype, g_)
+        bss = torch.stack([1 + 0.3 * torch.randn(cin, generator=g_), 0.3 * torch.randn(cin, generator=g_)], 1)
+        gate = torch.rand((n, cin), generator=g_)
+        kw = dict(braw=dev(braw), b_ss=dev(bss), gate=dev(gate))
+        x = None
+    else:
+        x, _ = rnd((n, cin, t, h, w), dtype, g_)
+        x = dev(torch.relu(x))
+        add, _ = rnd((n, cin, t, h, w), dtype, g_)
+        kw = dict(add=dev(add))
+    tc = dev(rnd((n, cin, t, h, w), dtype, g_)[0]) if kind == "a_tail" else None
+
+    def run(fold):
+        dx = torch.empty((n, cin, t, h, w), dtype=dtype, device=gpu)
+        dw = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)
+        out = dict(dx=dx, dw=dw)
+        dga = torch.full((cout,), 0.25, device=gpu)
+        dbe = torch.full((cout,), 0.25, device=gpu)
+        cout_ = torch.zeros((cout, 4), device=gpu)
+        pub = ops.bn_bwd_fold(sums, m_, mi, gamma, dga, dbe, cout_) if fold else None
+        quiet = ops.bn_bwd_fold(sums, m_, mi, gamma) if fold else None
+        cf = None if fold else coef
+        if kind in ("c",):
+            out["ncs"] = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+            assert ops.pw_bwd(gyd, yrd, cf, dp, dx, dw, ops.EPI_SWISH_BWD, nc_sums=out["ncs"], slab=True, coef_fold=pub, **kw)
+        elif kind in ("a", "a_tail"):
+            if tc is not None:
+                out["ts"] = torch.zeros((cin, 2), dtype=torch.float64, device=gpu)
+            assert ops.pw_bwd(gyd, yrd, cf, dp, dx, dw, ops.EPI_ADD, x=x, tail_c=tc, tail_sums_c=out.get("ts"), slab=True, coef_fold=pub, **kw)
+        elif kind == "pair":
+            assert ops.pw_wgrad(gyd, yrd, cf, x, dw, slab=True, coef_fold=quiet)
+            ops.pw_dgrad(gyd, yrd, cf, wtd, dx, ops.EPI_ADD, w_panel=dp, coef_fold=pub, **kw)
+        else:
+            out["ncs"] = torch.zeros((n, cin, 2), dtype=torch.float64, device=gpu)
+            assert ops.pw_wgrad(gyd, yrd, cf, kw["braw"], dw, in_ss=kw["b_ss"], in_gate=kw["gate"], in_act=2, slab=True, coef_fold=quiet)
+            ops.pw_dgrad(gyd, yrd, cf, wtd, dx, ops.EPI_SWISH_BWD, nc_sums=out["ncs"], w_panel=dp, coef_fold=pub, **kw)
+        torch.cuda.synchronize()
+        out.update(dga=dga, dbe=dbe, coef=cout_)
+        return out
+
+    ref, got = run(False), run(True)
+    assert torch.equal(got["dx"], ref["dx"]) and torch.equal(got["dw"], ref["dw"])
+    # (the per-(n, c) sums and the tail sums are fp64 atomics over workgroups: summation order only)
+    for k in ("ncs", "ts"):
+        if k in ref:
+            report(k, got[k], ref[k], 1e-12, 1e-9 * max(1.0, ref[k].abs().max().item()))
+    assert torch.equal(got["coef"], coef), "the published table differs from x3d_bn_bwd_finalize's"
+    assert torch.equal(got["dga"], dga_ref) and torch.equal(got["dbe"], dbe_ref)
+    assert float((ref["dga"] - 0.25).abs().max()) == 0.0           # (without the fold the consumers leave dgamma alone)
+
+
 @pytest.mark.parametrize("bf", HALF)
 @pytest.mark.parametrize("shape", S.PW_BWD)   # N, Cin, Cout, T, H, W, epi   (a conv: Cin = block input, Cout = inner; c conv: Cin = inner, Cout = out)
 def test_pw_bwd_fused(gpu, shape, bf):

@@ -422,6 +422,56 @@ def test_recomputed_output_backward_against_the_stored_output_backward(gpu, name
     one_round("step 2 (perturbed weights)")
 
 
+@pytest.mark.parametrize("dtype", S.HALF_DTYPES)
+@pytest.mark.parametrize("off", ["coef_fold", "dw_slab"])
+def test_launch_saving_plan_options_do_not_change_the_gradients(gpu, off, dtype):
+    """Round 5's two launch-list options -- coef_fold (the BatchNorm-backward finalize derived by its consumers: 37 launches of an
+    X3D-M step) and dw_slab (partial weight-gradient slabs added up by x3d_se_bnb_bwd instead of fp32 atomics) -- change WHERE
+    numbers are computed, not the numbers: on the same forward state the list recorded with the option off gives the same
+    gradients up to the summation order of the remaining fp32 atomics (the headline's planes, X3D-M 1 x 4 x 224^2)."""
+    from tests.util import record_alternate_backward
+    from x3d_tf_amd import hip
+    cfg, arch, params = _setup("M")
+    torch.manual_seed(3)
+    n, t, s = 1, 4, 224
+    x = torch.randn(n, t, s, s, 3).to(dtype).to(gpu)
+    labels = torch.randint(0, arch.num_classes, (n,)).to(gpu)
+    m = _model(cfg, params, dtype, gpu)
+    m.set_dropout_mask((torch.rand(n, arch.fc1_out) >= arch.dropout_rate).float())
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    pl = m.forward_backward(x, labels, loss_scale=ls)
+    torch.cuda.synchronize()
+    names = [i[0] for i in pl.bwd]
+    alt = record_alternate_backward(m, pl, x, **{off: False})
+    alt_names = [i[0] for i in alt.lst]
+    if off == "coef_fold":
+        assert names.count("x3d_bn_bwd_finalize") == 0 and alt_names.count("x3d_bn_bwd_finalize") == 37
+    else:
+        slabbed = lambda lst: sum(1 for i, it in enumerate(lst) if it[0] in ("x3d_pw_bwd", "x3d_pw_wgrad") and pl.structs[(id(lst), i)].dw_slab)
+        assert slabbed(pl.bwd) >= 20 and slabbed(alt.lst) == 0      # (stage 4: 21 launches; stage 5 has P % 8 != 0 at T = 4)
+    m._pack_panels()
+    pl.zero_buf.zero_()
+    pl.run(pl.fwd, 0, pl.grad_scale_slot)
+    hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(), pl.loss_rows.data_ptr(),
+             pl.dlogits.data_ptr(), ls / n, n, arch.num_classes)
+    snap = pl.zero_buf.clone()
+    out = []
+    for runner in (lambda: pl.run(pl.bwd), alt.run):
+        pl.zero_buf.copy_(snap)
+        m.flat_grads.zero_()
+        runner()
+        torch.cuda.synchronize()
+        assert torch.isfinite(m.flat_grads).all()
+        out.append({k: g.detach().double().cpu().clone() for k, g in m.grads.items()})
+    g1, g0 = out
+    scale = {k: max(v.norm().item(), 1e-30) for k, v in g0.items()}
+    med = sorted(scale[k] / g0[k].numel() ** 0.5 for k in g0)[len(g0) // 2]
+    errs = {k: (g1[k] - g0[k]).norm().item() / max(scale[k], 0.05 * med * g0[k].numel() ** 0.5) for k in g0}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("plan option", off, dtype, "worst:", worst)
+    assert worst[0][1] < 2e-5, worst
+
+
 def test_train_step_bf16_end_to_end_sanity(gpu):
     """Free-running bf16 vs the fp32 oracle: only what chaos leaves meaningful -- probabilities within 3e-3
     abs (they are ~2.5e-3 each), cross-entropy within 2 %, all gradients finite and of the right magnitude

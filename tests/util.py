@@ -133,6 +133,8 @@ def record_alternate_backward(model, pl, x, **options):
             pl._zero_views.append(extra[off:off + numel].view(shape))
             off += numel
         X3D._resolve(pl, alt)
+        for f, handle in getattr(pl, "bwd_folds", []):          # (folds recorded by either list: the same accumulators)
+            f.sums = pl._zero_views[handle].data_ptr()
         info = dict(tail_folded=[bool(B.tail_folded) for B in pl.blocks], a_bwd_rc=[bool(getattr(B, "a_bwd_rc", False)) for B in pl.blocks],
                     stem_bwd_folded=bool(getattr(pl, "stem_bwd_folded", False)))
         # the scratch buffers of the new list are referenced from argument structs by ADDRESS only (the plan keeps them alive as

@@ -320,6 +320,51 @@ static inline bool xcd_pad_enabled() {
   return x3d_env_int("X3D_XCD_PAD", 1) != 0;
 }
 
+// BatchNorm backward finalize, one channel (x3d_bn_bwd_finalize; include/x3d_hip.h x3d_bn_bwd_fold): ONE definition, used by
+// the finalize kernels and by the consumers that derive their coefficient table from the sums themselves, so the table is the
+// same bits whichever path computed it.
+//   dY = k1*(g - dbeta/M - xhat*dgamma/M), k1 = gamma*invstd, xhat = (y - mean)*invstd
+//      = A*g + B*y + C with A = k1, B = -k1*invstd*dgamma/M, C = -k1*dbeta/M - B*mean
+__device__ __forceinline__ void bn_bwd_coefs(const double* __restrict__ sums, double count, const float* __restrict__ mi,
+                                             const float* __restrict__ gamma, int c, float& A, float& B, float& C, double& dga,
+                                             double& dbe) {
+  const double mean = mi[c * 2], invstd = mi[c * 2 + 1];
+  dbe = sums[c * 2];
+  dga = (sums[c * 2 + 1] - mean * dbe) * invstd;
+  const double k1 = (double)gamma[c] * invstd;
+  const double Bd = -k1 * invstd * dga / count;
+  A = (float)k1;
+  B = (float)Bd;
+  C = (float)(-k1 * dbe / count - Bd * mean);
+}
+// by-value copy of x3d_bn_bwd_fold for kernel arguments (sums == NULL: off, the table `coef` is read)
+struct BnBwdFold { const double* sums; double count; const float* mi; const float* gamma; float* dgamma; float* dbeta; float* coef_out; };
+static inline BnBwdFold bn_bwd_fold_arg(const x3d_bn_bwd_fold* f) {
+  BnBwdFold o;
+  memset(&o, 0, sizeof(o));
+  if (f) { o.sums = f->sums; o.count = f->count; o.mi = f->mean_invstd; o.gamma = f->gamma; o.dgamma = f->dgamma; o.dbeta = f->dbeta; o.coef_out = f->coef_out; }
+  return o;
+}
+static inline bool bn_bwd_fold_ok(const x3d_bn_bwd_fold* f) {
+  return !f || (f->sums && f->mean_invstd && f->gamma && f->count > 0 && ((f->dgamma != nullptr) == (f->dbeta != nullptr)));
+}
+// coefficients of channel k: from the table, or from the sums; `publish`: this thread is the ONE thread of the launch that
+// handles channel k in workgroup (0, 0, 0) -- it adds the gamma / beta gradients and writes the table (when asked to)
+__device__ __forceinline__ void bn_bwd_coef_load(const float* __restrict__ coef, const BnBwdFold& f, int k, bool publish, float& A,
+                                                 float& B, float& C) {
+  if (f.sums) {
+    double dga, dbe;
+    bn_bwd_coefs(f.sums, f.count, f.mi, f.gamma, k, A, B, C, dga, dbe);
+    if (publish && f.dgamma) {
+      f.dgamma[k] += (float)dga;
+      f.dbeta[k] += (float)dbe;
+      if (f.coef_out) { f.coef_out[k * 4] = A; f.coef_out[k * 4 + 1] = B; f.coef_out[k * 4 + 2] = C; f.coef_out[k * 4 + 3] = 0.f; }
+    }
+  } else {
+    A = coef[k * 4]; B = coef[k * 4 + 1]; C = coef[k * 4 + 2];
+  }
+}
+
 // CUs of the current device (256 on MI355X; also the answer without a device: dry-run dispatch / x3d_pw_bwd_dw_parts on a
 // build host).  The persistent one-workgroup-per-CU kernels size their grids from it.
 static inline int x3d_device_cus() {

@@ -25,21 +25,17 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const x3d_bn_fold f, in
   bn_coefs(f, cc, s1, s2, ga, be, r == 0 && c < C, sc, sh);
 }
 
-// dY = k1*(g - dbeta/M - xhat*dgamma/M), k1 = gamma*invstd, xhat = (y-mean)*invstd
-//    = A*g + B*y + C with A = k1, B = -k1*invstd*dgamma/M, C = -k1*dbeta/M - B*mean
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
                                        const float* __restrict__ mi, const float* __restrict__ gamma,
                                        float* coef, float* dgamma, float* dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = mi[c * 2], invstd = mi[c * 2 + 1];
-  const double dbe = sums[c * 2];
-  const double dga = (sums[c * 2 + 1] - mean * dbe) * invstd;
-  const double k1 = (double)gamma[c] * invstd;
-  const double B = -k1 * invstd * dga / count;
-  coef[c * 4] = (float)k1;
-  coef[c * 4 + 1] = (float)B;
-  coef[c * 4 + 2] = (float)(-k1 * dbe / count - B * mean);
+  float A, B, Cc;
+  double dga, dbe;
+  bn_bwd_coefs(sums, count, mi, gamma, c, A, B, Cc, dga, dbe);     // (common.h: the one definition)
+  coef[c * 4] = A;
+  coef[c * 4 + 1] = B;
+  coef[c * 4 + 2] = Cc;
   coef[c * 4 + 3] = 0.f;
   dgamma[c] += (float)dga;
   dbeta[c] += (float)dbe;

@@ -28,7 +28,9 @@ struct PwBwdWstArgs {
   int N, Co, Ci;
   long long P;
   int tiles_per_block;
+  BnBwdFold fold;                                       // sums != NULL: the coefficient table is derived from the BatchNorm-backward sums here (x3d_hip.h coef_fold)
   float* slab;                                          // NULL | per-workgroup partial dW slabs [gridDim.x][Co][Ci] (plain stores)
+  int hot;                                              // experiments build only (X3D_PW_BWD_HOT=1): every tile load re-reads the FIRST tile (cache hits): what memory latency costs
   int noflush;                                          // experiments build only (X3D_PW_BWD_NOFLUSH=1): timing without the dW flush
 };
 
@@ -69,7 +71,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
     for (int i = tid; i < 2 * CoP * YRP / 8; i += NT) ((hx8*)Yr)[i] = z;
     for (int k = tid; k < Kp; k += NT) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
-      if (k < a.Co) { c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2]; }
+      if (k < a.Co) {
+        float cA_, cB_, cC_;
+        bn_bwd_coef_load(a.coef, a.fold, k, blockIdx.x == 0 && blockIdx.y == 0, cA_, cB_, cC_);
+        c[0] = cA_; c[1] = cB_; c[2] = cC_;
+      }
       *(f32x4*)&Cs[k * 4] = c;
     }
   }
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   // ---- dY staging: vector v = tid + NT * i -> row v >> 2, 8 points at unit v & 3 (unconditional clamped loads)
   hx8 g0[NSV], y0[NSV], g1[NSV], y1[NSV];
   auto issue_loads = [&](int tile_, hx8 (&gr)[NSV], hx8 (&yr)[NSV]) {
-    const int tile = min(tile_, tile_end - 1);
+    const int tile = a.hot ? tile_begin : min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wst_kernel(const PwBwdWstArgs a
   float gl0, gl1;
   const float* gsrc = a.egate ? a.egate : a.b_ss;      // (no SE: any valid address, the value is not used)
   auto issue_braw = [&](int tile_, hx8 (&eb)[2], float& gl) {
-    const int tile = min(tile_, tile_end - 1);
+    const int tile = a.hot ? tile_begin : min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
     gl = gsrc[(a.egate && mrow) ? (long long)n * a.Ci + m : 0];
@@ -294,7 +300,7 @@ static inline size_t bw_lds_bytes() {
 // most 96 output channels -- stage 4 of X3D-XS / S / M / L (216 <-> 96)
 bool pw_bwd_wst_applies(const x3d_pw_bwd_args* b) {
   if (x3d_env_int("X3D_PW_BWD_WST", 1) == 0) return false;   // A/B switch: 0 = off
-  if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw || b->epi != X3D_EPI_SWISH_BWD || b->tail_c) return false;
+  if (!x3d_is_half(b->dtype) || !b->w_panel || (!b->coef && !b->coef_fold) || !b->yraw || b->epi != X3D_EPI_SWISH_BWD || b->tail_c) return false;
   // stage 4: 129..224 input channels, six k-steps (the panel's pitch is roundup(Co, 16) + 8); stage 5 (round 5): 225..448 input
   // channels as two slices of seven row blocks, twelve k-steps (432 <-> 192)
   const int ks = (b->Cout + 15) >> 4;
@@ -330,6 +336,7 @@ static int bw_launch(PwBwdWstArgs& a, hipStream_t st) {
   bw_grid(a.N, a.P, a.Ci, &tpb, &gx, &slices);
   a.tiles_per_block = (int)tpb;
   a.noflush = x3d_env_int("X3D_PW_BWD_NOFLUSH", 0);
+  a.hot = x3d_env_int("X3D_PW_BWD_HOT", 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)slices), dim3(512), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_wst");
   return X3D_OK;
@@ -343,7 +350,7 @@ int pw_bwd_wst(const x3d_pw_bwd_args* b, hipStream_t st) {
   a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
   a.wp = b->w_panel; a.wp_rows = (b->Cin + 31) & ~31;
   a.dx = b->dx; a.braw = b->braw; a.b_ss = b->b_scale_shift; a.egate = b->gate; a.nc_sums = b->nc_sums;
-  a.dw = b->dw; a.slab = b->dw_slab;
+  a.dw = b->dw; a.slab = b->dw_slab; a.fold = bn_bwd_fold_arg(b->coef_fold);
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin;
   a.P = (long long)b->T * b->H * b->W;
   if (((b->Cout + 15) >> 4) == 12) return b->dtype == X3D_F16 ? bw_launch<f16, 12, 6>(a, st) : bw_launch<bf16, 12, 6>(a, st);

@@ -30,7 +30,9 @@ struct PwBwdWstaArgs {
   int N, Co, Ci;
   long long P;
   int tiles_per_block;
+  BnBwdFold fold;                                       // sums != NULL: the coefficient table is derived from the BatchNorm-backward sums here (x3d_hip.h coef_fold)
   float* slab;                                          // NULL | per-workgroup partial dW slabs [gridDim.x][Co][Ci] (plain stores)
+  int hot;                                              // experiments build only (X3D_PW_BWD_HOT=1): every tile load re-reads the FIRST tile
   int noflush;                                          // experiments build only (X3D_PW_BWD_NOFLUSH=1): timing without the dW flush
 };
 
@@ -69,7 +71,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wsta_kernel(const PwBwdWstaArgs
     for (int i = tid; i < (int)((YR_B + XR_B) / 16); i += NT) ((hx8*)Yr)[i] = z;
     for (int k = tid; k < Kp; k += NT) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
-      if (k < a.Co) { c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2]; }
+      if (k < a.Co) {
+        float cA_, cB_, cC_;
+        bn_bwd_coef_load(a.coef, a.fold, k, blockIdx.x == 0 && blockIdx.y == 0, cA_, cB_, cC_);
+        c[0] = cA_; c[1] = cB_; c[2] = cC_;
+      }
       *(f32x4*)&Cs[k * 4] = c;
     }
   }
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wsta_kernel(const PwBwdWstaArgs
   // ---- staging: dY vectors v = tid + NT * i -> row v >> 2, unit v & 3; x vectors v = tid -> row tid >> 2 (tid < 4 * CiP)
   hx8 g0[NSV], y0[NSV], g1[NSV], y1[NSV], x0, x1;
   auto issue_loads = [&](int tile_, hx8 (&gr)[NSV], hx8 (&yr)[NSV], hx8& xr) __attribute__((always_inline)) {
-    const int tile = min(tile_, tile_end - 1);
+    const int tile = a.hot ? tile_begin : min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_wsta_kernel(const PwBwdWstaArgs
   constexpr int NEO = 1 + (TAIL >= 1) + (TAIL == 2);     // add, tail_c, tail_r
   hx8 eo0[NEO][2], eo1[NEO][2];
   auto issue_epi = [&](int tile_, hx8 (&eo)[NEO][2]) __attribute__((always_inline)) {
-    const int tile = min(tile_, tile_end - 1);
+    const int tile = a.hot ? tile_begin : min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -298,7 +304,7 @@ static inline size_t bwa_lds_bytes() {
 // Co in 209..224 (fourteen k-steps), Ci <= 96: stage 4 of X3D-XS / S / M / L (96 <-> 216)
 bool pw_bwd_wsta_applies(const x3d_pw_bwd_args* b) {
   if (x3d_env_int("X3D_PW_BWD_WSTA", 1) == 0) return false;   // A/B switch: 0 = off
-  if (!x3d_is_half(b->dtype) || !b->w_panel || !b->coef || !b->yraw || b->epi != X3D_EPI_ADD || !b->x || !b->add) return false;
+  if (!x3d_is_half(b->dtype) || !b->w_panel || (!b->coef && !b->coef_fold) || !b->yraw || b->epi != X3D_EPI_ADD || !b->x || !b->add) return false;
   if (b->Cin <= 64 || b->Cin > 96 || ((b->Cout + 15) >> 4) != 14) return false;
   const long long P = (long long)b->T * b->H * b->W;
   if (P % 8 || P >= (1ll << 31) || (long long)b->Cin * P * 2 >= (1ll << 31)) return false;
@@ -328,6 +334,7 @@ static int bwa_launch(PwBwdWstaArgs& a, hipStream_t st) {
   x3d_persistent_grid(total_tiles, x3d_device_cus(), &tpb, &gx);
   a.tiles_per_block = (int)tpb;
   a.noflush = x3d_env_int("X3D_PW_BWD_NOFLUSH", 0);
+  a.hot = x3d_env_int("X3D_PW_BWD_HOT", 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
   X3D_LAUNCH_CHECK("pw_bwd_wsta");
   return X3D_OK;
@@ -340,7 +347,7 @@ int pw_bwd_wsta(const x3d_pw_bwd_args* b, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.g = b->g; a.yraw = b->yraw; a.coef = b->coef;
   a.wp = b->w_panel; a.wp_rows = (b->Cin + 31) & ~31;
-  a.dx = b->dx; a.add = b->add; a.x = b->x; a.dw = b->dw; a.slab = b->dw_slab;
+  a.dx = b->dx; a.add = b->add; a.x = b->x; a.dw = b->dw; a.slab = b->dw_slab; a.fold = bn_bwd_fold_arg(b->coef_fold);
   a.tail_c = b->tail_c; a.tail_r = b->tail_r; a.tail_sums_c = b->tail_sums_c; a.tail_sums_r = b->tail_sums_r;
   a.N = b->N; a.Co = b->Cout; a.Ci = b->Cin;
   a.P = (long long)b->T * b->H * b->W;

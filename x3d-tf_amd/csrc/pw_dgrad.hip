@@ -40,6 +40,8 @@ static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int v
       case X3D_EPI_SWISH_BWD: return pw_wst_launch<H, PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, shp, st);
     }
   }
+  // (coef_fold: the weights-stationary kernel above is the one data-gradient kernel that derives its table from the sums)
+  X3D_REQUIRE(!d->coef_fold, "pw_dgrad: coef_fold is not taken by the kernel behind this call (x3d_pw_coef_fold_supported() == 0)");
   if (d->epi != X3D_EPI_ADD_STRIDED && pw_ws_applies(a, vec, ovec)) {   // deep, narrow layers (stage 5)
     switch (d->epi) {
       case X3D_EPI_STORE: return pw_ws_launch<H, PRO_BNBWD, X3D_EPI_STORE>(a, st);
@@ -59,7 +61,9 @@ static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int v
 
 extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   X3D_REQUIRE(d && d->g && d->w && d->dx, "pw_dgrad: null pointer");
-  X3D_REQUIRE(d->coef && d->yraw, "pw_dgrad: coef/yraw required (every conv on the path feeds a BN)");
+  X3D_REQUIRE((d->coef || d->coef_fold) && d->yraw, "pw_dgrad: coef (or coef_fold) / yraw required (every conv on the path feeds a BN)");
+  X3D_REQUIRE(bn_bwd_fold_ok(d->coef_fold), "pw_dgrad: incomplete coef_fold");
+  X3D_REQUIRE(!d->coef_fold || d->dtype != X3D_F32, "pw_dgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
   X3D_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0 && d->H > 0 && d->W > 0,
               "pw_dgrad: bad extents");
   X3D_REQUIRE(x3d_dtype_ok(d->dtype), "pw_dgrad: bad dtype");
@@ -70,7 +74,7 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   X3D_REQUIRE(((uintptr_t)d->w_panel % 16) == 0, "pw_dgrad: w_panel must be 16-byte aligned");
   PwGemmArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = d->g; a.x2 = d->yraw; a.coef = d->coef;
+  a.x = d->g; a.x2 = d->yraw; a.coef = d->coef; a.fold = bn_bwd_fold_arg(d->coef_fold);
   a.w = d->w; a.wsk = d->Cin; a.wsm = 1;  // (k = co, m = ci) -> w[co*Cin + ci]
   a.N = d->N; a.K = d->Cout; a.M = d->Cin;
   a.stride = 1;
@@ -90,4 +94,21 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   return d->dtype == X3D_F16 ? pw_dgrad_h16<f16>(a, d, eb, vec, st) : pw_dgrad_h16<bf16>(a, d, eb, vec, st);
 }
 
-
+// does the kernel behind a call derive its coefficient table from the BatchNorm-backward sums (include/x3d_hip.h coef_fold)?
+// Asked of the dispatch itself: the name of the instantiation the call would launch.
+extern "C" int x3d_pw_coef_fold_supported(const x3d_pw_dgrad_args* dgrad, const x3d_pw_wgrad_args* wgrad, const x3d_pw_bwd_args* bwd) {
+  if ((dgrad != nullptr) + (wgrad != nullptr) + (bwd != nullptr) != 1) return 0;
+  char name[160];
+  int rc;
+  if (dgrad) { x3d_pw_dgrad_args t = *dgrad; t.coef_fold = nullptr; if (!t.coef) t.coef = (const float*)16; if (!t.nc_sums) t.nc_sums = (double*)16; rc = x3d_pw_kernel_name(nullptr, &t, nullptr, nullptr, name, sizeof(name)); }
+  else if (wgrad) { x3d_pw_wgrad_args t = *wgrad; t.coef_fold = nullptr; if (!t.coef) t.coef = (const float*)16; rc = x3d_pw_kernel_name(nullptr, nullptr, &t, nullptr, name, sizeof(name)); }
+  else {   // (a plan asks before it has resolved its accumulators: the dry-run dispatch only looks at what is NULL)
+    x3d_pw_bwd_args t = *bwd; t.coef_fold = nullptr; if (!t.coef) t.coef = (const float*)16; if (!t.nc_sums) t.nc_sums = (double*)16;
+    rc = x3d_pw_kernel_name(nullptr, nullptr, nullptr, &t, name, sizeof(name));
+  }
+  if (rc != X3D_OK) return 0;
+  static const char* const ok[] = {"pw_bwd_wst_kernel<", "pw_bwd_wsta_kernel<", "pw_wgrad_bf16_v2_kernel<"};
+  for (const char* p : ok) if (strncmp(name, p, strlen(p)) == 0) return 1;
+  if (strncmp(name, "pw_gemm_wst_kernel<", 19) == 0) return dgrad != nullptr;
+  return 0;
+}

@@ -43,6 +43,8 @@ struct PwGemmArgs {
   int stride, H, W, Ho, Wo;  // strided gather (stride > 1): source H,W ; sampled Ho,Wo
   int KC, nchunks, tiles_per_block;
   int wvec;            // bf16 kernel: fp32 vector width for the weight-panel staging
+  BnBwdFold fold;      // PRO_BNBWD, pw_gemm_wst.h only: sums != NULL -> `coef` is derived from the BatchNorm-backward sums (x3d_hip.h coef_fold)
+  int hot;             // experiments build only (X3D_PW_WST_HOT=1, pw_gemm_wst.h): every tile load re-reads the first tile
   const void* wp;      // bf16 kernel: packed panel (x3d_pw_pack_weights) [wp_rows][KC + 8] or null
   int wp_rows;
   // epilogue

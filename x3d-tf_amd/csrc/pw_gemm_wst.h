@@ -82,8 +82,10 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
           } else if constexpr (PRO == PRO_TAIL) {   // s_c*x + (s_r|1)*x2 + (t_c + t_r|0), as in pw_gemm_bf16.h
             c[0] = a.coef[k * 2]; c[1] = a.coef2 ? a.coef2[k * 2] : 1.0f;
             c[2] = a.coef[k * 2 + 1] + (a.coef2 ? a.coef2[k * 2 + 1] : 0.f);
-          } else {
-            c[0] = a.coef[k * 4]; c[1] = a.coef[k * 4 + 1]; c[2] = a.coef[k * 4 + 2];
+          } else {   // (filled once per workgroup: the publishing thread of channel k is unique in the launch)
+            float cA_, cB_, cC_;
+            bn_bwd_coef_load(a.coef, a.fold, k, blockIdx.x == 0 && blockIdx.y == 0, cA_, cB_, cC_);
+            c[0] = cA_; c[1] = cB_; c[2] = cC_;
           }
         }
         if constexpr (CSW == 2) *(float2*)&Cs[k * 2] = make_float2(c[0], c[1]);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NWT * 64, OCC) void pw_gemm_wst_kernel(const PwGemm
   constexpr int NSY = TWO ? NSV : 1;
   hx8 xr0[NSV], yr0[NSY], xr1[NSV], yr1[NSY];
   auto issue_loads = [&](int tile_, hx8 (&xr)[NSV], hx8 (&yr)[NSY]) {
-    const int tile = min(tile_, tile_end - 1);
+    const int tile = a.hot ? tile_begin : min(tile_, tile_end - 1);
     const int n = tile / tiles_per_n;
     const long long p0 = (long long)(tile - n * tiles_per_n) * BN;
 #pragma unroll
@@ -478,6 +480,7 @@ static int pw_wst_launch_t(PwGemmArgs& a, hipStream_t st) {
   const long long slots = (long long)cus * OCC / gy > 0 ? (long long)cus * OCC / gy : 1;
   const long long tpb = ceil_div_ll(total_tiles, slots);
   a.tiles_per_block = (int)tpb;
+  a.hot = x3d_env_int("X3D_PW_WST_HOT", 0);
   const long long gx = ceil_div_ll(total_tiles, tpb);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(NWT * 64), lds, st, a);
   X3D_LAUNCH_CHECK("pw_gemm_wst");

@@ -16,6 +16,7 @@ struct PwWgradArgs {
   int steps_per_block;  // 32-point steps per block
   int noflush;          // X3D_PW_WG_NOFLUSH=1 (timing experiment only: the partial tiles are NOT added to dw)
   int ragged;           // 16-bit storage, P % 8 != 0, stride 1: the vector kernel with ragged row ends (pw_gemm.h)
+  BnBwdFold fold;       // sums != NULL: the dY coefficients are derived from the BatchNorm-backward sums (x3d_hip.h coef_fold; pw_wgrad_bf16_v2 only)
   float* slab;          // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
 };
 
@@ -226,7 +227,8 @@ extern "C" int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* w);
 
 extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(w && w->g && w->x && w->dw, "pw_wgrad: null pointer");
-  X3D_REQUIRE((w->coef == nullptr) == (w->yraw == nullptr), "pw_wgrad: coef and yraw go together");
+  X3D_REQUIRE(((w->coef == nullptr) && (w->coef_fold == nullptr)) == (w->yraw == nullptr), "pw_wgrad: coef (or coef_fold) and yraw go together");
+  X3D_REQUIRE(bn_bwd_fold_ok(w->coef_fold) && !(w->coef_fold && w->coef_fold->dgamma), "pw_wgrad: bad coef_fold (the weight-gradient launch never publishes dgamma / dbeta)");
   X3D_REQUIRE(w->stride == 1 || w->stride == 2, "pw_wgrad: stride must be 1 or 2");
   X3D_REQUIRE(w->N > 0 && w->Cin > 0 && w->Cout > 0 && w->T > 0 && w->H > 0 && w->W > 0,
               "pw_wgrad: bad extents");
@@ -234,7 +236,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(w->Cin <= 32 * 32, "pw_wgrad: Cin too large");
   PwWgradArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = w->g; a.yraw = w->yraw; a.coef = w->coef;
+  a.g = w->g; a.yraw = w->yraw; a.coef = w->coef; a.fold = bn_bwd_fold_arg(w->coef_fold);
   a.x = w->x; a.xcoef = w->in_scale_shift; a.xgate = w->in_gate; a.xact = w->in_act;
   a.dw = w->dw; a.slab = w->dw_slab; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
   a.stride = w->stride; a.H = w->H; a.W = w->W;
@@ -257,6 +259,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   }
   if (w->dtype == X3D_F32) {
     if (x3d_parts_query) return X3D_OK;     // (no slab form in the fp32 kernels)
+    X3D_REQUIRE(!w->coef_fold, "pw_wgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
     if (a.stride == 1 && a.P >= 4 && x3d_env_int("X3D_PW_F32R", 1) != 0) {      // tile groups of <= 8, long double-buffered runs (pw_wgrad_f32r.h)
       PwWgradRArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -271,10 +274,12 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   if (w->dtype == X3D_F16) {
     const int rc = pw_wgrad_v2_dispatch<f16>(a, vec, xpro, st);
     if (rc < 0 && x3d_parts_query) return X3D_OK;       // (query mode: the generic kernel has no slab form)
+    X3D_REQUIRE(rc >= 0 || !w->coef_fold, "pw_wgrad: coef_fold is not taken by the generic kernel (x3d_pw_coef_fold_supported() == 0)");
     return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<f16>(a, vec, xpro, st);
   }
   const int rc = pw_wgrad_v2_dispatch<bf16>(a, vec, xpro, st);
   if (rc < 0 && x3d_parts_query) return X3D_OK;
+  X3D_REQUIRE(rc >= 0 || !w->coef_fold, "pw_wgrad: coef_fold is not taken by the generic kernel (x3d_pw_coef_fold_supported() == 0)");
   return rc >= 0 ? rc : pw_wgrad_bf16_dispatch<bf16>(a, vec, xpro, st);
 }
 

@@ -245,11 +245,13 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
   // once here instead of from global inside every step's prologue (an exposed L2 round trip per 64-point step);
   // only the SE gate depends on the sample and is re-read when the step crosses into the next sample
   float cA[MGS], cB[MGS], cC[MGS], xs_[XPRO ? NGS : 1], xt_[XPRO ? NGS : 1], xg_[XPRO ? NGS : 1];
+  const bool has_bn = a.coef || a.fold.sums;          // dY = A*g + B*yraw + C (coefficients from the table or from the sums)
 #pragma unroll
   for (int i = 0; i < MGS; i++) {
     const int co = co0 + (i * NTS + tsel) * 32 + srow;
-    const bool ok = a.coef && co < a.Cout && i * NTS + tsel < MG;
-    cA[i] = ok ? a.coef[co * 4] : 1.f; cB[i] = ok ? a.coef[co * 4 + 1] : 0.f; cC[i] = ok ? a.coef[co * 4 + 2] : 0.f;
+    const bool ok = has_bn && co < a.Cout && i * NTS + tsel < MG;
+    cA[i] = 1.f; cB[i] = 0.f; cC[i] = 0.f;
+    if (ok) bn_bwd_coef_load(a.coef, a.fold, co, false, cA[i], cB[i], cC[i]);
   }
   int n_gate = -1;
   auto load_gate = [&](int n) {
@@ -279,10 +281,10 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
         if (!RAG || a.P - p >= 8) {
           rg[u][i] = *(const hx8*)((const T*)a.g + o);
-          if (a.coef) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
+          if (has_bn) ry[u][i] = *(const hx8*)((const T*)a.yraw + o);
         } else {   // P % 8 != 0: the row ends inside this vector (zero fill: points are the reduction dimension)
           rg[u][i] = load8_ragged<T, hx8>((const T*)a.g + o, (int)(a.P - p));
-          if (a.coef) ry[u][i] = load8_ragged<T, hx8>((const T*)a.yraw + o, (int)(a.P - p));
+          if (has_bn) ry[u][i] = load8_ragged<T, hx8>((const T*)a.yraw + o, (int)(a.P - p));
         }
       }
     }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 && MG * NG > 8 && MG * NG <= 12)
       if (ti >= MG) continue;
       const int co = co0 + ti * 32 + srow;
       H* dst = &As[(ti * 32 + srow) * LP + u * BP + sp];
-      if (a.coef && co < a.Cout) {
+      if (has_bn && co < a.Cout) {
         const float A = cA[i], B = cB[i], C = cC[i];
         float v[8];
 #pragma unroll
@@ -540,7 +542,7 @@ static int pw_wgrad_v2_pick(PwWgradArgs& a, hipStream_t st) {
     // fit two workgroups per CU; pick the cheapest of 4x2 / 4x3 / 3x4 (216 x 96: 1056 -> 624 rows, 192 x 432:
     // 3552 -> 2400, 432 x 192: 3360 -> 2496).
     if (MG == 4 && nt >= 3 && x3d_env_int("X3D_PW_WG_T12", 1) != 0) {   // A/B switch: 0 = 4x2 only
-      const int dyr = a.coef ? 2 : 1;
+      const int dyr = (a.coef || a.fold.sums) ? 2 : 1;
       auto rows = [&](int mg, int ng) { return (long long)ceil_div(nt, ng) * dyr * a.Cout + (long long)ceil_div(mt, mg) * a.Cin; };
       const long long r42 = rows(4, 2), r43 = rows(4, 3), r34 = rows(3, 4);
       if (r43 < r42 && r43 <= r34) return pw_wgrad_v2_launch<H, 4, 3, XPRO, STRIDED>(a, st);

@@ -82,6 +82,8 @@ def _struct_pointers(st, out):
         if ftype is C.c_void_p:
             if isinstance(v, int) and v:
                 out.append(v)
+                if fname == "coef_fold" and v in hip.FOLDS:      # (a host struct referred to by address)
+                    _struct_pointers(hip.FOLDS[v], out)
         elif isinstance(v, C.Structure):
             _struct_pointers(v, out)
         elif isinstance(v, C.Array):

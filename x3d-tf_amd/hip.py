@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 129   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 130   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -35,7 +35,7 @@ class PwDgradArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("w", _vp), ("dx", _vp), ("epi", _i),
                 ("add", _vp), ("braw", _vp), ("b_scale_shift", _vp), ("gate", _vp), ("nc_sums", _vp),
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
-                ("w_panel", _vp)]
+                ("w_panel", _vp), ("coef_fold", _vp)]
 
 
 class PwBwdArgs(C.Structure):
@@ -45,7 +45,7 @@ class PwBwdArgs(C.Structure):
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
                 ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp),
                 ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp), ("x_stride", _i), ("xH", _i), ("xW", _i),
-                ("dw_slab", _vp)]
+                ("dw_slab", _vp), ("coef_fold", _vp)]
 
 
 class DwReduceJob(C.Structure):
@@ -75,7 +75,23 @@ class PwPackItem(C.Structure):
 class PwWgradArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("x", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("dw", _vp), ("N", _i), ("Cin", _i), ("Cout", _i),
-                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("dw_slab", _vp)]
+                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("dw_slab", _vp), ("coef_fold", _vp)]
+
+
+class BnBwdFold(C.Structure):
+    """x3d_bn_bwd_fold: the BatchNorm-backward finalize folded into its consumers (coef_fold of the backward argument structs)."""
+    _fields_ = [("sums", _vp), ("count", _d), ("mean_invstd", _vp), ("gamma", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("coef_out", _vp)]
+
+
+FOLDS = {}      # address -> BnBwdFold: argument structs refer to a fold by address (tools that walk a plan's pointers follow it)
+
+
+def fold_address(f: BnBwdFold) -> int:
+    """Address to put into an argument struct's `coef_fold`; the caller keeps `f` alive for as long as launches use it."""
+    a = C.addressof(f)
+    FOLDS[a] = f
+    return a
 
 
 class BnFold(C.Structure):
@@ -124,6 +140,7 @@ _SIGS = {
     "x3d_pw_bwd_supported": ([C.POINTER(PwBwdArgs)], _i),
     "x3d_pw_bwd": ([C.POINTER(PwBwdArgs), _vp], _i),
     "x3d_pw_bwd_dw_parts": ([C.POINTER(PwBwdArgs)], _i),
+    "x3d_pw_coef_fold_supported": ([C.POINTER(PwDgradArgs), C.POINTER(PwWgradArgs), C.POINTER(PwBwdArgs)], _i),
     "x3d_dw_slab_reduce": ([C.POINTER(DwReduceJob), _i, _vp], _i),
     "x3d_pw_bwd_rc_panel_elems": ([_i, _i], _ll),
     "x3d_pw_bwd_rc_sums_elems": ([_i, _i], _ll),

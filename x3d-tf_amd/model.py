@@ -121,6 +121,7 @@ PLAN_DEFAULTS = {
     "tail_bwd_fold": True,     # Add + ReLU backward in the epilogue of the kernel that produces dy
     "stem_bwd_fold": True,     # the stem BatchNorm's backward sums in the first block's `a` backward
     "side_wgrad": False,       # unfused weight-gradient GEMMs on a side stream
+    "coef_fold": True,         # the BatchNorm-backward finalize derived by its consumers where their kernels take it (no launch)
     "dw_slab": True,           # persistent fused backward kernels store per-workgroup partial weight gradients (plain stores) that
                                #   the next x3d_se_bnb_bwd launch adds up, instead of flushing them with fp32 atomics
 }
@@ -131,7 +132,7 @@ _ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-defa
     "X3D_BN_FOLD": ("bn_fold", "1", True), "X3D_NO_TAIL_FWD_FOLD": ("tail_fwd_fold", "1", False),
     "X3D_NO_TAIL_FOLD_WST": ("tail_fold_wst", "1", False), "X3D_NO_TAIL_FOLD": ("tail_bwd_fold", "1", False),
     "X3D_NO_STEM_BWD_FOLD": ("stem_bwd_fold", "1", False), "X3D_SIDE_WGRAD": ("side_wgrad", "1", True),
-    "X3D_NO_DW_SLAB": ("dw_slab", "1", False),
+    "X3D_NO_DW_SLAB": ("dw_slab", "1", False), "X3D_NO_COEF_FOLD": ("coef_fold", "1", False),
 }
 
 
@@ -952,6 +953,8 @@ class X3D:
         pl.finalize_acc()
         for f, handle in pl.folds:
             f.stats = pl._zero_views[handle].data_ptr()
+        for f, handle in getattr(pl, "bwd_folds", []):
+            f.sums = pl._zero_views[handle].data_ptr()
         self._resolve(pl, pl.fwd)
         self._resolve(pl, pl.bwd)
         pl.wrap_side(pl.bwd)
@@ -1021,17 +1024,48 @@ class X3D:
         b5 = pl.bn5
         pl.rec(Bk, "x3d_relu_bn_bwd_reduce", None, pl.dpooled, pl.c5_raw, b5.ss, pl.g5, ("acc", b5.bsums), n, c5,
                pl.P5, dt)
-        pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b5.bsums), float(n * pl.P5), b5.mi, p[f"{b5.prefix}/gamma"],
-               b5.coef, g[f"{b5.prefix}/gamma"], g[f"{b5.prefix}/beta"], c5)
+        # The BatchNorm-backward finalize (sums -> the coefficient table of dYraw = A g + B yraw + C, dgamma, dbeta) is a ~6 us launch
+        # between the producer of the sums and the consumers of the table.  Where EVERY consumer's kernel takes `coef_fold`
+        # (include/x3d_hip.h x3d_bn_bwd_fold: the persistent weights-stationary kernels and the 16-bit weight-gradient kernel
+        # -- stages 4 / 5 and conv5, 37 launches of an X3D-M step) the consumers derive the table themselves, the same bits, and
+        # one of them -- never the weight-gradient launch -- publishes dgamma / dbeta and the table; no launch is recorded.
+        fold_coef = self.opt["coef_fold"] and self.dtype != torch.float32 and not pl.side_on
+        pl.bwd_folds = getattr(pl, "bwd_folds", [])
+
+        def fold_bn_bwd(bn, count, gamma, dgamma, dbeta, consumers):
+            """consumers: [(argument struct, "dgrad" | "wgrad" | "bwd")] -- every launch that reads bn.coef.  True: folded."""
+            if not fold_coef or not consumers:
+                return False
+            slot = {"dgrad": 0, "wgrad": 1, "bwd": 2}
+            for st, kind in consumers:
+                q3 = [None, None, None]
+                q3[slot[kind]] = C.byref(st)
+                if not pl.lib.x3d_pw_coef_fold_supported(*q3):
+                    return False
+            pub = next((st for st, kind in consumers if kind != "wgrad"), None)
+            if pub is None:
+                return False
+            for st, kind in consumers:
+                f = hip.BnBwdFold(None, float(count), _p(bn.mi), _p(gamma), _p(dgamma) if st is pub else None,
+                                  _p(dbeta) if st is pub else None, _p(bn.coef) if st is pub else None)
+                pl.keep += [f, bn.mi, gamma, dgamma, dbeta, bn.coef]
+                pl.bwd_folds.append((f, bn.bsums))      # (the sums pointer is resolved with the other fp64 accumulators)
+                st.coef_fold = hip.fold_address(f)
+            return True
+
         c_last = a.stages[-1].cout
         w5 = hip.PwWgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(pl.y_last), None, None, ACT_NONE,
                              _p(g["conv5/layer_with_weights-0/kernel"]), n, c_last, c5, t, pl.h5, pl.w5, 1, dt)
-        pl.rec_side(Bk, "x3d_pw_wgrad", w5)
         cur = 0
         dy = pl.gbuf[cur][:pl.y_last.numel()]
         d5 = hip.PwDgradArgs(_p(pl.g5), _p(pl.c5_raw), _p(b5.coef), _p(p["conv5/layer_with_weights-0/kernel"]),
                              _p(dy), EPI_STORE, None, None, None, None, None, n, c_last, c5, t, pl.h5, pl.w5, dt)
         d5.w_panel = self._wp("conv5/layer_with_weights-0/kernel", True)
+        if not fold_bn_bwd(b5, n * pl.P5, p[f"{b5.prefix}/gamma"], g[f"{b5.prefix}/gamma"], g[f"{b5.prefix}/beta"],
+                           [(w5, "wgrad"), (d5, "dgrad")]):
+            pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", b5.bsums), float(n * pl.P5), b5.mi, p[f"{b5.prefix}/gamma"],
+                   b5.coef, g[f"{b5.prefix}/gamma"], g[f"{b5.prefix}/beta"], c5)
+        pl.rec_side(Bk, "x3d_pw_wgrad", w5)
         pl.rec(Bk, "x3d_pw_dgrad", d5)
         pl.rec_join(Bk)
         pl.bwd_stage_marks[len(a.stages)] = len(Bk)   # head finished
@@ -1080,7 +1114,9 @@ class X3D:
 
         pending_mark = {"stage": None}
 
-        def rec_bn_bwd_finalize(bn, count, gamma, dgamma, dbeta, c, prep=None):
+        def rec_bn_bwd_finalize(bn, count, gamma, dgamma, dbeta, c, prep=None, consumers=None):
+            if prep is None and pending_fin["job"] is None and fold_bn_bwd(bn, count, gamma, dgamma, dbeta, consumers):
+                return          # (derived by the consumers: no launch)
             fin, pending_fin["job"] = pending_fin["job"], None
             if prep is None and fin is None:
                 pl.rec(Bk, "x3d_bn_bwd_finalize", ("acc", bn.bsums), float(count), bn.mi, gamma, bn.coef, dgamma, dbeta, c)
@@ -1108,7 +1144,6 @@ class X3D:
                 pl.rec(Bk, "x3d_tail_bwd", dy, B.y, B.c_raw, B.r_raw, ("acc", B.bn_c.bsums),
                        ("acc", B.bn_r.bsums) if B.bn_r else None, n, b.cout, P_out, dt)
             gten = dy
-            rec_bn_bwd_finalize(B.bn_c, n * P_out, p[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout)
             # c
             wc = hip.PwWgradArgs(_p(gten), _p(B.c_raw), _p(B.bn_c.coef), _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate),
                                  ACT_SWISH, _p(g[f"{q}/c/kernel"]), n, b.inner, b.cout, t, B.ho, B.wo, 1, dt)
@@ -1123,7 +1158,10 @@ class X3D:
                                _p(B.b_raw), _p(B.bn_b.ss), _p(B.gate), None, None, _p(g[f"{q}/c/kernel"]), n, b.inner,
                                b.cout, t, B.ho, B.wo, dt)
             c_job = None
-            if self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fc)):
+            c_fused = bool(self._fuse_pw_bwd and pl.lib.x3d_pw_bwd_supported(C.byref(fc)))
+            rec_bn_bwd_finalize(B.bn_c, n * P_out, p[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/gamma"], g[f"{q}/bn_c/beta"], b.cout,
+                                consumers=[(fc, "bwd")] if c_fused else [(wc, "wgrad"), (dc, "dgrad")])
+            if c_fused:
                 c_job = dw_slab_job(fc, "c", g[f"{q}/c/kernel"])
                 pl.rec(Bk, "x3d_pw_bwd", ("field", fc, {"nc_sums": B.nc_sums}))
             else:
@@ -1190,13 +1228,14 @@ class X3D:
                     else:
                         pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rcr[2]), w_r, B.bn_r.coef, g_r, b.cout, b.cin, dt)
                 else:
-                    rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout)
                     wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
                                          _p(g_r), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
-                    pl.rec_side(Bk, "x3d_pw_wgrad", wr)
                     dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(w_r), _p(rt),
                                          EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
                     dr.w_panel = self._wp(f"{pre}/residual/kernel", True)
+                    rec_bn_bwd_finalize(B.bn_r, n * P_out, p[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/gamma"], g[f"{pre}/bn_r/beta"], b.cout,
+                                        consumers=[(wr, "wgrad"), (dr, "dgrad")])
+                    pl.rec_side(Bk, "x3d_pw_wgrad", wr)
                     pl.rec(Bk, "x3d_pw_dgrad", dr)
                 da = hip.PwDgradArgs(_p(gaa), _p(B.a_raw), _p(B.bn_a.coef), _p(p[f"{q}/a/kernel"]), _p(nxt),
                                      EPI_ADD_STRIDED if b.stride == 2 else EPI_ADD, _p(rt), None, None, None, None, n,
@@ -1250,7 +1289,9 @@ class X3D:
                 rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner,
                                     prep=(p[f"{q}/a/kernel"], rc[0], rc[1], b.cin))
             else:
-                rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner)
+                rec_bn_bwd_finalize(B.bn_a, n * P_in, p[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/gamma"], g[f"{q}/bn_a/beta"], b.inner,
+                                    consumers=None if B.a_bwd_rc else ([(chosen, "bwd")] if chosen is not None else
+                                                                       [(wa, "wgrad"), (da, "dgrad")]))
             if B.a_bwd_rc and not merge_rc:
                 pl.rec(Bk, "x3d_pw_bwd_rc_prepare", p[f"{q}/a/kernel"], B.bn_a.coef, rc[0], rc[1], b.inner, b.cin, dt)
             # (the `a` conv's slab is added up by the NEXT block's x3d_se_bnb_bwd: not for the first block of a stage, whose

@@ -187,8 +187,18 @@ def pw_fwd(x, w, y=None, stats=None, in_ss=None, in_gate=None, in_act=ACT_NONE, 
     return y
 
 
+def bn_bwd_fold(sums, count, mi, gamma, dgamma=None, dbeta=None, coef_out=None):
+    """x3d_bn_bwd_fold for the `coef_fold` argument of pw_dgrad / pw_wgrad / pw_bwd: the consumer derives its coefficient table
+    from the BatchNorm-backward sums; dgamma / dbeta / coef_out: this launch also publishes them (one launch per BatchNorm)."""
+    _chk(sums, mi, gamma, dgamma, dbeta, coef_out)
+    f = hip.BnBwdFold(ptr(sums), float(count), ptr(mi), ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(coef_out))
+    _KEEP.append((f, sums, mi, gamma, dgamma, dbeta, coef_out))
+    del _KEEP[:-64]
+    return f
+
+
 def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None, gate=None,
-             nc_sums=None, w_panel=None):
+             nc_sums=None, w_panel=None, coef_fold=None):
     """g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]."""
     _chk(g, yraw, coef, w, dx, add, braw, b_ss, gate, nc_sums)
     n, cout, t, h, ww = g.shape
@@ -196,12 +206,14 @@ def pw_dgrad(g, yraw, coef, w, dx, epi=EPI_STORE, add=None, braw=None, b_ss=None
     a = hip.PwDgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w), ptr(dx), epi, ptr(add), ptr(braw),
                         ptr(b_ss), ptr(gate), ptr(nc_sums), n, cin, cout, t, h, ww,
                         hip.dtype_code(g.dtype), ptr(w_panel))
+    if coef_fold is not None:
+        a.coef_fold = hip.fold_address(coef_fold)
     hip.call_struct("x3d_pw_dgrad", a)
     return dx
 
 
 def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_ss=None, gate=None, nc_sums=None,
-           tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None, slab=False):
+           tail_c=None, tail_r=None, tail_sums_c=None, tail_sums_r=None, slab=False, coef_fold=None):
     """Fused dgrad + wgrad (x3d_pw_bwd).  g/yraw: [N,Cout,T,H,W]; dx: [N,Cin,T,H,W]; dw: [Cout,Cin] +=.
     tail_c (/ tail_r) + their [Cin, 2] fp64 sums: the folded Add + ReLU backward of the block whose output is x.
     slab: the weight gradient through per-workgroup partial slabs + x3d_dw_slab_reduce instead of fp32 atomics (None is
@@ -213,6 +225,8 @@ def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_s
     a = hip.PwBwdArgs(ptr(g), ptr(yraw), ptr(coef), ptr(w_panel), ptr(dx), epi, ptr(add), ptr(braw), ptr(b_ss),
                       ptr(gate), ptr(nc_sums), ptr(x), ptr(dw), n, cin, cout, t, h, ww, hip.dtype_code(g.dtype),
                       ptr(tail_c), ptr(tail_r), ptr(tail_sums_c), ptr(tail_sums_r))
+    if coef_fold is not None:
+        a.coef_fold = hip.fold_address(coef_fold)
     import ctypes as C
     if not hip.load().x3d_pw_bwd_supported(C.byref(a)):
         return False
@@ -286,7 +300,7 @@ def bn_bwd_finalize_rc(sums, count, mi, gamma, coef, dgamma, dbeta, dtype, prep=
              0 if fw is None else fw.shape[0], 0 if fw is None else fw.shape[1], hip.dtype_code(dtype))
 
 
-def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, slab=False):
+def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, stride=1, slab=False, coef_fold=None):
     """x: conv input [N,Cin,T,H,W] (input extents); g/yraw at the output points.  slab: through partial slabs +
     x3d_dw_slab_reduce (returns None, nothing launched, when the kernel behind the call has no slab form)."""
     _chk(g, yraw, coef, x, dw, in_ss, in_gate)
@@ -294,6 +308,8 @@ def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, st
     cout = g.shape[1]
     a = hip.PwWgradArgs(ptr(g), ptr(yraw), ptr(coef), ptr(x), ptr(in_ss), ptr(in_gate), in_act, ptr(dw),
                         n, cin, cout, t, h, ww, stride, hip.dtype_code(x.dtype))
+    if coef_fold is not None:
+        a.coef_fold = hip.fold_address(coef_fold)
     if slab:
         import ctypes as C
         parts = int(hip.load().x3d_pw_wgrad_dw_parts(C.byref(a)))
