@@ -62,7 +62,7 @@ static int pw_dgrad_h16(PwGemmArgs& a, const x3d_pw_dgrad_args* d, int eb, int v
 extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   X3D_REQUIRE(d && d->g && d->w && d->dx, "pw_dgrad: null pointer");
   X3D_REQUIRE((d->coef || d->coef_fold) && d->yraw, "pw_dgrad: coef (or coef_fold) / yraw required (every conv on the path feeds a BN)");
-  X3D_REQUIRE(bn_bwd_fold_ok(d->coef_fold), "pw_dgrad: incomplete coef_fold");
+  X3D_REQUIRE(x3d_describe.out || bn_bwd_fold_ok(d->coef_fold), "pw_dgrad: incomplete coef_fold");
   X3D_REQUIRE(!d->coef_fold || d->dtype != X3D_F32, "pw_dgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
   X3D_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0 && d->H > 0 && d->W > 0,
               "pw_dgrad: bad extents");

@@ -228,7 +228,10 @@ extern "C" int x3d_pw_wgrad_dw_parts(const x3d_pw_wgrad_args* w);
 extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   X3D_REQUIRE(w && w->g && w->x && w->dw, "pw_wgrad: null pointer");
   X3D_REQUIRE(((w->coef == nullptr) && (w->coef_fold == nullptr)) == (w->yraw == nullptr), "pw_wgrad: coef (or coef_fold) and yraw go together");
-  X3D_REQUIRE(bn_bwd_fold_ok(w->coef_fold) && !(w->coef_fold && w->coef_fold->dgamma), "pw_wgrad: bad coef_fold (the weight-gradient launch never publishes dgamma / dbeta)");
+  // (dry runs -- kernel name, slab-part count -- are asked while a plan is still being recorded: its accumulators, the fold's
+  // `sums` among them, have no address yet)
+  X3D_REQUIRE(x3d_describe.out || x3d_parts_query || (bn_bwd_fold_ok(w->coef_fold) && !(w->coef_fold && w->coef_fold->dgamma)),
+              "pw_wgrad: bad coef_fold (the weight-gradient launch never publishes dgamma / dbeta)");
   X3D_REQUIRE(w->stride == 1 || w->stride == 2, "pw_wgrad: stride must be 1 or 2");
   X3D_REQUIRE(w->N > 0 && w->Cin > 0 && w->Cout > 0 && w->T > 0 && w->H > 0 && w->W > 0,
               "pw_wgrad: bad extents");
