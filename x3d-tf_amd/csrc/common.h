@@ -517,6 +517,21 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   v += dpp_get<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
   return v;
 }
+// End of a one-wave depthwise backward (dw_mx.hip, dw_mxg.hip): 27 weight-gradient sums + the two BatchNorm-backward sums, each
+// valid in lane 63 (wave_sum_lane63).  Lane 63 used to issue them as 29 single-lane atomic instructions -- 13 824 waves x 29
+// lone dwords per launch, which the memory-side atomic unit takes one request at a time (~9 % of the launch).
+// Here lane k takes sum k (a scalar read of lane 63 + one select each) and the wave issues TWO atomic instructions: 27 floats
+// at 108 contiguous bytes, two doubles.
+__device__ __forceinline__ void dw_flush_sums29(const float (&red)[29], int lane, float* dw27, double* sums2) {
+  float mine = 0.f;
+#pragma unroll
+  for (int k = 0; k < 29; k++) {
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, red[k]), 63));
+    mine = lane == k ? b : mine;
+  }
+  if (lane < 27) atomicAdd(&dw27[lane], mine);
+  else if (lane < 29) atomicAdd(&sums2[lane - 27], (double)mine);
+}
 // sum over the 64 lanes, returned to every lane (as a wave-uniform value)
 __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(v)), 63));

@@ -472,12 +472,7 @@ __global__ __launch_bounds__(64, 3) void dw3d_bwd_mx14_kernel(const DwMxBwdArgs 
     }
   red[27] = wave_sum_lane63(s1);
   red[28] = wave_sum_lane63(s2);
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
-    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
-    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
-  }
+  dw_flush_sums29(red, lane, a.dw + c * 27, a.a_sums + c * 2);
 }
 
 bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
@@ -731,12 +726,7 @@ __global__ __launch_bounds__(64, 2) void dw3d_bwd_mxw_kernel(const DwMxwBwdArgs 
     }
   red[27] = wave_sum_lane63(s1);
   red[28] = wave_sum_lane63(s2);
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
-    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
-    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
-  }
+  dw_flush_sums29(red, lane, a.dw + c * 27, a.a_sums + c * 2);
 }
 
 // X3D_DW_MXW=0: never (A/B hook)

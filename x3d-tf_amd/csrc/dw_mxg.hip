@@ -292,12 +292,7 @@ __global__ __launch_bounds__(64, 2) void dw3d_bwd_mxg_kernel(const DwMxgBwdArgs 
     }
   red[27] = wave_sum_lane63(s1);
   red[28] = wave_sum_lane63(s2);
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < 27; k++) atomicAdd(&a.dw[c * 27 + k], red[k]);
-    atomic_add_d(&a.a_sums[c * 2], (double)red[27]);
-    atomic_add_d(&a.a_sums[c * 2 + 1], (double)red[28]);
-  }
+  dw_flush_sums29(red, lane, a.dw + c * 27, a.a_sums + c * 2);
 }
 
 // (A FORWARD kernel on the same tiling -- ring of input planes, 9 NT MFMAs per plane -- was built and measured in round 4: 108 ch x 16
