@@ -479,32 +479,40 @@ bool dw_bwd_mx_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
   const int e = x3d_env_int("X3D_DW_MX", 1);
   bool p7;
-  // fp16: the forward only (dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back)
-  if (e == 0 || dtype != X3D_BF16 || S != 1 || !mx_plane_ok(g, &p7)) return false;
+  // fp16 (round 5): as bf16.  dB = cA * dv + cB * braw + cC is rounded to the storage type for the matrix cores; in fp16 it can
+  // leave the range where an fp32 dB would not -- by about the factor the stored ga = conv^T(dB) leaves it as well, and exactly
+  // what the reference's mixed_float16 policy does (its BatchNorm gradient is an fp16 tensor, utils.py:176-192): an overflow is
+  // an inf, the loss scale halves and the step is skipped (train.py:99-100 LossScaleOptimizer; Trainer.step)
+  if (e == 0 || (dtype != X3D_BF16 && (dtype != X3D_F16 || x3d_env_int("X3D_DW_MX_F16", 1) == 0)) || S != 1 || !mx_plane_ok(g, &p7)) return false;
   // 7 x 7 planes: 64.3 -> 60.3 us per launch in isolation, but 66.8 -> 73.2 us inside the X3D-M step (operands in the infinity
   // cache: the packed vector kernel gains more from that): the forward only, unless X3D_DW_MX=7
   if (p7 && e != 7) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 3) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 3) || ((uintptr_t)a.braw & 3)) return false;
-  const bool exact = g.T % 4 == 0;
+  const bool exact = g.T % 4 == 0 && !(p7 && dtype != X3D_BF16);   // (f16 + four 7 x 7 planes per tile: the exit-free variant spills)
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mx14_kernel<bf16, %s, %d>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0", (int)p7);
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mx14_kernel<%s, %s, %d>", dtype == X3D_BF16 ? "bf16" : "f16", exact ? "4, 4, 2, 1" : "6, 3, 3, 0", (int)p7);
     return true;
   }
   DwMxBwdArgs pa;
   pa.b = a;
   pa.bytes = (unsigned)bytes;
   const dim3 grid((unsigned)(g.C * (p7 ? ceil_div(g.N, 4) : g.N)));
-  if (p7) {
-    if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, true>), grid, dim3(64), 0, st, pa);
-    else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, true>), grid, dim3(64), 0, st, pa);
-  } else {
-    // (four planes in flight instead of two, <4, 4, 4>: 104.9 -> 101.8 us in isolation, 165 VGPRs; the 28 x 28 kernel 263.5 -> 269.5 us
-    // at 216 VGPRs: neither is short of loads in flight -- round 4, not kept)
-    if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);
-    else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<bf16, 6, 3, 3, false, false>), grid, dim3(64), 0, st, pa);
-  }
+#define MX14_BWD(T_)                                                                                              \
+  do {                                                                                                            \
+    if (p7) {                                                                                                     \
+      if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<T_, 4, 4, 2, true, true>), grid, dim3(64), 0, st, pa);    \
+      else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<T_, 6, 3, 3, false, true>), grid, dim3(64), 0, st, pa);         \
+    } else {                                                                                                      \
+      if (exact) hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<T_, 4, 4, 2, true, false>), grid, dim3(64), 0, st, pa);   \
+      else hipLaunchKernelGGL((dw3d_bwd_mx14_kernel<T_, 6, 3, 3, false, false>), grid, dim3(64), 0, st, pa);        \
+    }                                                                                                             \
+  } while (0)
+  // (four planes in flight instead of two, <4, 4, 4>: 104.9 -> 101.8 us in isolation, 165 VGPRs; the 28 x 28 kernel 263.5 -> 269.5 us
+  // at 216 VGPRs: neither is short of loads in flight -- round 4, not kept)
+  if (dtype == X3D_BF16) MX14_BWD(bf16); else MX14_BWD(f16);
+#undef MX14_BWD
   return true;
 }
 
@@ -736,15 +744,17 @@ bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   // measured (108 ch x 64 clips of 16 x 28 x 28): 240 -> 226 us per launch, 235 -> 222 us inside the X3D-M step, at two waves
   // per SIMD (188 VGPRs: nine weight operands + nine dW accumulators + two strips of three tensors in flight).  Rows of 20
   // elements in tiles of 14 + 6 rows (X3D-XL stage 4) lose (341 -> 564 us): only planes that fill the tiles
-  if (e == 0 || dtype != X3D_BF16 || S != 1 || (g.W & 1) || g.W < 26 || g.W > 30 || g.H < 12 ||
+  if (e == 0 || (dtype != X3D_BF16 && (dtype != X3D_F16 || x3d_env_int("X3D_DW_MX_F16", 1) == 0)) || S != 1 || (g.W & 1) || g.W < 26 || g.W > 30 || g.H < 12 ||
       (g.H % 14 != 0 && g.H % 14 < 10)) return false;
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   const int HT = ceil_div(g.H, 14);
   if (bytes >= (1ll << 30) || (long long)g.C * g.N * HT >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 7) || ((uintptr_t)a.ga & 3) || ((uintptr_t)a.dv & 7) || ((uintptr_t)a.braw & 7)) return false;
-  const bool exact = g.T % 4 == 0;
+  // (f16: the exit-free <4, 4, 2> variant spills 248 bytes per lane under hipcc 7.2 -- 256 VGPRs against bf16's 188 -- so fp16 takes the
+  // general one, 211 VGPRs, whatever T)
+  const bool exact = g.T % 4 == 0 && dtype == X3D_BF16;
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mxw_kernel<bf16, %s>", exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mxw_kernel<%s, %s>", dtype == X3D_BF16 ? "bf16" : "f16", exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
     return true;
   }
   DwMxwBwdArgs pa;
@@ -752,7 +762,12 @@ bool dw_bwd_mxw_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   pa.bytes = (unsigned)bytes;
   pa.HT = HT;
   const dim3 grid((unsigned)((long long)g.C * g.N * HT));
-  if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
-  else hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  if (dtype == X3D_BF16) {
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<bf16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  } else {
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<f16, 4, 4, 2, true>), grid, dim3(64), 0, st, pa);
+    else hipLaunchKernelGGL((dw3d_bwd_mxw_kernel<f16, 6, 3, 3, false>), grid, dim3(64), 0, st, pa);
+  }
   return true;
 }

@@ -328,8 +328,9 @@ bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const DwGeom& g = a.g;
   const int e = x3d_env_int("X3D_DW_MXG", 1);   // A/B hook (experiments builds): 0 = never
   int NT, WT, own_w, own0, HT;
-  // bf16 only: dB = cA * dv + cB * braw + cC may leave the fp16 range before the sum brings it back
-  if (e == 0 || dtype != X3D_BF16 || S != 1 || !mxg_tiling(g, &NT, &WT, &own_w, &own0, &HT)) return false;
+  // (fp16 since round 5: dw_mx.hip, dw_bwd_mx_launch)
+  if (e == 0 || (dtype != X3D_BF16 && (dtype != X3D_F16 || x3d_env_int("X3D_DW_MX_F16", 1) == 0)) || S != 1 ||
+      !mxg_tiling(g, &NT, &WT, &own_w, &own0, &HT)) return false;
   // Only rows the vector kernels must take with ragged (flat, unaligned) staging.  Measured in isolation, vector -> this kernel:
   // 108 ch x 16 clips of 16 x 39 x 39 (X3D-L stage 3) 226.7 -> 160.5 us, 162 ch x 8 (XL) 157.3 -> 109.3; 54 ch x 16 of 78 x 78
   // (two W-tiles of 40 + 38 columns in windows of 48) 380.5 -> 361.7, 72 ch x 8 275.5 -> 242.4; but the ALIGNED 56 x 56 plane of
@@ -339,9 +340,11 @@ bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   const long long bytes = (long long)g.N * g.C * g.T * g.H * g.W * 2;
   if (bytes >= (1ll << 30) || (long long)g.C * g.N * HT * WT >= (1ll << 31)) return false;
   if (((uintptr_t)a.araw & 1) || ((uintptr_t)a.ga & 1) || ((uintptr_t)a.dv & 1) || ((uintptr_t)a.braw & 1)) return false;
-  const bool exact = g.T % 4 == 0, odd = (g.W & 1) != 0, wtiled = WT > 1;
+  const bool odd = (g.W & 1) != 0, wtiled = WT > 1;
+  // (f16, one W-tile of two column tiles, even rows: the exit-free variant spills 188 bytes per lane -- the general one then)
+  const bool exact = g.T % 4 == 0 && !(dtype != X3D_BF16 && NT == 2 && !wtiled && !odd);
   if (x3d_describe.out) {
-    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mxg_kernel<bf16, %d, %d, %d, %s>", NT, (int)wtiled, (int)odd, exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
+    snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_bwd_mxg_kernel<%s, %d, %d, %d, %s>", dtype == X3D_BF16 ? "bf16" : "f16", NT, (int)wtiled, (int)odd, exact ? "4, 4, 2, 1" : "6, 3, 3, 0");
     return true;
   }
   DwMxgBwdArgs pa;
@@ -349,10 +352,11 @@ bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   pa.bytes = (unsigned)bytes;
   pa.HT = HT; pa.WT = WT; pa.own_w = own_w; pa.own0 = own0;
   const dim3 grid((unsigned)((long long)g.C * g.N * HT * WT));
-#define MXG_GO(NT_, WTL_, ODD_) do { \
-    if (exact) hipLaunchKernelGGL((dw3d_bwd_mxg_kernel<bf16, NT_, WTL_, ODD_, 4, 4, 2, true>), grid, dim3(64), 0, st, pa); \
-    else hipLaunchKernelGGL((dw3d_bwd_mxg_kernel<bf16, NT_, WTL_, ODD_, 6, 3, 3, false>), grid, dim3(64), 0, st, pa); \
+#define MXG_GO_T(T_, NT_, WTL_, ODD_) do { \
+    if (exact) hipLaunchKernelGGL((dw3d_bwd_mxg_kernel<T_, NT_, WTL_, ODD_, 4, 4, 2, true>), grid, dim3(64), 0, st, pa); \
+    else hipLaunchKernelGGL((dw3d_bwd_mxg_kernel<T_, NT_, WTL_, ODD_, 6, 3, 3, false>), grid, dim3(64), 0, st, pa); \
     return true; } while (0)
+#define MXG_GO(NT_, WTL_, ODD_) do { if (dtype == X3D_BF16) MXG_GO_T(bf16, NT_, WTL_, ODD_); else MXG_GO_T(f16, NT_, WTL_, ODD_); } while (0)
   if (NT == 2 && !wtiled && !odd) MXG_GO(2, false, false);
   if (NT == 2 && wtiled && !odd) MXG_GO(2, true, false);
   if (NT == 3 && !wtiled && !odd) MXG_GO(3, false, false);
@@ -362,5 +366,6 @@ bool dw_bwd_mxg_launch(const DwBwdArgs& a, int dtype, int S, hipStream_t st) {
   if (NT == 2 && !wtiled && odd) MXG_GO(2, false, true);
   if (NT == 2 && wtiled && odd) MXG_GO(2, true, true);
 #undef MXG_GO
+#undef MXG_GO_T
   return false;
 }
