@@ -14,7 +14,7 @@ PART=${3:-all}
 if [ "$PART" != "configs" ]; then
 python3 "$REPO/bench.py" --steps 10 --warmup 3 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench_line.json"
-rocprofv3 -M --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+rocprofv3 -M --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 8 --warmup 3 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
 find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 python3 "$REPO/tools/bench_layers.py" M 64 > "$OUT/per_launch_layers.txt" 2>&1
 if [ "${2:-}" = "pmc" ]; then
