@@ -16,6 +16,7 @@ struct PwWgradRArgs {
   const void* g; const void* yraw; const float* coef;
   const void* x; const float* xcoef; const float* xgate; int xact;
   float* dw;
+  float* slab;               // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
   int N, Cout, Cin;
   long long P;
   int mgroups, ngroups;      // tile groups along Cout / Cin
@@ -158,10 +159,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32r_kernel(const PwWgradRArgs a
     if (id < NTILE) {
       const int mt = id / NTG, nt = id - mt * NTG;
       const int ci = ci0 + nt * 32 + r;
+      // partial slab of this (sample, point chunk) -- every workgroup of the grid has steps, so every slab is written whole --
+      // or fp32 atomics into dw (x3d_hip.h dw_slab; the flush of 32-64 chunks x [Cout][Cin] is 10-15 us of a ~55 us launch)
+      float* slab = a.slab ? a.slab + (long long)blockIdx.x * a.Cout * a.Cin : nullptr;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int co = co0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+        if (co < a.Cout && ci < a.Cin) {
+          if (slab) slab[(long long)co * a.Cin + ci] = acc[s][j];
+          else atomicAdd(&a.dw[(long long)co * a.Cin + ci], acc[s][j]);
+        }
       }
     }
   }
@@ -176,14 +183,11 @@ static int wgrad_f32r_launch(PwWgradRArgs& a, hipStream_t st) {
   const size_t lds = ((size_t)2 * (MTG + NTG) * 32 * 33 + (size_t)(MTG + NTG) * 32 * 4) * sizeof(float);
   auto kern = pw_wgrad_f32r_kernel<MTG, NTG, XPRO>;
   static bool attr_set = false;
-  static int cus = 256;
-  if (!attr_set) {
+  if (!attr_set && !x3d_parts_query) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     attr_set = true;
   }
+  const int cus = x3d_device_cus();
   const int groups = a.mgroups * a.ngroups;
   const long long steps_per_n = ceil_div_ll(a.P, 32);
   // about two workgroups per CU in all: few point chunks = few atomic flushes, long runs = the pipeline's latency amortised
@@ -196,6 +200,7 @@ static int wgrad_f32r_launch(PwWgradRArgs& a, hipStream_t st) {
   if (spb > steps_per_n) spb = steps_per_n;
   a.steps_per_block = (int)spb;
   const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
+  if (x3d_parts_query) { *x3d_parts_query = (int)gx; return X3D_OK; }     // (x3d_pw_wgrad_dw_parts: one slab per blockIdx.x)
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)groups), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_f32r");
   return X3D_OK;

@@ -1085,7 +1085,7 @@ class X3D:
         # plain stores into a slab per workgroup a few.  The slabs are added up by extra workgroups of the NEXT x3d_se_bnb_bwd
         # launch (every block has one, 12 us of latency on the critical path anyway): the `c` conv's by its own block's, the `a`
         # conv's by the block below's.  Two slab buffers per role, reused by every block (stream order).
-        slab_on = self.opt["dw_slab"] and self.dtype != torch.float32
+        slab_on = self.opt["dw_slab"]
         slab_bufs = {}
         pending_reduce = {"a": None}
 
@@ -1093,7 +1093,8 @@ class X3D:
             """st: the x3d_pw_bwd / x3d_pw_wgrad arguments about to be recorded; returns its reduce job (and points st at the
             slab) or None."""
             query = pl.lib.x3d_pw_wgrad_dw_parts if isinstance(st, hip.PwWgradArgs) else pl.lib.x3d_pw_bwd_dw_parts
-            parts = int(query(C.byref(st))) if slab_on else 0
+            # (small weight gradients -- stages 2 / 3 of the unfused fp32 path -- flush a few MB: not worth a reduce job)
+            parts = int(query(C.byref(st))) if (slab_on and st.Cout * st.Cin >= 8192) else 0
             if parts <= 0:
                 return None
             elems = st.Cout * st.Cin
