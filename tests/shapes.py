@@ -183,6 +183,10 @@ DW = [
     (1, 2, 1, 7, 7, 1), (1, 2, 7, 12, 12, 2),         #   T < depth, stride 2
     (1, 2, 4, 28, 28, 2),                             # X3D-M stage-4 first block (216 ch 28 -> 14): <2, 2, 2, 4> in bf16
     (1, 2, 3, 56, 56, 2),                             # X3D-M stage-3 first block (56 -> 28)
+    # dw3d_bwd_s2_kernel (dw_s2.hip; 16-bit storage, rows of whole 16-byte vectors): T loop unrolled by 6 (T = 6 / 7 / 13 / 16 / 2 / 1),
+    # several samples and channels, a partial last H-tile, non-square planes, odd H (one pad row on top)
+    (2, 3, 7, 112, 112, 2), (1, 2, 13, 56, 56, 2), (1, 2, 16, 48, 48, 2), (2, 2, 6, 64, 40, 2), (1, 3, 2, 96, 112, 2), (1, 2, 1, 56, 56, 2),
+    (1, 2, 8, 45, 48, 2),
     (1, 2, 3, 156, 156, 2), (1, 2, 3, 78, 78, 1), (1, 2, 3, 78, 78, 2), (1, 2, 3, 39, 39, 1),   # X3D-L / XL planes (16 x 312 x 312 clips)
     (1, 2, 3, 20, 20, 2), (1, 2, 3, 10, 10, 1), (1, 2, 3, 80, 80, 2), (1, 2, 3, 40, 40, 1), (1, 2, 3, 40, 40, 2),  # + X3D-S planes
     (1, 2, 3, 10, 10, 2), (1, 2, 3, 5, 5, 1),

@@ -338,6 +338,7 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     x3d_set_error("dw3d_bwd: row of %d outputs does not fit one workgroup", Wo);
     return X3D_ERR_INVALID;
   }
+  a.exp = x3d_env_int("X3D_DW_PD_EXP", 0);   // result-changing timing hooks: -DX3D_EXPERIMENTS builds only
   a.RB = (S == 1) ? a.g.TH + 2 : a.g.TH + 1;
   a.LPB = (a.g.nstrips * SW + ((S == 1) ? 2 : 1) + 3) & ~3;   // multiple of 4 floats (aligned window reads)
   a.vecB = pick_vec(sizeof(T), a.g.Wo, f->dv, f->braw);

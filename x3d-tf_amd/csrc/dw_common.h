@@ -63,6 +63,8 @@ struct DwBwdArgs {
   void* ga; double* a_sums; float* dw;
   int LPB, RB;  // dB plane pitch / rows
   int vecB;     // staging vector width for the dv / braw planes
+  int exp;      // timing hooks of the deep-prefetch kernel (X3D_DW_PD_EXP, experiments builds only; 0 in the product):
+                // 1 = skip the tap sums, 2 = every global access out of range, 4 = skip the emit arithmetic
 };
 // prefetch depth (planes in flight per workgroup) of the deep-prefetch variants for strips of SW outputs:
 // 4 for SW <= 2 (rows of < 20 outputs), else 1 (one-plane-ahead kernels).  X3D_DW_PD=1 switches them off (A/B hook).
@@ -72,6 +74,9 @@ bool dw_fwd_pd_launch(const DwFwdArgs& a, int dtype, int S, int SW, int cv, int 
                       size_t lds, hipStream_t st);
 bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st);
+
+// stride 2, strips of two outputs, aligned 16-byte staging vectors (dw_s2.hip): register roles + packed FMAs
+bool dw_bwd_s2_launch(const DwBwdArgs& a, int dtype, int SW, int cv, int pd, unsigned grid, int bd, size_t lds, hipStream_t st);
 
 // packed variant for small stride-1 planes (dw_pk.hip): several samples of one channel per 512-thread workgroup
 bool dw_bwd_pk_launch(const DwBwdArgs& a, int dtype, int S, int SW, hipStream_t st);

@@ -308,6 +308,16 @@ __global__ __launch_bounds__(256, ((CV < 0 && SW == 2 && sizeof(T) == 2) ? 3 : B
 #pragma unroll
     for (int q = 0; q < NR; q++) raw_bload<NA * EB>(s.O[q], rsA, oOwn[q] + t * iplB, 0);
   };
+#ifdef X3D_EXPERIMENTS
+  const bool x_nomath = a.exp & 1, x_noload = a.exp & 2, x_noemit = a.exp & 4;
+#else
+  constexpr bool x_nomath = false, x_noload = false, x_noemit = false;
+#endif
+  if (x_noload) {
+    gA = DW_OOB; gB = DW_OOB;
+#pragma unroll
+    for (int q = 0; q < NR; q++) oOwn[q] = DW_OOB;
+  }
 
   float dA0[NR][NA], dA1[NR][NA], dA2[NR][NA], fin[NR][NA];
 #pragma unroll
@@ -330,15 +340,21 @@ __global__ __launch_bounds__(256, ((CV < 0 && SW == 2 && sizeof(T) == 2) ? 3 : B
   for (int q = 0; q < NR; q++) { own1[q].w[0] = own1[q].w[1] = own1[q].w[2] = own1[q].w[3] = 0u; own2[q] = own1[q]; }
 
   auto emit = [&](int t, bool live, const float (&v)[NR][NA], const Raw (&own)[NR]) {   // !live: nothing stored / summed
+    if (x_noload) live = false;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       float gv[NA];
+      if (x_noemit) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) gv[i] = v[q][i];
+      } else {
 #pragma unroll
       for (int i = 0; i < NA; i++) {
         const float av = raw_get<T>(own[q], i);
         gv[i] = (live && okOwn[q] && (!RO || ((cmask >> i) & 1)) && sc * av + sh > 0.f) ? v[q][i] : 0.f;
         s1 += gv[i];
         s2 += gv[i] * av;
+      }
       }
       Raw o;
       raw_pack<T, NA>(o, gv);
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(256, ((CV < 0 && SW == 2 && sizeof(T) == 2) ? 3 : B
       __syncthreads();
       issue(t + PD, slot[d]);
       if constexpr (DEFER) emit(t - 2, t >= 2, fin, own2);   // plane t-2, completed at the end of iteration t-1
-      if (active) {
+      if (active && !x_nomath) {
         float winA[3][WIN], winB[BR][BW];
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
@@ -844,6 +860,7 @@ bool dw_fwd_pd_launch(const DwFwdArgs& a, int dtype, int S, int SW, int cv, int 
 }
 bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int pd, unsigned grid, int bd,
                       size_t lds, hipStream_t st) {
+  if (S == 2 && dw_bwd_s2_launch(a, dtype, SW, cv, pd, grid, bd, lds, st)) return true;
   return dtype == X3D_BF16 ? bwd_pd_t<bf16>(a, S, SW, cv, pd, grid, bd, lds, st)
          : dtype == X3D_F16 ? bwd_pd_t<f16>(a, S, SW, cv, pd, grid, bd, lds, st)
                             : bwd_pd_t<float>(a, S, SW, cv, pd, grid, bd, lds, st);
