@@ -529,7 +529,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwGemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) val[2 * e] += (float)epl4[i][e];
           }
-        } else
+        } else if (m < a.M)   // (BSTORE runs the rows past M too: without this guard the last sample's padding rows read up to
+                              //  31 rows * T * Hh * Wh elements behind `add` -- unmapped memory when the tensor ends a segment)
         for (int e = 0; e < nvalid; e++) {
           const int pe = (int)p + e;
           const int t = pe / hw;
