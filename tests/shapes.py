@@ -187,6 +187,10 @@ DW = [
     # several samples and channels, a partial last H-tile, non-square planes, odd H (one pad row on top)
     (2, 3, 7, 112, 112, 2), (1, 2, 13, 56, 56, 2), (1, 2, 16, 48, 48, 2), (2, 2, 6, 64, 40, 2), (1, 3, 2, 96, 112, 2), (1, 2, 1, 56, 56, 2),
     (1, 2, 8, 45, 48, 2),
+    # dw3d_bwd_s1r_kernel (dw_s1.hip; stride 1, strips of four, 16-bit storage): every T mod 6 of the unrolled loop and its drain,
+    # several samples / channels, a partial last H-tile, non-square planes
+    (2, 3, 7, 56, 56, 1), (1, 2, 13, 40, 40, 1), (1, 2, 16, 48, 48, 1), (1, 2, 6, 80, 80, 1), (1, 2, 1, 56, 56, 1), (1, 2, 2, 56, 56, 1),
+    (1, 3, 8, 64, 40, 1), (1, 2, 4, 56, 56, 1), (1, 2, 5, 56, 56, 1), (1, 2, 9, 32, 32, 1),
     (1, 2, 3, 156, 156, 2), (1, 2, 3, 78, 78, 1), (1, 2, 3, 78, 78, 2), (1, 2, 3, 39, 39, 1),   # X3D-L / XL planes (16 x 312 x 312 clips)
     (1, 2, 3, 20, 20, 2), (1, 2, 3, 10, 10, 1), (1, 2, 3, 80, 80, 2), (1, 2, 3, 40, 40, 1), (1, 2, 3, 40, 40, 2),  # + X3D-S planes
     (1, 2, 3, 10, 10, 2), (1, 2, 3, 5, 5, 1),

@@ -380,6 +380,11 @@ static int dw_bwd_launch(const x3d_dw3d_bwd_args* f, hipStream_t st) {
     X3D_LAUNCH_CHECK("dw3d_bwd");
     return X3D_OK;
   }
+  if (S == 1 && cv > 0 && dw_bwd_s1_launch(a, f->dtype, SW, cv, (unsigned)grid, bd, st)) {   // strips of four, rows of whole vectors (56 x 56, 80 x 80, 40 x 40): dw_s1.hip
+    if (x3d_describe.out) return X3D_OK;
+    X3D_LAUNCH_CHECK("dw3d_bwd");
+    return X3D_OK;
+  }
   if (cv > 0 && dw_bwd_pk_launch(a, f->dtype, S, SW, st)) {   // 10..18-wide stride-1 planes: packed kernel (dw_pk.hip)
     if (x3d_describe.out) return X3D_OK;
     X3D_LAUNCH_CHECK("dw3d_bwd");

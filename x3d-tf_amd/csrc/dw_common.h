@@ -76,6 +76,8 @@ bool dw_bwd_pd_launch(const DwBwdArgs& a, int dtype, int S, int SW, int cv, int 
                       size_t lds, hipStream_t st);
 
 // stride 2, strips of two outputs, aligned 16-byte staging vectors (dw_s2.hip): register roles + packed FMAs
+// stride 1, strips of four outputs, rows of whole 16-byte vectors in 16-bit storage (dw_s1.hip): the same form
+bool dw_bwd_s1_launch(const DwBwdArgs& a, int dtype, int SW, int cv, unsigned grid, int bd, hipStream_t st);
 bool dw_bwd_s2_launch(const DwBwdArgs& a, int dtype, int SW, int cv, int pd, unsigned grid, int bd, size_t lds, hipStream_t st);
 
 // packed variant for small stride-1 planes (dw_pk.hip): several samples of one channel per 512-thread workgroup
