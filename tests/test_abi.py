@@ -93,8 +93,11 @@ def test_dw3d_kernel_name_dry_run():
     b.dv = b.braw = b.coef_nc = b.araw = b.a_scale_shift = b.w = b.ga = b.a_sums = b.dw = 256
     b.dtype = hip.BF16
     b.N, b.C, b.T, b.H, b.W, b.stride = 64, 108, 16, 56, 56, 1
-    name = hip.dw3d_kernel_name(b)
-    assert name.startswith("dw3d_bwd_kernel<bf16, 1, 4, "), name
+    assert hip.dw3d_kernel_name(b) == "dw3d_bwd_s1r_kernel<bf16, 8, 1, 6>"      # dw_s1.hip
+    b.C, b.H, b.W, b.stride = 54, 112, 112, 2
+    assert hip.dw3d_kernel_name(b) == "dw3d_bwd_s2r_kernel<bf16, 8, 2, 6>"      # dw_s2.hip: the headline's largest launches
+    b.dtype = hip.F32
+    assert hip.dw3d_kernel_name(b).startswith("dw3d_bwd_kernel<float, 2, 2, "), hip.dw3d_kernel_name(b)   # fp32 storage keeps the older kernels
     f.stride = 3
     import pytest
     with pytest.raises(hip.X3DHipError):
