@@ -88,7 +88,7 @@ def test_dw3d_kernel_name_dry_run():
     f.x = f.w = f.y = 256
     f.dtype = hip.BF16
     f.N, f.C, f.T, f.H, f.W, f.stride = 64, 54, 16, 112, 112, 2
-    assert hip.dw3d_kernel_name(f) == "dw3d_fwd_kernel<bf16, 2, 4, 2, 8>"
+    assert hip.dw3d_kernel_name(f) == "dw3d_fwd_di_kernel<bf16, 2>"             # stride 2, strips of four: the de-interleaved LDS plane
     b = hip.Dw3dBwdArgs()
     b.dv = b.braw = b.coef_nc = b.araw = b.a_scale_shift = b.w = b.ga = b.a_sums = b.dw = 256
     b.dtype = hip.BF16

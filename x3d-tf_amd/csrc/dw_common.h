@@ -55,6 +55,7 @@ struct DwFwdArgs {
   const float* ss; int act;
   double* stats; double* pool;
   x3d_bn_fold bn;   // bn.stats != nullptr: scale/shift of the prologue from these statistics (BN finalize folded in)
+  int exp;          // timing hooks (X3D_DW_FWD_EXP, experiments builds only; 0 in the product): 1 = skip the tap sums, 2 = no global access
 };
 struct DwBwdArgs {
   DwGeom g;

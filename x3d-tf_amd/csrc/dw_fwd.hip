@@ -7,16 +7,28 @@
 // ================================================================================================
 // CV > 0: the staging vector width (CV elements) and SW-aligned strips are guaranteed by the host, so every
 // width / alignment decision is compile-time (the runtime-width path costs ~300 scalar instructions per plane)
-template <typename T, int S, int SW, int NSV, int CV>
-__global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
+// DI (stride 2, strips of four, 16-byte staging vectors of 16-bit elements, no left pad): the LDS plane is DE-INTERLEAVED -- every
+// row holds its even columns, then its odd columns (half pitch LPh).  With the plain layout a thread's window starts 8 floats
+// after its neighbour's and its staging vector lands 8 floats after its neighbour's: lanes 32 bytes apart meet on the same
+// banks (SQ_LDS_BANK_CONFLICT = 74 % of SQ_LDS_IDX_ACTIVE, the LDS pipe busy 68 % of the launch).  De-interleaved, a staging
+// vector is two 16-byte writes and a window two 16-byte reads (+ one float) at a lane stride of 16 bytes: conflict-free.
+template <typename T, int S, int SW, int NSV, int CV, bool DI>
+__device__ __forceinline__ void dw3d_fwd_body(const DwFwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const DwGeom& g = a.g;
+  static_assert(!DI || (S == 2 && SW == 4 && CV == 8 && NSV > 0 && sizeof(T) == 2), "de-interleaved planes: stride 2, strips of 4, 8-element vectors");
+  const int LPh = (g.Wo + 4) & ~3;      // DI: floats per half row (even columns 0 .. Wo: the last one is the right halo)
   constexpr int WIN = (SW - 1) * S + 3;
   constexpr int NS = NSV > 0 ? NSV : 1;
   constexpr bool RAG = CV < 0;            // ragged plane: flat staging in vectors of -CV elements (FlatMap, dw_common.h)
   constexpr int RV = RAG ? -CV : 1;
-  const int plane_sz = g.RIN * g.LP;
+  const int plane_sz = g.RIN * (DI ? 2 * LPh : g.LP);
   float* scratch = lds + plane_sz;
+#ifdef X3D_EXPERIMENTS
+  const bool x_nomath = a.exp & 1, x_noload = a.exp & 2;
+#else
+  constexpr bool x_nomath = false, x_noload = false;
+#endif
 
   int b = blockIdx.x;
   const int tile = __builtin_amdgcn_readfirstlane(b % g.ntile_h); b /= g.ntile_h;
@@ -58,7 +70,14 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   if constexpr (NSV > 0) {
     map.build(g.RIN, g.LP, row0, g.H, g.W, g.pw, vec);
 #pragma unroll
-    for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + map.goff[i], vec);
+    for (int i = 0; i < NS; i++) if (map.goff[i] >= 0 && !x_noload) raw_load<T>(raw[i], xin + map.goff[i], vec);
+    if constexpr (DI) {   // loff = row * LP + column (pw == 0)  ->  row * 2 LPh + column / 2
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        const int lr = map.loff[i] / g.LP, c0 = map.loff[i] - lr * g.LP;
+        map.loff[i] = lr * 2 * LPh + (c0 >> 1);
+      }
+    }
   }
 
   v2f acc01[SW], acc2p[(SW + 1) / 2];   // (out[t-1], out[t]) per output, out[t+1] as pairs over outputs
@@ -77,7 +96,7 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
   const bool vstore = RAG ? (SW > 1 && wo0 + SW <= g.Wo)
                           : ((CV > 0 && SW > 1) || ((SW > 1) && (g.Wo % SW == 0) && (((uintptr_t)a.y) % (SW * sizeof(T)) == 0)));
   auto store_plane = [&](int t, const float (&v)[SW]) {
-    if (!active) return;
+    if (!active || x_noload) return;
     T* dst = yout + t * oplane + (long long)ho * g.Wo + wo0;
     if (vstore) {
       VecIO<T, SW>::store(dst, v);
@@ -106,7 +125,13 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
         if (map.goff[i] >= 0) {
           float* d = lds + map.loff[i];
           if constexpr (RAG) flat_commit<T, RV>(d, map.wrap[i], g.LP - g.W, raw[i], xf);
-          else {
+          else if constexpr (DI) {
+            f32x4 ev, od;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ev[e] = xf(raw_get<T>(raw[i], 2 * e)); od[e] = xf(raw_get<T>(raw[i], 2 * e + 1)); }
+            *(f32x4*)d = ev;
+            *(f32x4*)(d + LPh) = od;
+          } else {
 #pragma unroll
             for (int e = 0; e < MaxVec<T>::v; e++) if (e < vec) d[e] = xf(raw_get<T>(raw[i], e));
           }
@@ -119,16 +144,24 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
     if constexpr (NSV > 0) {  // next plane's loads fly while this one is consumed
       if (t + 1 < g.T) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) if (map.goff[i] >= 0) raw_load<T>(raw[i], xin + (t + 1) * iplane + map.goff[i], vec);
+        for (int i = 0; i < NS; i++) if (map.goff[i] >= 0 && !x_noload) raw_load<T>(raw[i], xin + (t + 1) * iplane + map.goff[i], vec);
       }
     }
     if (t >= 2) store_plane(t - 2, fin);
-    if (active) {
+    if (active && !x_nomath) {
 #pragma unroll
       for (int kh = 0; kh < 3; kh++) {
         float win[WIN];
+        if constexpr (DI) {
+          const float* row = lds + (r * S + kh) * 2 * LPh + wo0;
+          const f32x4 ev = *(const f32x4*)row, od = *(const f32x4*)(row + LPh);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { win[2 * e] = ev[e]; win[2 * e + 1] = od[e]; }
+          win[8] = row[4];
+        } else {
         const float* row = lds + (r * S + kh) * g.LP + wo0 * S;   // wo0 * S is a multiple of SW * S floats
         lds_window<WIN, (SW * S >= 4 ? 4 : SW * S)>(row, win);
+        }
         // out[t-1] sees this plane through kt = 2, out[t] through kt = 1, out[t+1] through kt = 0
         dw_taps_row<S, SW, WIN>(win, w21[kh], w0[kh], acc01, acc2p);
       }
@@ -157,6 +190,11 @@ __global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) {
     }
   }
 }
+
+template <typename T, int S, int SW, int NSV, int CV>
+__global__ __launch_bounds__(256) void dw3d_fwd_kernel(const DwFwdArgs a) { dw3d_fwd_body<T, S, SW, NSV, CV, false>(a); }
+template <typename T, int NSV>
+__global__ __launch_bounds__(256) void dw3d_fwd_di_kernel(const DwFwdArgs a) { dw3d_fwd_body<T, 2, 4, NSV, 8, true>(a); }
 
 template <typename T, int S, int SW, int CV>
 static void dw_fwd_launch_cv(const DwFwdArgs& a, int nsv, unsigned grid, int bd, size_t lds, hipStream_t st) {
@@ -190,6 +228,7 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   a.stats = f->stats; a.pool = f->pool;
   memset(&a.bn, 0, sizeof(a.bn));
   if (f->in_bn) a.bn = *f->in_bn;
+  a.exp = x3d_env_int("X3D_DW_FWD_EXP", 0);   // result-changing timing hooks: -DX3D_EXPERIMENTS builds only
   const int Wo = ceil_div(f->W, S);
   const int SW = dw_pick_sw(Wo);
   int bd; size_t ldsf;
@@ -232,6 +271,23 @@ static int dw_fwd_launch(const x3d_dw3d_fwd_args* f, hipStream_t st) {
   if ((cv == 0 || narrow) && flat_env != 0) {
     const int rv = dw_flat_vec(sizeof(T), a.g.W);
     if (rv > 0 && dw_nsv_flat(a.g.RIN, a.g.W, rv, bd) <= 4) { cv = -rv; nsv = dw_nsv_flat(a.g.RIN, a.g.W, rv, bd); }
+  }
+  // stride 2, strips of four, whole 16-byte vectors, no left pad: the de-interleaved LDS plane.  X3D_DW_FWD_DI=0: A/B hook
+  if constexpr (S == 2 && sizeof(T) == 2) {
+    if (SW == 4 && cv == 8 && a.g.pw == 0 && nsv <= 4 && x3d_env_int("X3D_DW_FWD_DI", 1) != 0) {
+      const int LPh = (a.g.Wo + 4) & ~3;
+      const size_t lds_di = ((size_t)a.g.RIN * 2 * LPh + 2 * 4 + 8) * sizeof(float);
+      if (lds_di <= 64 * 1024) {
+        if (x3d_describe.out) {
+          snprintf(x3d_describe.out, x3d_describe.cap, "dw3d_fwd_di_kernel<%s, %d>", TypeName<T>::v, nsv <= 2 ? 2 : 4);
+          return X3D_OK;
+        }
+        if (nsv <= 2) hipLaunchKernelGGL((dw3d_fwd_di_kernel<T, 2>), dim3((unsigned)grid), dim3(bd), lds_di, st, a);
+        else hipLaunchKernelGGL((dw3d_fwd_di_kernel<T, 4>), dim3((unsigned)grid), dim3(bd), lds_di, st, a);
+        X3D_LAUNCH_CHECK("dw3d_fwd");
+        return X3D_OK;
+      }
+    }
   }
   switch (SW) {
     case 4: dw_fwd_launch_nsv<T, S, 4>(a, nsv, cv, (unsigned)grid, bd, lds, st); break;
