@@ -187,6 +187,7 @@ DW = [
     # several samples and channels, a partial last H-tile, non-square planes, odd H (one pad row on top)
     (2, 3, 7, 112, 112, 2), (1, 2, 13, 56, 56, 2), (1, 2, 16, 48, 48, 2), (2, 2, 6, 64, 40, 2), (1, 3, 2, 96, 112, 2), (1, 2, 1, 56, 56, 2),
     (1, 2, 8, 45, 48, 2),
+    (1, 2, 7, 120, 120, 2),   # planes too large for the ring kernel's constant LDS strides: dw3d_bwd_s2_kernel (two barriers per plane)
     # dw3d_bwd_s1r_kernel (dw_s1.hip; stride 1, strips of four, 16-bit storage): every T mod 6 of the unrolled loop and its drain,
     # several samples / channels, a partial last H-tile, non-square planes
     (2, 3, 7, 56, 56, 1), (1, 2, 13, 40, 40, 1), (1, 2, 16, 48, 48, 1), (1, 2, 6, 80, 80, 1), (1, 2, 1, 56, 56, 1), (1, 2, 2, 56, 56, 1),
