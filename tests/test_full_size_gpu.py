@@ -236,3 +236,60 @@ def test_depthwise_56_backward_full_size(gpu, dtype):
     sref = torch.stack([s1, s2], 1)
     _check("a_sums", a_sums, sref, 10 * st, 10 * st * max(1.0, sref.abs().max().item()))
     print(f"full-size 56^2 depthwise backward {dtype} ({'matrix-core' if mx else 'vector'} kernel): ga err {worst:.2e} of max, dW err {e:.2e} of max (limit {wtol:.0e})")
+
+
+@pytest.mark.parametrize("dtype", HALF)
+def test_depthwise_112_stride2_backward_full_size(gpu, dtype):
+    """x3d_dw3d_bwd of the first block's stride-2 layer at batch 64: 54 channels of 16 x 112 x 112 -> 56 x 56 (the launch with the
+    largest total of the train step; dw3d_bwd_s2r_kernel for 16-bit storage), against the fp64 stencil written as strided slices
+    (TF-SAME for an even extent at stride 2: no pad in front, one behind)."""
+    from x3d_tf_amd import hip, ops
+    from tests import shapes as S
+    n, c, t, h, w = 64, 54, 16, 112, 112
+    ho, wo = h // 2, w // 2
+    g_ = torch.Generator(device=gpu)
+    g_.manual_seed(53)
+    rn = lambda *s: torch.randn(*s, generator=g_, device=gpu, dtype=torch.float32)
+    araw = rn(n, c, t, h, w).to(dtype)
+    dv = rn(n, c, t, ho, wo).to(dtype)
+    braw = rn(n, c, t, ho, wo).to(dtype)
+    coef = rn(n, c, 4) * 0.5
+    wt = rn(c, 3, 3, 3) * 0.3
+    ss = torch.stack([1 + 0.3 * rn(c), 0.3 * rn(c)], 1)
+    ga = torch.empty((n, c, t, h, w), dtype=dtype, device=gpu)
+    a_sums = torch.zeros((c, 2), dtype=torch.float64, device=gpu)
+    dw = torch.full((c, 27), 0.25, dtype=torch.float32, device=gpu)
+    ops.dw3d_bwd(dv, braw, coef, araw, ss, wt.view(c, 27), ga, a_sums, dw, 2)
+    torch.cuda.synchronize()
+    name = hip.kernel_name(S.dw_bwd_struct((n, c, t, h, w, 2), dtype))
+    assert "s2r" in name, name
+    wd = wt.double()
+    dw_ref = torch.zeros((c, 3, 3, 3), dtype=torch.float64, device=gpu)
+    worst, CH = 0.0, 4
+    s1 = torch.zeros(c, dtype=torch.float64, device=gpu)
+    s2 = torch.zeros(c, dtype=torch.float64, device=gpu)
+    rt, at = tol_store(dtype)
+    for i in range(0, n, CH):
+        cd = coef[i:i + CH].double()
+        dB = cd[:, :, 0, None, None, None] * dv[i:i + CH].double() + cd[:, :, 1, None, None, None] * braw[i:i + CH].double() + cd[:, :, 2, None, None, None]
+        z = araw[i:i + CH].double() * ss[:, 0].double().view(1, -1, 1, 1, 1) + ss[:, 1].double().view(1, -1, 1, 1, 1)
+        pa = torch.nn.functional.pad(torch.relu(z), (0, 1, 0, 1, 1, 1))
+        dAp = torch.zeros_like(pa)
+        for kt in range(3):
+            for kh in range(3):
+                for kw in range(3):
+                    # out[t, ho, wo] = sum_k w[k] a[t + kt - 1, 2 ho + kh, 2 wo + kw]
+                    sl = (slice(None), slice(None), slice(kt, kt + t), slice(kh, kh + 2 * ho, 2), slice(kw, kw + 2 * wo, 2))
+                    dAp[sl] += wd[:, kt, kh, kw].view(1, -1, 1, 1, 1) * dB
+                    dw_ref[:, kt, kh, kw] += (dB * pa[sl]).sum((0, 2, 3, 4))
+        ref = dAp[:, :, 1:1 + t, :h, :w] * (z > 0)
+        worst = max(worst, _check(f"ga[{i}:{i + CH}]", ga[i:i + CH], ref, rt, at * ref.abs().max().item()))
+        gs = ga[i:i + CH].double()
+        s1 += gs.sum((0, 2, 3, 4))
+        s2 += (gs * araw[i:i + CH].double()).sum((0, 2, 3, 4))
+        del dB, z, pa, dAp, ref, gs
+    e = _check("dw", dw.double().view(c, 3, 3, 3) - 0.25, dw_ref, 2e-5, 2e-5 * dw_ref.abs().max().item())
+    st = 3e-3 if dtype == torch.bfloat16 else 5e-4
+    sref = torch.stack([s1, s2], 1)
+    _check("a_sums", a_sums, sref, 10 * st, 10 * st * max(1.0, sref.abs().max().item()))
+    print(f"full-size 112^2 -> 56^2 depthwise backward {dtype} ({name}): ga err {worst:.2e} of max, dW err {e:.2e} of max (limit 2e-05)")
