@@ -12,7 +12,7 @@ CHANS = [24, 48, 54, 96, 108, 192, 216, 432, 40, 72, 200]
 
 
 def case_calls(rng: random.Random):
-    """One fuzz case = 9 kernel-test calls: [(test function name, positional args after `gpu`)]."""
+    """One fuzz case = 11 kernel-test calls: [(test function name, positional args after `gpu`)]."""
     dt = rng.choice(DTYPES)
     out = []
     shp = (rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 5, 8]), rng.choice(WIDTHS), rng.choice(WIDTHS),
@@ -39,6 +39,12 @@ def case_calls(rng: random.Random):
     ts, hs, ws = rng.choice([1, 2, 4, 8]), rng.choice([3, 5, 7, 8, 9, 13, 16, 20, 39]), rng.choice([3, 7, 8, 11, 13, 16, 23, 27, 39, 40, 46])
     out.append(("test_pw_fwd", (dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None), False)))
     out.append(("test_pw_wgrad", (dt, (n, rng.choice([24, 32, 48]), rng.choice([24, 48, 96]), ts, hs, ws, 2, None))))
+    # round 5: planes whose rows are whole 16-byte vectors (the stride-2 / stride-1 ring kernels of dw_s2.hip / dw_s1.hip, the
+    # de-interleaved stride-2 forward): T around the 6-fold unrolled loop and its drain, partial H-tiles, non-square planes
+    shv = (rng.choice([1, 2, 3]), rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5, 6, 7, 8, 12, 13]),
+           rng.choice([8, 14, 20, 27, 28, 33, 40, 45, 56, 64]), rng.choice([16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 120]), rng.choice([1, 2]))
+    out.append(("test_dw3d_fwd", (dt, shv)))
+    out.append(("test_dw3d_bwd", (dt, shv)))
     return out
 
 

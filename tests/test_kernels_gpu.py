@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from tests import shapes as S
-from tests.util import report, rnd, round_to, tol_gemm, tol_store
+from tests.util import report, rnd, round_to, tie_slack, tol_gemm, tol_store
 
 pytestmark = pytest.mark.gpu
 
@@ -106,7 +106,10 @@ def test_pw_fwd(gpu, dtype, shape, panel):
     torch.cuda.synchronize()
     rt, at = tol_gemm(dtype)
     scale = ref.abs().max().item()
-    report("y", y, ref, rt, at * scale)
+    slack = 0.0
+    if pro and dtype != torch.float32 and stride == 1:   # an operand on a rounding tie may land on the other neighbour (util.tie_slack)
+        slack = tie_slack(xin, dtype, round_to(wt, dtype).abs())
+    report("y", y, ref, rt, at * scale + slack)
     # statistics describe the tensor as stored
     sref = _stats_ref(y.float().cpu(), dtype)
     report("stats", stats, sref, _stol(dtype), _stol(dtype) * max(1.0, sref.abs().max().item()))
