@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 130
+#define X3D_ABI_VERSION 131
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -87,6 +87,25 @@ int x3d_dwt_fwd(const void* x, const float* w, void* y, double* stats, const flo
  * dx [N][C][T][HW] = conv_t^T dY ; dw [C][KT] += */
 int x3d_dwt_bwd(const void* g, const void* yraw, const float* relu_scale_shift, const float* coef, const void* x,
                 const float* w, void* dx, float* dw, int N, int C, int T, int HW, int KT, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 + K2 FUSED (ABI 131): the whole stem convolution pair, reference model.py:202-206 -- conv_s, then conv_t, with nothing
+ *     in between -- as one launch each way, so neither the conv_s output nor its gradient ever exists in HBM.
+ *   x3d_stem_fwd: x (channels-last clip batch [N][T][H][W][3], X3D_LAYOUT_NTHWC) -> y [N][Cout][T][Ho][Wo] = conv_t(conv_s(x)),
+ *     the conv_s output rounded to the storage type between the two exactly as x3d_stem_s_fwd stores it: y is bit-identical to
+ *     x3d_stem_s_fwd + x3d_dwt_fwd.  stats / out_scale_shift / out_act as in x3d_dwt_fwd.
+ *   x3d_stem_bwd: g (grad wrt relu(bn(y)), masked here when relu_scale_shift != NULL), yraw (= y of the forward), coef as in
+ *     x3d_dwt_bwd; dw_t [Cout][KT] += , dw_s [Cout][3][3][3] += .  The conv_s output is recomputed on the matrix cores, the
+ *     conv_t input gradient stays in LDS as the operand of the conv_s weight-gradient tile.
+ *   Supported (x3d_stem_fused_supported != 0): 16-bit storage, x_layout = X3D_LAYOUT_NTHWC, Cin = 3, W % 8 == 0, Cout <= 32,
+ *     KT = 5, y under 2 GB; x 16-byte aligned.  Everything else runs the separate K1 / K2 entry points above.
+ * ------------------------------------------------------------------------------------------ */
+int x3d_stem_fused_supported(int Cin, int Cout, int KT, int N, int T, int H, int W, int dtype, int x_layout);
+int x3d_stem_fwd(const void* x, const float* w_s, const float* w_t, void* y, double* stats, const float* out_scale_shift,
+                 int out_act, int N, int Cin, int T, int H, int W, int Cout, int KT, int dtype, int x_layout, void* stream);
+int x3d_stem_bwd(const void* g, const void* yraw, const float* relu_scale_shift, const float* coef, const void* x,
+                 const float* w_s, const float* w_t, float* dw_s, float* dw_t, int N, int Cin, int T, int H, int W, int Cout,
+                 int KT, int dtype, int x_layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3  BatchNormalization(axis=-1, eps, momentum)   reference model.py:89-92,196-199,254-257,

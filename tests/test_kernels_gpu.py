@@ -1000,6 +1000,92 @@ def test_stem(gpu, dtype, shape):
             ops.stem_s_fwd(x.to(gpu).permute(0, 2, 3, 4, 1).contiguous(), ws.to(gpu), channels_last=True)
 
 
+STEM_FUSED = [(2, 4, 16, 16, 24), (1, 16, 12, 224, 24),     # two segments per row (64 + 48 columns), T = 16: three ring turns
+              (3, 5, 10, 72, 24),                           # 15 segments: the last group is three segments, Wo = 36 of 64 columns
+              (1, 7, 6, 312, 32), (2, 3, 5, 160, 32),       # X3D-XL: 32 channels (four rows per wave), Wo % 8 == 4, odd H
+              (1, 1, 8, 24, 24), (2, 2, 9, 32, 8),          # T < KT; Cout = 8 (rows 8.. of every wave idle)
+              (5, 6, 40, 128, 24)]                          # 100 segments = 25 groups: several groups per workgroup on a small GPU grid
+
+
+@pytest.mark.parametrize("dtype", S.HALF_DTYPES)
+@pytest.mark.parametrize("shape", STEM_FUSED)
+def test_stem_fused(gpu, dtype, shape):
+    """x3d_stem_fwd / x3d_stem_bwd (conv_s -> conv_t in one launch each way, reference model.py:202-206) against the
+    two-kernel path they replace -- the forward BIT FOR BIT (same products in the same order, the conv_s output rounded to
+    the storage type on chip as it was in HBM) -- and the two weight gradients against fp64 autograd as well."""
+    ops = _ops()
+    n, t, h, w, c1 = shape
+    g_ = _gen(11)
+    x, xd = rnd((n, 3, t, h, w), dtype, g_)
+    ws = (torch.randn((c1, 3, 3, 3), generator=g_) * 0.3).to(gpu)
+    wt = (torch.randn((c1, 5), generator=g_) * 0.4).to(gpu)
+    xcl = x.to(gpu).permute(0, 2, 3, 4, 1).contiguous()
+    assert ops.stem_fused_supported(xcl, c1)
+    ys = ops.stem_s_fwd(xcl, ws, channels_last=True)
+    st_ref = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
+    yt_ref = ops.dwt_fwd(ys, wt, stats=st_ref)
+    st = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
+    yt = ops.stem_fwd(xcl, ws, wt, stats=st)
+    torch.cuda.synchronize()
+    assert torch.equal(yt, yt_ref), f"fused stem forward differs from conv_s + conv_t: {(yt.float() - yt_ref.float()).abs().max().item()}"
+    report("stats", st, st_ref, 1e-5, 1e-5 * max(1.0, st_ref.abs().max().item()))
+    # inference epilogue
+    oss = torch.stack([1 + 0.3 * torch.randn(c1, generator=g_), 0.3 * torch.randn(c1, generator=g_)], 1).to(gpu)
+    for act in (0, 1):
+        yi = ops.stem_fwd(xcl, ws, wt, out_ss=oss, out_act=act)
+        yi_ref = ops.dwt_fwd(ys, wt, out_ss=oss, out_act=act)
+        torch.cuda.synchronize()
+        assert torch.equal(yi, yi_ref), f"fused stem inference epilogue (act {act}) differs"
+    # backward: unmasked gradient + mask inside, as the train plan runs it
+    g, gd = rnd(tuple(yt.shape), dtype, g_)
+    coef = (torch.randn((c1, 4), generator=g_) * 0.5).to(gpu)
+    rss = torch.stack([1 + 0.3 * torch.randn(c1, generator=g_), 0.3 * torch.randn(c1, generator=g_)], 1).to(gpu)
+    gg = g.to(gpu)
+    for relu_ss in (None, rss):
+        ds = torch.empty_like(ys)
+        dwt_ref = torch.zeros((c1, 5), dtype=torch.float32, device=gpu)
+        dws_ref = torch.zeros((c1, 3, 3, 3), dtype=torch.float32, device=gpu)
+        ops.dwt_bwd(gg, yt, coef, ys, wt, ds, dwt_ref, relu_ss=relu_ss)
+        ops.stem_s_wgrad(xcl, ds, dws_ref, channels_last=True)
+        dwt = torch.full((c1, 5), 0.5, dtype=torch.float32, device=gpu)          # += on what is there
+        dws = torch.full((c1, 3, 3, 3), -0.25, dtype=torch.float32, device=gpu)
+        ops.stem_bwd(gg, yt, coef, xcl, ws, wt, dws, dwt, relu_ss=relu_ss)
+        torch.cuda.synchronize()
+        report("dw_t vs two kernels", dwt - 0.5, dwt_ref, 2e-5, 2e-5 * dwt_ref.abs().max().item())
+        report("dw_s vs two kernels", dws + 0.25, dws_ref, 2e-5, 2e-5 * dws_ref.abs().max().item())
+    # fp64 autograd over the stored tensors (mask inside): dY -> conv_t^T -> ds rounded to storage -> conv_s weight gradient
+    ysd, ytd = ys.float().cpu().double(), yt.float().cpu().double()
+    cf, rs_ = coef.cpu().double(), rss.cpu().double()
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    gm = torch.where(v(rs_[:, 0]) * ytd + v(rs_[:, 1]) > 0, gd, torch.zeros_like(gd))
+    dY = v(cf[:, 0]) * gm + v(cf[:, 1]) * ytd + v(cf[:, 2])
+    xs = ysd.clone().requires_grad_(True)
+    wtr = wt.cpu().double().requires_grad_(True)
+    out = F.conv3d(F.pad(xs, (0, 0, 0, 0, 2, 2)), wtr.view(-1, 1, 5, 1, 1), groups=c1)
+    dxs, dwt64 = torch.autograd.grad((out * dY).sum(), [xs, wtr])
+    report("dw_t vs fp64", dwt - 0.5, dwt64, 2e-4, 2e-4 * dwt64.abs().max().item())
+    wsr = ws.cpu().double().requires_grad_(True)
+    out_s = F.conv3d(F.pad(xd, (1, 1, 1, 1, 0, 0)), wsr.unsqueeze(2), stride=(1, 2, 2))
+    (dws64,) = torch.autograd.grad((out_s * round_to(dxs.float(), dtype)).sum(), [wsr])
+    report("dw_s vs fp64", dws + 0.25, dws64, 2e-4, 2e-4 * dws64.abs().max().item())
+
+
+def test_stem_fused_unsupported(gpu):
+    """fp32 storage, a planar batch, W % 8 != 0 and KT != 5 stay on the two-kernel path: the fused entry points refuse them."""
+    from x3d_tf_amd import hip
+    lib = hip.load()
+    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 1) == 1
+    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.float32), 1) == 0
+    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 0) == 0
+    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 20, hip.dtype_code(torch.bfloat16), 1) == 0
+    assert lib.x3d_stem_fused_supported(3, 24, 3, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 1) == 0
+    assert lib.x3d_stem_fused_supported(3, 40, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 1) == 0
+    ops = _ops()
+    x = torch.randn(1, 2, 8, 16, 3, device=gpu)
+    with pytest.raises(hip.X3DHipError):
+        ops.stem_fwd(x, torch.randn(24, 3, 3, 3, device=gpu), torch.randn(24, 5, device=gpu))
+
+
 @pytest.mark.parametrize("dtype", S.HALF_DTYPES)
 @pytest.mark.parametrize("n,c,P,conv", [(23, 5, (16, 7, 7), True), (23, 3, (16, 7, 7), False), (64, 2, (16, 7, 7), True),
                                         (7, 4, (4, 5, 10), True), (33, 2, (2, 8, 8), False)])

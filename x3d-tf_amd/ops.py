@@ -114,6 +114,37 @@ def dwt_bwd(g, yraw, coef, x, w, dx, dw, relu_ss=None):
              h * ww, w.shape[1], hip.dtype_code(x.dtype))
 
 
+def stem_fused_supported(x, cout, kt=5):
+    """x: the channels-last clip batch [N, T, H, W, Cin] (x3d_stem_fused_supported)."""
+    n, t, h, ww, cin = x.shape
+    code = hip.dtype_code(x.dtype)
+    return bool(hip.load().x3d_stem_fused_supported(cin, cout, kt, n, t, h, ww, code, 1))
+
+
+def stem_fwd(x, w_s, w_t, y=None, stats=None, out_ss=None, out_act=ACT_NONE):
+    """conv_s -> conv_t in one launch (x3d_stem_fwd): x is the channels-last clip batch [N, T, H, W, 3]; the conv_s output
+    never reaches HBM.  stats / out_ss / out_act as in dwt_fwd."""
+    _chk(x, w_s, w_t, y, stats, out_ss)
+    n, t, h, ww, cin = x.shape
+    cout = w_s.shape[0]
+    ho, wo = (h - 1) // 2 + 1, (ww - 1) // 2 + 1
+    if y is None:
+        y = torch.empty((n, cout, t, ho, wo), dtype=x.dtype, device=x.device)
+    st = _Stats(stats, cout)
+    hip.call("x3d_stem_fwd", ptr(x), ptr(w_s), ptr(w_t), ptr(y), ptr(st.arg()), ptr(out_ss), out_act, n, cin, t, h, ww, cout,
+             w_t.shape[1], hip.dtype_code(x.dtype), 1)
+    st.done()
+    return y
+
+
+def stem_bwd(g, yraw, coef, x, w_s, w_t, dw_s, dw_t, relu_ss=None):
+    """Backward of the fused stem (x3d_stem_bwd): dw_s, dw_t += ; the conv_s output is recomputed, its gradient stays on chip."""
+    _chk(g, yraw, coef, x, w_s, w_t, dw_s, dw_t, relu_ss)
+    n, t, h, ww, cin = x.shape
+    hip.call("x3d_stem_bwd", ptr(g), ptr(yraw), ptr(relu_ss), ptr(coef), ptr(x), ptr(w_s), ptr(w_t), ptr(dw_s), ptr(dw_t),
+             n, cin, t, h, ww, w_s.shape[0], w_t.shape[1], hip.dtype_code(x.dtype), 1)
+
+
 # ---- batch norm ---------------------------------------------------------------------------------
 def bn_finalize(stats, count, gamma, beta, mmean, mvar, eps, momentum, update, ss, mi):
     _chk(stats, gamma, beta, mmean, mvar, ss, mi)
