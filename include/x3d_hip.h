@@ -97,8 +97,10 @@ int x3d_dwt_bwd(const void* g, const void* yraw, const float* relu_scale_shift, 
  *   x3d_stem_bwd: g (grad wrt relu(bn(y)), masked here when relu_scale_shift != NULL), yraw (= y of the forward), coef as in
  *     x3d_dwt_bwd; dw_t [Cout][KT] += , dw_s [Cout][3][3][3] += .  The conv_s output is recomputed on the matrix cores, the
  *     conv_t input gradient stays in LDS as the operand of the conv_s weight-gradient tile.
- *   Supported (x3d_stem_fused_supported != 0): 16-bit storage, x_layout = X3D_LAYOUT_NTHWC, Cin = 3, W % 8 == 0, Cout <= 32,
- *     KT = 5, y under 2 GB; x 16-byte aligned.  Everything else runs the separate K1 / K2 entry points above.
+ *   x3d_stem_fused_supported: bit 0 = x3d_stem_fwd takes the shape (16-bit storage, x_layout = X3D_LAYOUT_NTHWC, Cin = 3,
+ *     W % 8 == 0, Cout <= 32, KT = 5, x and y under 2 GB; x 16-byte aligned), bit 1 = x3d_stem_bwd takes it and is the faster
+ *     backward (Cout <= 24; it runs, slower than K2 + K1's backward, up to 32).  Everything else runs the separate K1 / K2 entry
+ *     points above.
  * ------------------------------------------------------------------------------------------ */
 int x3d_stem_fused_supported(int Cin, int Cout, int KT, int N, int T, int H, int W, int dtype, int x_layout);
 int x3d_stem_fwd(const void* x, const float* w_s, const float* w_t, void* y, double* stats, const float* out_scale_shift,

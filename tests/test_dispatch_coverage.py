@@ -121,14 +121,18 @@ def test_inference_plan_is_inference_shaped(index):
     names = [item[0] for item in pl.fwd]
     assert names[0] == "x3d_bn_eval_coef_batched" and names.count("x3d_bn_eval_coef_batched") == 1
     assert not [k for k in names if k.startswith(("x3d_tail", "x3d_bn_finalize"))]
-    assert names[1:3] == ["x3d_stem_s_fwd", "x3d_dwt_fwd"]
+    # the stem: one launch (conv_s -> conv_t -> BN + ReLU, x3d_stem_fwd) with 16-bit storage, the two-kernel path in fp32
+    assert pl.stem_fused == (dtype != torch.float32)
+    stem = ["x3d_stem_fwd"] if pl.stem_fused else ["x3d_stem_s_fwd", "x3d_dwt_fwd"]
+    k0 = 1 + len(stem)
+    assert names[1:k0] == stem
     blocks = m.arch.blocks
     want = []
     for b in blocks:
         want += ["x3d_pw_fwd", "x3d_dw3d_fwd"] + (["x3d_se_fwd"] if b.has_se else []) + \
                 (["x3d_pw_fwd"] if b.has_shortcut_conv else []) + ["x3d_pw_fwd"]
-    assert names[3:3 + len(want)] == want
-    assert names[3 + len(want):] == ["x3d_pw_fwd", "x3d_pool_fwd", "x3d_dense_fwd", "x3d_dense_fwd", "x3d_softmax_xent", "x3d_view_mean"]
+    assert names[k0:k0 + len(want)] == want
+    assert names[k0 + len(want):] == ["x3d_pw_fwd", "x3d_pool_fwd", "x3d_dense_fwd", "x3d_dense_fwd", "x3d_softmax_xent", "x3d_view_mean"]
     assert len(want) <= 5 * len(blocks) and sum(3 + b.has_se + b.has_shortcut_conv for b in blocks) == len(want)
     for B in pl.blocks:                      # the `c` conv carries the epilogue; `a` and the shortcut stay raw
         assert B.sc.out_scale_shift and B.sc.out_add and B.sc.out_act == 1 and not B.sc.stats

@@ -1000,7 +1000,7 @@ def test_stem(gpu, dtype, shape):
             ops.stem_s_fwd(x.to(gpu).permute(0, 2, 3, 4, 1).contiguous(), ws.to(gpu), channels_last=True)
 
 
-STEM_FUSED = [(2, 4, 16, 16, 24), (1, 16, 12, 224, 24),     # two segments per row (64 + 48 columns), T = 16: three ring turns
+STEM_FUSED = [(2, 4, 16, 16, 24), (1, 16, 12, 224, 24), (1, 2, 10, 312, 24),     # two segments per row (64 + 48 columns), T = 16: three ring turns
               (3, 5, 10, 72, 24),                           # 15 segments: the last group is three segments, Wo = 36 of 64 columns
               (1, 7, 6, 312, 32), (2, 3, 5, 160, 32),       # X3D-XL: 32 channels (four rows per wave), Wo % 8 == 4, odd H
               (1, 1, 8, 24, 24), (2, 2, 9, 32, 8),          # T < KT; Cout = 8 (rows 8.. of every wave idle)
@@ -1020,7 +1020,7 @@ def test_stem_fused(gpu, dtype, shape):
     ws = (torch.randn((c1, 3, 3, 3), generator=g_) * 0.3).to(gpu)
     wt = (torch.randn((c1, 5), generator=g_) * 0.4).to(gpu)
     xcl = x.to(gpu).permute(0, 2, 3, 4, 1).contiguous()
-    assert ops.stem_fused_supported(xcl, c1)
+    assert ops.stem_fused_supported(xcl, c1) == (3 if c1 <= 24 else 1)     # (the backward kernel runs with 32 channels too: checked below)
     ys = ops.stem_s_fwd(xcl, ws, channels_last=True)
     st_ref = torch.zeros((c1, 2), dtype=torch.float64, device=gpu)
     yt_ref = ops.dwt_fwd(ys, wt, stats=st_ref)
@@ -1074,7 +1074,8 @@ def test_stem_fused_unsupported(gpu):
     """fp32 storage, a planar batch, W % 8 != 0 and KT != 5 stay on the two-kernel path: the fused entry points refuse them."""
     from x3d_tf_amd import hip
     lib = hip.load()
-    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 1) == 1
+    assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 1) == 3
+    assert lib.x3d_stem_fused_supported(3, 32, 5, 2, 4, 16, 16, hip.dtype_code(torch.float16), 1) == 1      # forward only
     assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.float32), 1) == 0
     assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 16, hip.dtype_code(torch.bfloat16), 0) == 0
     assert lib.x3d_stem_fused_supported(3, 24, 5, 2, 4, 16, 20, hip.dtype_code(torch.bfloat16), 1) == 0

@@ -307,7 +307,11 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
     # lands between 4.6e-2 and 6.0e-2 depending on the input alone (5.4 / 4.7 / 5.7 / 4.9 / 5.2 / 5.4e-2 before the 48 -> 216
     # layer took the recomputed-output backward, 5.7 / 4.7 / 6.0 / 4.9 / 5.2 / 5.4e-2 after: only the stage-2 tensor downstream
     # of it moves, by 3e-3) -- the bf16 limit below is that spread plus 10 %, not a margin for a kernel error of that size.
-    lim, lim_se, med = (6.5e-2, 8e-2, 1.5e-2) if dtype == torch.bfloat16 else (8e-3, 1.2e-2, 2.5e-3)
+    # Round 6 (profiles/r06_seed_sweep.log: seeds 2 .. 7, recomputed-output backward on and off, at HEAD -- the fp16 depthwise
+    # backward on the matrix cores too, 14 blocks, which the round-5 log predated): worst general tensor 6.0e-2 bf16 (a bn_a
+    # gamma, seed 4) / 7.2e-3 fp16 (seed 6), worst SE bias 6.3e-2 / below the general worst.  Limits = that spread plus 25 %:
+    # the old bf16 limit (6.5e-2) sat 0.3 % above one seed's value.
+    lim, lim_se, med = (7.5e-2, 8e-2, 1.5e-2) if dtype == torch.bfloat16 else (9e-3, 1.2e-2, 2.5e-3)
     bad = {k: e for k, e in errs.items() if e > (lim_se if k.endswith(("/se_fc1/bias", "/se_fc2/bias")) else lim)}
     assert not bad, f"relative L2 error beyond {lim} ({lim_se} for the SE biases) (teacher-forced, {dtype}): {bad}"
     assert sorted(errs.values())[len(errs) // 2] < med        # median
@@ -326,7 +330,12 @@ def test_train_step_half_block_by_block(gpu, name, n, t, s, dtype):
 # With perturbed weights (the second round) the stage-2 SE gradients cancel further: X3D-L block 0 se_fc1 bias 1.7e-1, kernel
 # 3.6e-2 -- d(loss)/d(pooled) of an SE branch is a sum over 54 channels whose terms cancel to ~1e-3; the limit of that class is
 # set from it and guards against nothing but an O(1) error there.
-RC_DIFF_LIMITS = {torch.bfloat16: (2e-5, 3e-2, 6e-2, 2.5e-1), torch.float16: (2e-5, 5e-3, 8e-3, 3e-2)}
+# Round 6: the limits are the spread of a SEED SWEEP (tools/rc_diff_sweep.py, seeds 2 .. 7, both shapes, both rounds:
+# profiles/r06_rc_diff_sweep.log) plus 25 %, no longer one seed's value plus headroom -- the worst tensor of a class is a
+# heavy-tailed sample of the operand rounding (another forward state, e.g. another summation order of the stem's batch
+# statistics, draws another): bf16 general 3.9e-2 / gammas 6.9e-2 / SE class 1.7e-1, fp16 4.3e-3 / 9.8e-3 / 7.1e-3.  Fifth entry:
+# d(loss)/d(pooled) of the SE blocks (1.8e-1 / 5.7e-2: see one_round).
+RC_DIFF_LIMITS = {torch.bfloat16: (2e-5, 5e-2, 8.5e-2, 2.5e-1, 2.5e-1), torch.float16: (2e-5, 5.5e-3, 1.25e-2, 3e-2, 8e-2)}
 
 
 @pytest.mark.parametrize("dtype", S.HALF_DTYPES)
@@ -384,16 +393,49 @@ def test_recomputed_output_backward_against_the_stored_output_backward(gpu, name
         hip.call("x3d_softmax_xent", pl.logits.data_ptr(), pl.labels.data_ptr(), pl.probs.data_ptr(),
                  pl.loss_rows.data_ptr(), pl.dlogits.data_ptr(), ls / n, n, arch.num_classes)
         snap = pl.zero_buf.clone()
-        out = []
-        for runner in (lambda: pl.run(pl.bwd), alt.run, lambda: pl.run(pl.bwd)):
+        out, dpool = [], []
+        se_blocks = [B for B in reversed(pl.blocks) if B.spec.has_se]
+
+        def run_split(lst, scratch):
+            """the list in pieces that end behind each x3d_se_bnb_bwd launch: d(loss)/d(pooled) of every SE block, [N][inner],
+            as that launch leaves it at the head of its scratch (x3d_hip.h, x3d_se_bnb_bwd_args.scratch) -- the vector BEFORE
+            the SE layers project it onto sums that cancel"""
+            idx = [i for i, item in enumerate(lst) if item[0] == "x3d_se_bnb_bwd"]      # one per block (BN_b backward; SE or not)
+            assert len(idx) == len(pl.blocks), (len(idx), len(pl.blocks))
+            got, start = [], 0
+            for i, B in zip(idx, reversed(pl.blocks)):
+                if not B.spec.has_se:
+                    continue
+                pl.run(lst, start, i + 1)
+                torch.cuda.synchronize()
+                got.append(scratch[:n * B.spec.inner].double().cpu().clone())
+                start = i + 1
+            pl.run(lst, start)
+            return got
+
+        def run_alt():
+            alt.extra.zero_()
+            return run_split(alt.lst, alt.owned[5])         # (owned: the alternate list's scratch buffers, se_scratch sixth)
+
+        for runner in (lambda: run_split(pl.bwd, pl.se_scratch), run_alt, lambda: run_split(pl.bwd, pl.se_scratch)):
             pl.zero_buf.copy_(snap)
             m.flat_grads.zero_()
-            runner()
+            dpool.append(runner())
             torch.cuda.synchronize()
             assert torch.isfinite(m.flat_grads).all()
             out.append({k: g.detach().double().cpu().clone() for k, g in m.grads.items()})
         g1, g0, g1b = out
-        lim_same, lim, lim_g, lim_se = RC_DIFF_LIMITS[dtype]
+        lim_same, lim, lim_g, lim_se, lim_dp = RC_DIFF_LIMITS[dtype]
+        # d(loss)/d(pooled) of every SE block, the vector the SE layers project (round 6; asked for as the "pre-cancellation"
+        # quantity of the SE class).  Measured (profiles/r06_rc_diff_sweep.log, seeds 2 .. 7): it is ITSELF a cancelling sum --
+        # over the 50 K .. 200 K points of a plane, of swish-backward terms of either sign -- and sits at 1.3e-2 .. 1.8e-1 in bf16
+        # (worst: X3D-L stage-2 blocks) and up to 5.7e-2 even in fp16, i.e. in the class of the projections or beyond it, not at
+        # the 3e-2 of a general tensor.  Bounded as its own class (an O(1) error there fails); the tensor-level statements are
+        # test_pw_bwd_rc (2e-2 of the maximum per layer) and the full-size checks.
+        dp_err = [((a - b).norm() / (b.norm() + 1e-30)).item() for a, b in zip(dpool[0], dpool[1])]
+        dp_same = [((a - b).norm() / (b.norm() + 1e-30)).item() for a, b in zip(dpool[0], dpool[2])]
+        print(f"rc differential {tag}: d(loss)/d(pooled) of the {len(se_blocks)} SE blocks, worst rc vs stored {max(dp_err):.2e}, rc vs rc again {max(dp_same):.1e}")
+        assert max(dp_err) <= lim_dp and max(dp_same) <= 50 * lim_same, (dp_err, dp_same)
         errs = {}
         for B in pl.blocks + [None]:
             ks = [k for k in g1 if (k.startswith(block_prefix(B.spec) + "/") if B is not None else not k.startswith("stages/"))]
@@ -403,12 +445,13 @@ def test_recomputed_output_backward_against_the_stored_output_backward(gpu, name
                 den = max(g0[k].norm().item(), floor_rms * g0[k].numel() ** 0.5) + 1e-30
                 errs[k] = ((g1[k] - g0[k]).norm().item() / den, (g1[k] - g1b[k]).norm().item() / den)
         worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:4]
-        print(f"rc differential {tag}:", name, dtype, "worst (rc vs stored, rc vs rc again):", worst,
-              "out of reach:", sum(1 for v in reach.values() if not v), "of", len(reach))
+        cls = lambda k: ("se" if k.endswith(("/se_fc1/bias", "/se_fc2/bias", "/se_fc1/kernel")) else ("gamma" if k.endswith("/gamma") else "general"))
+        by_class = {c: max([e for k, (e, _) in errs.items() if reach[k] and cls(k) == c] + [0.0]) for c in ("general", "gamma", "se")}
+        print(f"rc differential {tag}:", name, dtype, "worst per class", {c: f"{v:.2e}" for c, v in by_class.items()},
+              "worst (rc vs stored, rc vs rc again):", worst, "out of reach:", sum(1 for v in reach.values() if not v), "of", len(reach))
         bad = {}
         for k, (e, e_same) in errs.items():
-            limit = lim_same if not reach[k] else (lim_se if k.endswith(("/se_fc1/bias", "/se_fc2/bias", "/se_fc1/kernel")) else
-                                                   (lim_g if k.endswith("/gamma") else lim))
+            limit = lim_same if not reach[k] else {"se": lim_se, "gamma": lim_g, "general": lim}[cls(k)]
             if e > limit or e_same > lim_same * (1 if not reach[k] else 50):
                 bad[k] = (e, e_same, limit)
         assert not bad, f"{tag}: recomputed-output backward vs stored-output backward beyond the limits: {bad}"

@@ -19,9 +19,9 @@
 //     dwt_bwd_kernel) both ds[t] = sum_k w[k] dY[t+2-k] and dW_t[k] += dY[t+2-k] . s[t] need nothing older; ds[t],
 //     rounded to the storage type as the stored ds was, is the A operand of the conv_s weight-gradient tile
 //     dW_s[co][tap] += ds[t] x im2col[t]^T (K = the 256 points, 32 per wave) -- the im2col tile already in LDS.
-// The ring / window slots and the two register buffers of the prefetched planes (distance 2) are compile-time: six slots,
+// The ring / window slots and the register buffers of the prefetched planes (distance 2) are compile-time: six slots,
 // the time loop unrolled by six (one instantiation per phase).  One workgroup per CU; both LDS images exist twice (plane
-// parity), which leaves two barriers per plane.
+// parity): two barriers per plane in the backward kernel, one in the forward kernel (whose three stages run skewed by a plane).
 // LDS images: the im2col tile is read transposed (ds_read_b64_tr_b16, pitch = 64 banks mod 256 B: conflict-free) AND as
 // k-contiguous 16-byte rows (dW_s); 16-byte chunks are XOR-swizzled with (tap >> 2) & 3, which is uniform over the lane
 // group of a transposed read and distinct over the four row quads of a 16-byte read group.
@@ -98,14 +98,14 @@ struct SfStage {
       if (v == 0 && wo0 > 0) loff = boff - 8;
     }
   }
+  // (the plane offset -- or SF_OOB for a plane past T -- is wave-uniform: the scalar offset operand.  SF_OOB + SF_OOB < 2^32: a
+  // lane without a vector stays out of range whatever the scalar part is)
   __device__ __forceinline__ void issue(SfXBuf<HT>& b, __amdgpu_buffer_rsrc_t rx, int t, int Tn, int plane3_bytes) const {
-    const bool in = t < Tn;
-    const int o = (in && boff != SF_OOB) ? boff + t * plane3_bytes : SF_OOB;
-    const int lo = (in && loff != SF_OOB) ? loff + t * plane3_bytes : SF_OOB;
-    b.r[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0);
-    b.r[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 16, 0);
-    b.r[2] = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 32, 0);
-    b.l = __builtin_amdgcn_raw_buffer_load_b64(rx, lo, 0, 0);
+    const int so = t < Tn ? t * plane3_bytes : SF_OOB;
+    b.r[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, boff, so, 0);
+    b.r[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, boff + 16, so, 0);
+    b.r[2] = __builtin_amdgcn_raw_buffer_load_b128(rx, boff + 32, so, 0);
+    b.l = __builtin_amdgcn_raw_buffer_load_b64(rx, loff, so, 0);
   }
   static __device__ __forceinline__ HT at(const SfXBuf<HT>& b, int i) {
     const unsigned int wd = b.r[i >> 3][(i & 7) >> 1];
@@ -194,16 +194,18 @@ constexpr int SF_RING = 6;          // ring / window slots: five live planes + o
                                     // both compile-time inside a time loop unrolled by six (prefetch distance 2 divides 6, 5 would need 10)
 
 // ------------------------------------------------------------------------------------------------
-// forward
+// forward.  ONE barrier per plane: tick k commits the im2col tile of plane k, runs conv_s of plane k - 1 (tile committed one
+// tick earlier) and the time-domain step of plane k - 2 (slab written one tick earlier) -- three independent instruction
+// streams per wave between two barriers; both LDS images exist twice (plane parity).
+// INFER: y = out_act(os * conv + ot), the stem's BatchNorm from the moving statistics + ReLU (no statistics).
 // ------------------------------------------------------------------------------------------------
-template <typename HT, int NR>
+template <typename HT, int NR, bool INFER>
 __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __restrict__ x, const float* __restrict__ ws,
                                                                     const float* __restrict__ wt, HT* __restrict__ y,
                                                                     double* stats, const float* __restrict__ oss, int oact,
                                                                     int Cout, int Tn, int H, int W, int Ho, int Wo, int nws,
                                                                     int total_segs, int ngroups, int groups_per_block) {
   typedef typename HV<HT>::x8 hx8; typedef typename HV<HT>::x4 hx4;
-  // both LDS images twice: plane u + 1 is committed while the slab of plane u - 1 may still be read -- two barriers per plane
   __shared__ __attribute__((aligned(16))) HT Bs2[2][32 * SF_LP];
   __shared__ __attribute__((aligned(16))) HT Ss2[2][32 * SF_SP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __
     const bool ok = row < Cout;
 #pragma unroll
     for (int k = 0; k < SF_KT; k++) wk[i][k] = ok ? wt[row * SF_KT + k] : 0.f;
-    os[i] = (oss && ok) ? oss[row * 2] : 1.f;
-    ot[i] = (oss && ok) ? oss[row * 2 + 1] : 0.f;
+    os[i] = (INFER && ok) ? oss[row * 2] : 1.f;
+    ot[i] = (INFER && ok) ? oss[row * 2 + 1] : 0.f;
   }
-  const float olo = (oss && oact == X3D_ACT_RELU) ? 0.f : -__builtin_inff();
+  const float olo = (INFER && oact == X3D_ACT_RELU) ? 0.f : -__builtin_inff();
   const int plane3 = H * W * 3 * 2;           // bytes of one input plane
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((HT*)x, 0, (int)((long long)(total_segs / (Ho * nws)) * Tn * plane3), 0x00020000);
   const int plane_bytes = Ho * Wo * 2;
@@ -253,74 +255,88 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __
     st.issue(xb[0], rx, 0, Tn, plane3);
     st.issue(xb[1], rx, 1, Tn, plane3);
 
-    auto iter = [&](auto ph, int u) {
-      constexpr int PH = decltype(ph)::value;      // u % 6
-      {                                             // (u >= Tn: the drain steps run on zero planes -- straight-line code, see below)
-        HT* Bs = Bs2[PH & 1];
-        HT* Ss = Ss2[PH & 1];
-        st.commit(xb[PH & 1], Bs);                  // (its last readers: conv_s of plane u - 2, two barriers back)
-        st.issue(xb[PH & 1], rx, u + 2, Tn, plane3);
-        __syncthreads();
-        sf_conv_s<HT>(Bs, Ss, wfrag, w, lane);
-        __syncthreads();
+    // tick k (PH = k % 6).  Planes past T are zeros (bounds-checked loads): their terms vanish, their stores are dropped.
+    auto tick = [&](auto ph, int k, auto do_conv, auto do_time) {
+      constexpr int PH = decltype(ph)::value;
+      st.commit(xb[PH & 1], Bs2[PH & 1]);           // plane k  (last readers of this image: conv_s of plane k - 2, last tick)
+      st.issue(xb[PH & 1], rx, k + 2, Tn, plane3);
+      if constexpr (decltype(do_conv)::value)       // plane k - 1
+        sf_conv_s<HT>(Bs2[(PH + 1) & 1], Ss2[(PH + 1) & 1], wfrag, w, lane);
+      if constexpr (decltype(do_time)::value) {     // plane j = k - 2: s[j] into the ring, plane j - 2 out
+        constexpr int PJ = (PH + 4) % SF_RING;
+        const HT* Ss = Ss2[PH & 1];
+        const int tau = k - 4;
+        const bool t_ok = tau >= 0 && tau < Tn;
 #pragma unroll
         for (int i = 0; i < NR; i++) {
           const hx4 sv = *(const hx4*)&Ss[(i * 8 + w) * SF_SP + 4 * lane];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float s = (float)sv[e];
-            // out[u + 2 - k] += w[k] s[u]; k = 0 opens the slot of plane u + 2
-            ring[(PH + 2) % SF_RING][i][e] = wk[i][0] * s;
+            // out[j + 2 - kk] += w[kk] s[j]; kk = 0 opens the slot of plane j + 2  (products and order of dwt_fwd_kernel)
+            ring[(PJ + 2) % SF_RING][i][e] = wk[i][0] * s;
 #pragma unroll
-            for (int k = 1; k < SF_KT; k++)
-              ring[(PH + 2 - k + SF_RING) % SF_RING][i][e] = __builtin_fmaf(wk[i][k], s, ring[(PH + 2 - k + SF_RING) % SF_RING][i][e]);
+            for (int kk = 1; kk < SF_KT; kk++)
+              ring[(PJ + 2 - kk + SF_RING) % SF_RING][i][e] = __builtin_fmaf(wk[i][kk], s, ring[(PJ + 2 - kk + SF_RING) % SF_RING][i][e]);
           }
-        }
-      }
-      const int tau = u - 2;                         // complete: its last term was s[u]  (tau < 0: zeros, store dropped)
-      {
-#pragma unroll
-        for (int i = 0; i < NR; i++) {
-          // (a column past Wo holds the row's last pixel in its kw = 0 taps: not a sum term)
-          const bool live = off0 != SF_OOB && i * 8 + w < Cout && tau >= 0 && tau < Tn;
+          // plane j - 2 is complete: its last term was s[j]
+          // (live: a column past Wo holds the row's last pixel in its kw = 0 taps -- stored nowhere, not a sum term)
+          const bool live = off0 != SF_OOB && i * 8 + w < Cout && t_ok;
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            float a = ring[(PH + SF_RING - 2) % SF_RING][i][e];
-            if (oss) a = fmaxf(os[i] * a + ot[i], olo);
-            o[e] = a;
-            const float vr = live ? round_to<HT>(a) : 0.f;
-            red[i][0] += vr;
-            red[i][1] += vr * vr;
+            o[e] = ring[(PJ + SF_RING - 2) % SF_RING][i][e];
+            // (the fp32 sum as dwt_fwd_kernel rounds it: without this the last fma and the fp16 conversion fuse into one
+            // v_fma_mixlo_f16 -- a single rounding, 1 ulp away from the two-kernel path on ~1e-4 of the elements)
+            asm volatile("" : "+v"(o[e]));
+            if constexpr (INFER) o[e] = fmaxf(os[i] * o[e] + ot[i], olo);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(sf_pack<HT>(o), ry, live ? off0 + ((i * 8 + w) * Tn + tau) * plane_bytes : SF_OOB, 0, 0);
-        }
-      }
-    };
-    // Tn + 2 steps rounded up to whole turns of the ring, NO guard between the phases: a guarded chain compiles to a dispatch
-    // block every phase returns to, where the wait-count pass merges all their states and drains vmcnt at every commit
-    const int steps = (Tn + 2 + SF_RING - 1) / SF_RING * SF_RING;
-    for (int u0 = 0; u0 < steps; u0 += SF_RING) {
-      iter(Phase<0>{}, u0);
-      iter(Phase<1>{}, u0 + 1);
-      iter(Phase<2>{}, u0 + 2);
-      iter(Phase<3>{}, u0 + 3);
-      iter(Phase<4>{}, u0 + 4);
-      iter(Phase<5>{}, u0 + 5);
-    }
-    if (stats) {
-      double* sp = stats_replica(stats, Cout, (unsigned)gi);
+          hx4 h;
 #pragma unroll
-      for (int i = 0; i < NR; i++) {
-        const float s0 = wave_sum(red[i][0]), s1 = wave_sum(red[i][1]);
-        const int row = i * 8 + w;
-        if (lane == 0 && row < Cout) {
-          atomic_add_d(&sp[row * 2], (double)s0);
-          atomic_add_d(&sp[row * 2 + 1], (double)s1);
+          for (int e = 0; e < 4; e++) h[e] = (HT)o[e];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sf_u32x2, h), ry, off0,
+                                                (i * 8 + w < Cout && t_ok) ? ((i * 8 + w) * Tn + tau) * plane_bytes : SF_OOB, 0);
+          if constexpr (!INFER) {   // BatchNorm sums of the tensor as stored
+            const float v0 = (float)h[0], v1 = (float)h[1], v2 = (float)h[2], v3 = (float)h[3];
+            const float s1 = (v0 + v1) + (v2 + v3);
+            const float s2 = __builtin_fmaf(v3, v3, __builtin_fmaf(v2, v2, __builtin_fmaf(v1, v1, v0 * v0)));
+            red[i][0] += live ? s1 : 0.f;
+            red[i][1] += live ? s2 : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+    };
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    tick(Phase<0>{}, 0, no, no);
+    tick(Phase<1>{}, 1, yes, no);
+    // the last plane leaves at tick Tn + 3: Tn + 2 more ticks, rounded up to whole turns of the ring -- NO guard between the
+    // phases (a guarded chain compiles to a dispatch block every phase returns to, where the wait-count pass merges all their
+    // states and drains vmcnt in front of every commit)
+    const int turns = (Tn + 2 + SF_RING - 1) / SF_RING;
+    for (int r = 0, k0 = 2; r < turns; r++, k0 += SF_RING) {
+      tick(Phase<2>{}, k0, yes, yes);
+      tick(Phase<3>{}, k0 + 1, yes, yes);
+      tick(Phase<4>{}, k0 + 2, yes, yes);
+      tick(Phase<5>{}, k0 + 3, yes, yes);
+      tick(Phase<0>{}, k0 + 4, yes, yes);
+      tick(Phase<1>{}, k0 + 5, yes, yes);
+    }
+    if constexpr (!INFER) {
+      if (stats) {
+        double* sp = stats_replica(stats, Cout, (unsigned)gi);
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+          const float s0 = wave_sum(red[i][0]), s1 = wave_sum(red[i][1]);
+          const int row = i * 8 + w;
+          if (lane == 0 && row < Cout) {
+            atomic_add_d(&sp[row * 2], (double)s0);
+            atomic_add_d(&sp[row * 2 + 1], (double)s1);
+          }
         }
       }
     }
-    __syncthreads();     // the next group's first planes reuse the images of this group's last two
   }
 }
 
@@ -411,9 +427,9 @@ __global__ __launch_bounds__(SF_THREADS) void stem_bwd_fused_kernel(const HT* __
       }
     };
     auto load_plane = [&](int b, int i, int t) {
-      const int o = (off0 != SF_OOB && i * 8 + w < Cout && t < Tn) ? off0 + ((i * 8 + w) * Tn + t) * plane_bytes : SF_OOB;
-      bg[b][i] = __builtin_amdgcn_raw_buffer_load_b64(rg, o, 0, 0);
-      by[b][i] = __builtin_amdgcn_raw_buffer_load_b64(ry, o, 0, 0);
+      const int so = (i * 8 + w < Cout && t < Tn) ? ((i * 8 + w) * Tn + t) * plane_bytes : SF_OOB;   // wave-uniform: scalar operand
+      bg[b][i] = __builtin_amdgcn_raw_buffer_load_b64(rg, off0, so, 0);
+      by[b][i] = __builtin_amdgcn_raw_buffer_load_b64(ry, off0, so, 0);
     };
     // g and yraw run two planes ahead of x: dY[0], dY[1] enter the window here, planes 2 and 3 are in flight when the loop starts
 #pragma unroll
@@ -540,8 +556,13 @@ bool sf_shape_ok(int Cin, int Cout, int KT, int N, int T, int H, int W, int dtyp
 
 }  // namespace
 
+// bit 0: x3d_stem_fwd takes the shape; bit 1: x3d_stem_bwd takes it AND is the faster path.  With more than 24 channels (X3D-XL:
+// 32, four rows per wave) the backward kernel's window no longer fits 256 registers and spills inside the time loop: 715 us
+// against 493 us for x3d_dwt_bwd + x3d_stem_s_wgrad at 16 x 16 x 312^2 (profiles/r06_stem_bench.txt), so a training plan keeps
+// the two-kernel path there; the forward kernel (254 us against 367 us) serves inference.
 extern "C" int x3d_stem_fused_supported(int Cin, int Cout, int KT, int N, int T, int H, int W, int dtype, int x_layout) {
-  return sf_shape_ok(Cin, Cout, KT, N, T, H, W, dtype, x_layout) ? 1 : 0;
+  if (!sf_shape_ok(Cin, Cout, KT, N, T, H, W, dtype, x_layout)) return 0;
+  return Cout <= 24 ? 3 : 1;
 }
 
 extern "C" int x3d_stem_fwd(const void* x, const float* w_s, const float* w_t, void* y, double* stats,
@@ -560,10 +581,13 @@ extern "C" int x3d_stem_fwd(const void* x, const float* w_s, const float* w_t, v
   const int gpb = (int)ceil_div_ll(ngroups, sf_slots());
   const int grid = ceil_div(ngroups, gpb);
   hipStream_t st = (hipStream_t)stream;
-#define SF_FWD(TT, NR_) hipLaunchKernelGGL((stem_fwd_fused_kernel<TT, NR_>), dim3(grid), dim3(SF_THREADS), 0, st, (const TT*)x, w_s, w_t, \
-                                           (TT*)y, stats, out_scale_shift, out_act, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, ngroups, gpb)
-  if (dtype == X3D_F16) { if (Cout <= 24) SF_FWD(f16, 3); else SF_FWD(f16, 4); }
-  else { if (Cout <= 24) SF_FWD(bf16, 3); else SF_FWD(bf16, 4); }
+#define SF_FWD(TT, NR_, INF_) hipLaunchKernelGGL((stem_fwd_fused_kernel<TT, NR_, INF_>), dim3(grid), dim3(SF_THREADS), 0, st, (const TT*)x, w_s, \
+                                                 w_t, (TT*)y, stats, out_scale_shift, out_act, Cout, T, H, W, Ho, Wo, nws,              \
+                                                 (int)total_segs, ngroups, gpb)
+#define SF_FWD_NR(TT, INF_) do { if (Cout <= 24) SF_FWD(TT, 3, INF_); else SF_FWD(TT, 4, INF_); } while (0)
+  if (dtype == X3D_F16) { if (out_scale_shift) SF_FWD_NR(f16, true); else SF_FWD_NR(f16, false); }
+  else { if (out_scale_shift) SF_FWD_NR(bf16, true); else SF_FWD_NR(bf16, false); }
+#undef SF_FWD_NR
 #undef SF_FWD
   X3D_LAUNCH_CHECK("stem_fwd");
   return X3D_OK;

@@ -114,6 +114,7 @@ PLAN_DEFAULTS = {
     "pw_bwd_rc_merge": True,   # its prepare / finish jobs ride on the BatchNorm-backward finalize launches
     "pw_bwd_rc_wide": True,    # ... also for the 48 -> 216 layer
     "stem_nthwc": True,        # the stem reads the caller's channels-last batch in place (16-bit storage)
+    "stem_fused": True,        # ... and runs conv_s -> conv_t as ONE launch each way (x3d_stem_fwd / x3d_stem_bwd): no s_raw, no ds
     "infer_train_plan": False,  # training-shaped launch list at inference
     "bn_fold": False,          # BatchNorm finalize inside the depthwise / tail consumer (x3d_bn_fold)
     "tail_fwd_fold": True,     # residual tail built on load by the next block's `a` conv
@@ -128,7 +129,7 @@ PLAN_DEFAULTS = {
 _ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-default setting selects)
     "X3D_NO_FUSED_PW_BWD": ("fused_pw_bwd", "1", False), "X3D_PW_BWD_RC": ("pw_bwd_rc", "0", False),
     "X3D_PW_BWD_RC_MERGE": ("pw_bwd_rc_merge", "0", False), "X3D_PW_BWD_RC_WIDE": ("pw_bwd_rc_wide", "0", False),
-    "X3D_NO_STEM_NTHWC": ("stem_nthwc", "1", False), "X3D_INFER_TRAIN_PLAN": ("infer_train_plan", "1", True),
+    "X3D_NO_STEM_NTHWC": ("stem_nthwc", "1", False), "X3D_NO_STEM_FUSED": ("stem_fused", "1", False), "X3D_INFER_TRAIN_PLAN": ("infer_train_plan", "1", True),
     "X3D_BN_FOLD": ("bn_fold", "1", True), "X3D_NO_TAIL_FWD_FOLD": ("tail_fwd_fold", "1", False),
     "X3D_NO_TAIL_FOLD_WST": ("tail_fold_wst", "1", False), "X3D_NO_TAIL_FOLD": ("tail_bwd_fold", "1", False),
     "X3D_NO_STEM_BWD_FOLD": ("stem_bwd_fold", "1", False), "X3D_SIDE_WGRAD": ("side_wgrad", "1", True),
@@ -197,7 +198,7 @@ class _Plan:
         # CUs and HBM, so the default is one stream.
         self.side_on = training and model.opt["side_wgrad"]
         self.side_entries = set()      # (id(list), index) of launches that go to the side stream
-        self.input_slots = []          # (list, index) of the launches whose first argument is the input batch
+        self.input_slots = []          # (list, index[, argument position = 0]) of the launches that read the input batch
         self.x_cl = False              # those launches read the caller's channels-last batch in place (no planar copy)
         self.side = None               # torch.cuda.Stream, created with the first forked launch
         self._side_pending = False
@@ -633,13 +634,19 @@ class X3D:
         # 16-bit storage: the stem's matrix-core kernels read the caller's channels-last batch in place (x3d_hip.h K1)
         pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and self.opt["stem_nthwc"]
         pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
-        pl.s_raw = view(abuf, n, a.c1, t, h1, w1)     # conv_s output: dead once conv_t has run, shares the `a` scratch
+        pl.stem_fused = self._stem_fused(pl, n, t, h, w, dt)
         pl.y0 = view(ybuf[0], n, a.c1, t, h1, w1)
         pl.bn1 = bn_coef("conv1/bn", a.c1)
         pl.input_slots.append((F, len(F)))     # (the launch reads the caller's batch in place when pl.x_cl: _bind_input)
-        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
-        pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.y0, None, pl.bn1.ss, ACT_RELU, n, a.c1, t, h1 * w1,
-               a.c1_temp_filter, dt)
+        if pl.stem_fused:   # conv_s -> conv_t -> BN + ReLU in one launch: the conv_s output stays on chip (reference model.py:202-208)
+            pl.s_raw = None
+            pl.rec(F, "x3d_stem_fwd", pl.x, p["conv1/conv_s/kernel"], p["conv1/conv_t/kernel"], pl.y0, None, pl.bn1.ss, ACT_RELU,
+                   n, self.in_channels, t, h, w, a.c1, a.c1_temp_filter, dt, 1)
+        else:
+            pl.s_raw = view(abuf, n, a.c1, t, h1, w1)     # conv_s output: dead once conv_t has run, shares the `a` scratch
+            pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
+            pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.y0, None, pl.bn1.ss, ACT_RELU, n, a.c1, t, h1 * w1,
+                   a.c1_temp_filter, dt)
         # ---- residual stages ---------------------------------------------------------------------------------------
         x_cur, cur = pl.y0, 0
         pl.blocks = []
@@ -783,14 +790,22 @@ class X3D:
         pl.x_cl = bool(pl.lib.x3d_stem_s_nthwc_supported(self.in_channels, w, a.c1, dt)) and self.opt["stem_nthwc"]
         pl.x = None if pl.x_cl else pl.act(n, self.in_channels, t, h, w)
         h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        pl.s_raw = pl.act(n, a.c1, t, h1, w1)
+        # conv_s -> conv_t as one launch each way where the fused kernels take the shape: the conv_s output (616 MB at the
+        # headline's size) and its gradient never exist in HBM (reference model.py:202-206: nothing between the two convs)
+        pl.stem_fused = self._stem_fused(pl, n, t, h, w, dt)
+        pl.s_raw = None if pl.stem_fused else pl.act(n, a.c1, t, h1, w1)
         pl.t_raw = pl.act(n, a.c1, t, h1, w1)
         pl.y0 = pl.act(n, a.c1, t, h1, w1)
         pl.bn1 = bn_bufs("conv1/bn", a.c1)
         pl.input_slots.append((F, len(F)))     # (the launch reads the caller's batch in place when pl.x_cl: _bind_input)
-        pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
-        pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.t_raw,
-               ("acc", pl.bn1.stats) if training else None, None, ACT_NONE, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
+        if pl.stem_fused:
+            pl.rec(F, "x3d_stem_fwd", pl.x, p["conv1/conv_s/kernel"], p["conv1/conv_t/kernel"], pl.t_raw,
+                   ("acc", pl.bn1.stats) if training else None, None, ACT_NONE, n, self.in_channels, t, h, w, a.c1,
+                   a.c1_temp_filter, dt, 1)
+        else:
+            pl.rec(F, "x3d_stem_s_fwd", pl.x, p["conv1/conv_s/kernel"], pl.s_raw, n, self.in_channels, t, h, w, a.c1, dt, int(pl.x_cl))
+            pl.rec(F, "x3d_dwt_fwd", pl.s_raw, p["conv1/conv_t/kernel"], pl.t_raw,
+                   ("acc", pl.bn1.stats) if training else None, None, ACT_NONE, n, a.c1, t, h1 * w1, a.c1_temp_filter, dt)
         if fold_on:
             pl.rec(F, "x3d_tail_fwd_bn", pl.t_raw, bn_fold(pl.bn1, n * t * h1 * w1), None, None, pl.y0, n, a.c1, t * h1 * w1, dt)
         else:
@@ -1014,7 +1029,7 @@ class X3D:
         pl.g5 = pl.act(*pl.c5_raw.shape)
         pl.dh1 = pl.f32(n, a.fc1_out)
         pl.dpooled = pl.f32(n, c5)
-        pl.ds = pl.act(*pl.s_raw.shape)
+        pl.ds = None if pl.stem_fused else pl.act(*pl.s_raw.shape)
 
         # ---- head ------------------------------------------------------------------------------
         pl.rec(Bk, "x3d_dense_bwd", pl.dlogits, None, ACT_NONE, pl.h1, pl.drop_mask, float(pl.drop_scale),
@@ -1338,17 +1353,34 @@ class X3D:
             pl.rec(Bk, "x3d_relu_bn_bwd_reduce", dy, None, pl.t_raw, b1.ss, None, ("acc", b1.bsums), n, a.c1, P1, dt)
         rec_bn_bwd_finalize(b1, n * P1, p["conv1/bn/gamma"], g["conv1/bn/gamma"], g["conv1/bn/beta"], a.c1)
         assert pending_fin["job"] is None and pending_mark["stage"] is None and pending_reduce["a"] is None
-        pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
-               g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
-        pl.input_slots.append((Bk, len(Bk)))
-        pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
-               a.c1, dt, int(pl.x_cl))
+        if pl.stem_fused:
+            # one pass over dy, t_raw and the batch: conv_s recomputed on the matrix cores, the conv_t input gradient kept in LDS
+            pl.input_slots.append((Bk, len(Bk), 4))
+            pl.rec(Bk, "x3d_stem_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.x, p["conv1/conv_s/kernel"], p["conv1/conv_t/kernel"],
+                   g["conv1/conv_s/kernel"], g["conv1/conv_t/kernel"], n, self.in_channels, t, pl.h, pl.w, a.c1,
+                   a.c1_temp_filter, dt, 1)
+        else:
+            pl.rec(Bk, "x3d_dwt_bwd", dy, pl.t_raw, b1.ss, b1.coef, pl.s_raw, p["conv1/conv_t/kernel"], pl.ds,
+                   g["conv1/conv_t/kernel"], n, a.c1, t, pl.y0.shape[3] * pl.y0.shape[4], a.c1_temp_filter, dt)
+            pl.input_slots.append((Bk, len(Bk)))
+            pl.rec(Bk, "x3d_stem_s_wgrad", pl.x, pl.ds, g["conv1/conv_s/kernel"], n, self.in_channels, t, pl.h, pl.w,
+                   a.c1, dt, int(pl.x_cl))
         pl.rec_join(Bk)
         pl.bwd_stage_marks[-1] = len(Bk)
 
     # ---------------------------------------------------------------------------------------------
     # execution
     # ---------------------------------------------------------------------------------------------
+    def _stem_fused(self, pl: _Plan, n, t, h, w, dt):
+        """Does this plan run the stem as x3d_stem_fwd / x3d_stem_bwd (one launch each way)?  Needs the in-place channels-last
+        input (pl.x_cl) and a shape the fused kernels take (x3d_stem_fused_supported: bit 0 forward, bit 1 backward -- a plan
+        with a backward pass needs both, since the fused forward stores no conv_s output); the two-kernel path otherwise."""
+        if not (pl.x_cl and self.opt["stem_fused"]):
+            return False
+        need = 3 if pl.training else 1
+        have = pl.lib.x3d_stem_fused_supported(self.in_channels, self.arch.c1, self.arch.c1_temp_filter, n, t, h, w, dt, 1)
+        return (have & need) == need
+
     def _bind_input(self, pl: _Plan, x):
         if self.dry:
             raise hip.X3DHipError("a dry model cannot run (no CPU fallback for the hot path)")
@@ -1366,9 +1398,10 @@ class X3D:
                 x = x.to(self.dtype)
             if x.data_ptr() % 16:
                 x = x.clone()
-            for lst, i in pl.input_slots:
+            for lst, i, *pos in pl.input_slots:
+                k = pos[0] if pos else 0                   # (the batch is argument 0 of most stem launches, argument 4 of x3d_stem_bwd)
                 name, fn, args = lst[i]
-                lst[i] = (name, fn, (x.data_ptr(),) + tuple(args[1:]))
+                lst[i] = (name, fn, tuple(args[:k]) + (x.data_ptr(),) + tuple(args[k + 1:]))
         else:
             hip.call("x3d_nthwc_to_ncthw", x.data_ptr(), hip.dtype_code(x.dtype), pl.x.data_ptr(),
                      hip.dtype_code(self.dtype), n, c, t * h * w)

@@ -115,10 +115,11 @@ def dwt_bwd(g, yraw, coef, x, w, dx, dw, relu_ss=None):
 
 
 def stem_fused_supported(x, cout, kt=5):
-    """x: the channels-last clip batch [N, T, H, W, Cin] (x3d_stem_fused_supported)."""
+    """x: the channels-last clip batch [N, T, H, W, Cin].  x3d_stem_fused_supported: bit 0 = stem_fwd takes the shape, bit 1 =
+    stem_bwd takes it and is the faster backward."""
     n, t, h, ww, cin = x.shape
     code = hip.dtype_code(x.dtype)
-    return bool(hip.load().x3d_stem_fused_supported(cin, cout, kt, n, t, h, ww, code, 1))
+    return int(hip.load().x3d_stem_fused_supported(cin, cout, kt, n, t, h, ww, code, 1))
 
 
 def stem_fwd(x, w_s, w_t, y=None, stats=None, out_ss=None, out_act=ACT_NONE):
