@@ -224,7 +224,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variant", default="M")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="activation storage: bf16 (the headline), fp16 (the reference's mixed_float16 mode; dynamic loss scale), fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     args = ap.parse_args()
@@ -259,7 +260,7 @@ def main():
     from x3d_tf_amd.model import X3D
     from x3d_tf_amd.train import Trainer
     cfg = x3d.get_config(args.variant)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     model = X3D(cfg, dtype=dtype, device=device, seed=0)
     trainer = Trainer(model, cfg)
     t, s = CLIP[args.variant]
@@ -278,7 +279,7 @@ def main():
         pl = trainer.step(clips, labels, lr)
     torch.cuda.synchronize()
     trainer.reducer.exposed_ms()      # (drop the warm-up steps' measurements)
-    timer = KernelTimer(model, pl, 2 if dtype == torch.bfloat16 else 4)
+    timer = KernelTimer(model, pl, 4 if dtype == torch.float32 else 2)
     timer.wrap(pl)
     timer.enabled = True
     for _ in range(2):                # untimed probe: which depthwise instantiation has the largest total
@@ -309,13 +310,26 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = False
     mfma = mfma_utilisation(model, pl, trainer, clips, labels, lr) if (world == 1 and rank == 0) else None
+    if world == 1 and trainer.collectives:
+        # one-rank rehearsal (X3D_DIST_REHEARSE=1): the same K steps again WITHOUT hooks and collectives -- what the data-parallel
+        # machinery costs a step before a byte crosses xGMI (profiles/r06_collective_overhead.txt: it is the first cross-queue
+        # dependency of the step in the HIP runtime, ~0.2 ms, not RCCL work)
+        trainer.collectives = trainer.reducer.active = trainer.sync_moving_stats = False
+        for _ in range(2):
+            trainer.step(clips, labels, lr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(clips, labels, lr)
+        torch.cuda.synchronize()
+        coll["overhead_ms_vs_no_collectives"] = 1e3 * (elapsed - (time.perf_counter() - t1)) / args.steps
 
     if rank == 0:
         clips_s = args.steps * B * world / elapsed
         kernels = timer.summary()
         dom = dominant[0] if dominant else None
         w = A.workload(model.arch, t, s, s)
-        eb = 2 if dtype == torch.bfloat16 else 4
+        eb = 4 if dtype == torch.float32 else 2
         step_bytes_per_clip = 3 * w["total_elements"] * eb
         # HBM traffic per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py:
         # separate FETCH_SIZE / WRITE_SIZE runs, (2*FETCH + WRITE) * 1024 on gfx950); null if not collected

@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 131
+#define X3D_ABI_VERSION 132
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -295,6 +295,9 @@ typedef struct {
    * x3d_dw_slab_reduce, or the two reduce slots of x3d_se_bnb_bwd (a small launch that is on the critical path anyway).
    * x3d_pw_bwd_dw_parts() == 0: the kernel behind this call has no slab form (leave dw_slab NULL). */
   float* dw_slab;              /* x3d_pw_bwd_dw_parts(a) * Cout * Cin floats, 16-byte aligned */
+  int dw_slab_parts;           /* (ABI 132) the number of slabs dw_slab holds = what x3d_pw_bwd_dw_parts(a) returned when the buffer was
+                                * sized: a launch whose grid differs (another device, another build switch between recording and
+                                * replay) is refused instead of writing past the buffer or leaving slabs unwritten */
   const x3d_bn_bwd_fold* coef_fold; /* NULL | derive `coef` from the BatchNorm-backward sums (x3d_bn_bwd_fold) */
 } x3d_pw_bwd_args;
 int x3d_pw_bwd_supported(const x3d_pw_bwd_args* a);
@@ -355,6 +358,7 @@ typedef struct {
   int N, Cin, Cout, T, H, W, stride, dtype; /* T,H,W: INPUT extents (as in fwd) */
   float* dw_slab;              /* NULL | partial slabs instead of atomics, as x3d_pw_bwd_args.dw_slab: x3d_pw_wgrad_dw_parts(a) * Cout * Cin
                                 * floats, every one of them written (dw untouched); added up by x3d_dw_slab_reduce / x3d_se_bnb_bwd */
+  int dw_slab_parts;           /* the number of slabs dw_slab holds (x3d_pw_wgrad_dw_parts(a) when it was sized): checked against the grid */
   const x3d_bn_bwd_fold* coef_fold; /* NULL | derive `coef` from the BatchNorm-backward sums (x3d_bn_bwd_fold) */
 } x3d_pw_wgrad_args;
 int x3d_pw_wgrad(const x3d_pw_wgrad_args* a, void* stream);

@@ -32,7 +32,7 @@ def main():
         tr = pmc.get(k["kernel"], {}).get("traffic_bytes_per_launch")
         print(f"{k['kernel']:52s} {int(st['Calls']):5d} {us:14.1f} {k['avg_us']:12.1f} {by / 1e9:8.3f} {gbs:7.0f} {gbs / 8000:9.3f} "
               f"{(tr / by if tr else float('nan')):18.2f}")
-        n = k["launches"] / line["steps"]
+        n = k["launches"] / 2          # (bench.py collects the `kernels` table over TWO steps after the timed region, not over `steps`)
         tot_b += by * n
         tot_t += us * n
     print(f"# all depthwise launches of one step: {tot_b / 1e9:.2f} GB algorithmic in {tot_t / 1e3:.2f} ms = {tot_b / tot_t / 1e3:.0f} GB/s "

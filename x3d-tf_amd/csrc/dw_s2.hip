@@ -586,6 +586,13 @@ __global__ __launch_bounds__(256, S2R_OCC) void dw3d_bwd_s2r_kernel(const DwBwdA
 bool dw_bwd_s2_launch(const DwBwdArgs& a, int dtype, int SW, int cv, int pd, unsigned grid, int bd, size_t lds, hipStream_t st) {
   if (SW != 2 || pd != 2 || a.g.pw != 0 || x3d_env_int("X3D_DW_S2", 1) == 0) return false;   // X3D_DW_S2=0: A/B hook
   if (dtype == X3D_F32 || cv != 8) return false;   // fp32 storage: 168 VGPRs + 68 B of scratch here -- stays on dw3d_bwd_pd_kernel
+  // what both kernels below assume (today's call site in dw_bwd.hip guarantees it; a changed call site must fall back, not
+  // compute wrong results): one staging vector per thread for either plane, four waves (the scratch of the final sums),
+  // 8-byte dB vectors, 32-bit buffer offsets within a channel
+  const DwGeom& g = a.g;
+  if (bd != 256 || a.vecB != 4 || (g.W % 8) != 0 || (g.Wo % 4) != 0) return false;
+  if (g.RIN * (g.W / 8) > bd || a.RB * (g.Wo / 4) > bd) return false;
+  if ((long long)g.T * g.H * g.W * 2 >= (1ll << 30)) return false;
   // two LDS plane buffers, one barrier per plane, when the planes fit the constant buffer stride.  X3D_DW_S2_DB=0: A/B hook
   const int ring = x3d_env_int("X3D_DW_S2_RING", 1);   // A/B hook: 0 = the two-barrier kernel
   if (ring && (a.g.RIN + 3) * a.g.LP <= DW_S2_SA && (a.RB + 2) * a.LPB <= DW_S2_SB) {

@@ -658,6 +658,10 @@ extern "C" int x3d_pw_bwd(const x3d_pw_bwd_args* b, void* stream) {
   X3D_REQUIRE(b->N > 0 && b->Cin > 0 && b->Cout > 0 && b->T > 0 && b->H > 0 && b->W > 0, "pw_bwd: bad extents");
   X3D_REQUIRE(!b->dw_slab || (x3d_pw_bwd_dw_parts(b) > 0 && ((uintptr_t)b->dw_slab % 16) == 0),
               "pw_bwd: dw_slab given but the kernel behind this call has no slab form (x3d_pw_bwd_dw_parts() == 0)");
+  // the grid of the slab kernels is x3d_pw_bwd_dw_parts() (the same function of the device's CU count): a buffer sized for
+  // another count would be overrun, or summed with unwritten slabs
+  X3D_REQUIRE(!b->dw_slab || x3d_describe.out || x3d_pw_bwd_dw_parts(b) == b->dw_slab_parts,
+              "pw_bwd: dw_slab holds %d slabs, this launch writes %d (x3d_pw_bwd_dw_parts)", b->dw_slab_parts, x3d_pw_bwd_dw_parts(b));
   X3D_REQUIRE(x3d_describe.out || bn_bwd_fold_ok(b->coef_fold), "pw_bwd: incomplete coef_fold");
   X3D_REQUIRE(!b->coef_fold || (!b->rc_panel && (pw_bwd_wst_applies(b) || pw_bwd_wsta_applies(b))),
               "pw_bwd: coef_fold is not taken by the kernel behind this call (x3d_pw_coef_fold_supported() == 0)");

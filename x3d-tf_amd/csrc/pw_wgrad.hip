@@ -18,6 +18,7 @@ struct PwWgradArgs {
   int ragged;           // 16-bit storage, P % 8 != 0, stride 1: the vector kernel with ragged row ends (pw_gemm.h)
   BnBwdFold fold;       // sums != NULL: the dY coefficients are derived from the BatchNorm-backward sums (x3d_hip.h coef_fold; pw_wgrad_bf16_v2 only)
   float* slab;          // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
+  int slab_parts;       // slabs the buffer holds: the launcher refuses another grid (host side only)
 };
 
 #include "pw_wgrad_bf16.h"
@@ -241,7 +242,7 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   memset(&a, 0, sizeof(a));
   a.g = w->g; a.yraw = w->yraw; a.coef = w->coef; a.fold = bn_bwd_fold_arg(w->coef_fold);
   a.x = w->x; a.xcoef = w->in_scale_shift; a.xgate = w->in_gate; a.xact = w->in_act;
-  a.dw = w->dw; a.slab = w->dw_slab; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
+  a.dw = w->dw; a.slab = w->dw_slab; a.slab_parts = w->dw_slab_parts; a.N = w->N; a.Cout = w->Cout; a.Cin = w->Cin;
   a.stride = w->stride; a.H = w->H; a.W = w->W;
   a.Ho = ceil_div(w->H, w->stride); a.Wo = ceil_div(w->W, w->stride);
   a.Pin = (long long)w->T * w->H * w->W;
@@ -254,19 +255,17 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   a.ragged = (pw_ragged_rows(a.P, eb) &&
               (((uintptr_t)w->g | (uintptr_t)w->yraw | (uintptr_t)w->x) % 16) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  // dw_slab: only where the kernel behind the call has the form (x3d_pw_wgrad_dw_parts() > 0); a launcher without it would
-  // flush into dw and leave the slabs unwritten -- refused up front
-  if (w->dw_slab && !x3d_parts_query && !x3d_describe.out) {
-    X3D_REQUIRE(((uintptr_t)w->dw_slab % 16) == 0 && x3d_pw_wgrad_dw_parts(w) > 0,
-                "pw_wgrad: dw_slab given but the kernel behind this call has no slab form (x3d_pw_wgrad_dw_parts() == 0)");
-  }
+  // dw_slab: only where the kernel behind the call has the form (x3d_pw_wgrad_dw_parts() > 0).  The launcher that is chosen
+  // checks it -- a kernel without the form refuses a slab, one with it refuses a buffer whose slab count (dw_slab_parts) is not
+  // its grid -- so the dispatch is not run a second time in query mode on every replayed step (round 5 did)
+  X3D_REQUIRE(!w->dw_slab || ((uintptr_t)w->dw_slab % 16) == 0, "pw_wgrad: dw_slab must be 16-byte aligned");
   if (w->dtype == X3D_F32) {
     X3D_REQUIRE(!w->coef_fold, "pw_wgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
     if (a.stride == 1 && a.P >= 4 && x3d_env_int("X3D_PW_F32R", 1) != 0) {      // tile groups of <= 8, long double-buffered runs (pw_wgrad_f32r.h)
       PwWgradRArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.g = a.g; ra.yraw = a.yraw; ra.coef = a.coef; ra.x = a.x; ra.xcoef = a.xcoef; ra.xgate = a.xgate; ra.xact = a.xact;
-      ra.dw = a.dw; ra.slab = a.slab; ra.N = a.N; ra.Cout = a.Cout; ra.Cin = a.Cin; ra.P = a.P;
+      ra.dw = a.dw; ra.slab = a.slab; ra.slab_parts = a.slab_parts; ra.N = a.N; ra.Cout = a.Cout; ra.Cin = a.Cin; ra.P = a.P;
       const int rc = xpro ? wgrad_f32r_pick<true>(ra, st) : wgrad_f32r_pick<false>(ra, st);
       if (rc >= 0) return rc;
     }

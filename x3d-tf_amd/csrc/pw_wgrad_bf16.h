@@ -509,6 +509,10 @@ static int pw_wgrad_v2_launch(PwWgradArgs& a, hipStream_t st) {
   long long gx = ceil_div_ll(total_steps, spb);
   if (gy * gz > 1 && xcd_pad_enabled()) gx = (gx + 7) & ~7ll;   // tile groups of one point chunk on one XCD (shared L2)
   if (x3d_parts_query) { *x3d_parts_query = (int)gx; return X3D_OK; }
+  if (a.slab && gx != a.slab_parts) {
+    x3d_set_error("pw_wgrad: dw_slab holds %d slabs, this launch writes %lld (x3d_pw_wgrad_dw_parts)", a.slab_parts, gx);
+    return X3D_ERR_INVALID;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(NTHR), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_bf16_v2");
   return X3D_OK;

@@ -17,6 +17,7 @@ struct PwWgradRArgs {
   const void* x; const float* xcoef; const float* xgate; int xact;
   float* dw;
   float* slab;               // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
+  int slab_parts;            // slabs the buffer holds (host side: checked against the grid)
   int N, Cout, Cin;
   long long P;
   int mgroups, ngroups;      // tile groups along Cout / Cin
@@ -201,6 +202,10 @@ static int wgrad_f32r_launch(PwWgradRArgs& a, hipStream_t st) {
   a.steps_per_block = (int)spb;
   const long long gx = ceil_div_ll(steps_per_n, spb) * a.N;
   if (x3d_parts_query) { *x3d_parts_query = (int)gx; return X3D_OK; }     // (x3d_pw_wgrad_dw_parts: one slab per blockIdx.x)
+  if (a.slab && gx != a.slab_parts) {
+    x3d_set_error("pw_wgrad: dw_slab holds %d slabs, this launch writes %lld (x3d_pw_wgrad_dw_parts)", a.slab_parts, gx);
+    return X3D_ERR_INVALID;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)groups), dim3(256), lds, st, a);
   X3D_LAUNCH_CHECK("pw_wgrad_f32r");
   return X3D_OK;

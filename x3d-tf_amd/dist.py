@@ -172,9 +172,11 @@ class BucketReducer:
             self._pairs.append((self._ev_mark, done))      # read later (exposed_ms), after the caller's own synchronisation
             while len(self._pairs) > self.EVENT_WINDOW:    # steps old: long finished, elapsed_time does not block
                 a, b = self._pairs.popleft()
-                if b.query():
-                    self._dev_ms += a.elapsed_time(b)
-                    self._dev_n += 1
+                if not b.query():                          # (not finished after all: keep it -- dropping it would bias the
+                    self._pairs.appendleft((a, b))         #  average towards the steps that happened to be done)
+                    break
+                self._dev_ms += a.elapsed_time(b)
+                self._dev_n += 1
         else:
             self._host_s += time.perf_counter() - self._t_mark
             self._host_n += 1

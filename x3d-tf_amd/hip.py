@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 131   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 132   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -45,7 +45,7 @@ class PwBwdArgs(C.Structure):
                 ("N", _i), ("Cin", _i), ("Cout", _i), ("T", _i), ("H", _i), ("W", _i), ("dtype", _i),
                 ("tail_c", _vp), ("tail_r", _vp), ("tail_sums_c", _vp), ("tail_sums_r", _vp),
                 ("rc_panel", _vp), ("rc_c0", _vp), ("rc_sums", _vp), ("x_stride", _i), ("xH", _i), ("xW", _i),
-                ("dw_slab", _vp), ("coef_fold", _vp)]
+                ("dw_slab", _vp), ("dw_slab_parts", _i), ("coef_fold", _vp)]
 
 
 class DwReduceJob(C.Structure):
@@ -75,7 +75,8 @@ class PwPackItem(C.Structure):
 class PwWgradArgs(C.Structure):
     _fields_ = [("g", _vp), ("yraw", _vp), ("coef", _vp), ("x", _vp), ("in_scale_shift", _vp),
                 ("in_gate", _vp), ("in_act", _i), ("dw", _vp), ("N", _i), ("Cin", _i), ("Cout", _i),
-                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("dw_slab", _vp), ("coef_fold", _vp)]
+                ("T", _i), ("H", _i), ("W", _i), ("stride", _i), ("dtype", _i), ("dw_slab", _vp), ("dw_slab_parts", _i),
+                ("coef_fold", _vp)]
 
 
 class BnBwdFold(C.Structure):
@@ -84,7 +85,11 @@ class BnBwdFold(C.Structure):
                 ("coef_out", _vp)]
 
 
-FOLDS = {}      # address -> BnBwdFold: argument structs refer to a fold by address (tools that walk a plan's pointers follow it)
+# address -> BnBwdFold: argument structs refer to a fold by address (tools that walk a plan's pointers follow it).  Weak values:
+# the plan (or the ops wrapper) that built a fold keeps it alive for as long as its launches exist; an entry whose owner is gone
+# disappears with it instead of accumulating -- and instead of handing dispatch._struct_pointers stale device addresses.
+import weakref  # noqa: E402
+FOLDS = weakref.WeakValueDictionary()
 
 
 def fold_address(f: BnBwdFold) -> int:

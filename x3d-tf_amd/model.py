@@ -1117,7 +1117,7 @@ class X3D:
             if buf is None:
                 buf = slab_bufs[(role, parts * elems)] = pl.f32(parts * elems)
                 pl.keep.append(buf)
-            st.dw_slab = _p(buf)
+            st.dw_slab, st.dw_slab_parts = _p(buf), parts
             return hip.DwReduceJob(_p(buf), _p(dw), parts, elems)
 
         def flush_pending_reduce():

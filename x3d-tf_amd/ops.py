@@ -267,7 +267,7 @@ def pw_bwd(g, yraw, coef, w_panel, dx, dw, epi, x=None, add=None, braw=None, b_s
         if parts <= 0:
             return None
         buf = torch.full((parts * cout * cin,), float("nan"), dtype=torch.float32, device=g.device)   # (every slab element must be written)
-        a.dw_slab = ptr(buf)
+        a.dw_slab, a.dw_slab_parts = ptr(buf), parts
         hip.call_struct("x3d_pw_bwd", a)
         dw_slab_reduce([(buf, dw, parts)])
         return True
@@ -348,7 +348,7 @@ def pw_wgrad(g, yraw, coef, x, dw, in_ss=None, in_gate=None, in_act=ACT_NONE, st
         if parts <= 0:
             return None
         buf = torch.full((parts * cout * cin,), float("nan"), dtype=torch.float32, device=g.device)   # (every slab element must be written)
-        a.dw_slab = ptr(buf)
+        a.dw_slab, a.dw_slab_parts = ptr(buf), parts
         hip.call_struct("x3d_pw_wgrad", a)
         dw_slab_reduce([(buf, dw, parts)])
         return True
