@@ -389,13 +389,20 @@ static inline void x3d_persistent_grid(long long total, int cus, long long* per_
 }
 
 #define STATS_R 32
+// copies the producers actually add into (the rest stay zero).  -DSTATS_USED=8: round-6 A/B of one copy per XCD with the finalize
+// folded into the consumers (plan option bn_fold), whose per-workgroup sum over the copies is then 8 terms instead of 32
+// (tools/ab_stats_used.sh, profiles/r06_ab_stats_used.txt)
+#ifndef STATS_USED
+#define STATS_USED 32
+#endif
+static_assert(STATS_USED == 32 || STATS_USED == 8, "STATS_USED: 32 (product) or 8 (experiment)");
 __host__ __device__ __forceinline__ long long stats_stride(int C) {
   const long long need = ((long long)C * 2 + 63) & ~63ll;
   return need > 512 ? need : 512;        // >= 4 KB apart: the copies land in different L2 channels
 }
 // the copy a producer workgroup adds into; `key`: any index that differs between the workgroups that share a channel
 __device__ __forceinline__ double* stats_replica(double* stats, int C, unsigned key) {
-  return stats + (long long)(key % STATS_R) * stats_stride(C);
+  return stats + (long long)(key % STATS_USED) * stats_stride(C);
 }
 
 // coefficients of one channel from its totals (sum, sum of squares); `writer` publishes them / updates the moving stats
@@ -429,7 +436,9 @@ __device__ __forceinline__ void bn_fold_channel(const x3d_bn_fold& f, int c, boo
   const long long rs = stats_stride(C);
   double q1[STATS_R / 8], q2[STATS_R / 8];
 #pragma unroll
-  for (int r0 = 0; r0 < STATS_R; r0 += 8) {
+  for (int i = 0; i < STATS_R / 8; i++) { q1[i] = 0.0; q2[i] = 0.0; }      // (copies past STATS_USED hold zeros: not read)
+#pragma unroll
+  for (int r0 = 0; r0 < STATS_USED; r0 += 8) {
     double p1[8], p2[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) { p1[r] = f.stats[(r0 + r) * rs + c * 2]; p2[r] = f.stats[(r0 + r) * rs + c * 2 + 1]; }
