@@ -12,7 +12,7 @@ CHANS = [24, 48, 54, 96, 108, 192, 216, 432, 40, 72, 200]
 
 
 def case_calls(rng: random.Random):
-    """One fuzz case = 11 kernel-test calls: [(test function name, positional args after `gpu`)]."""
+    """One fuzz case = 12 kernel-test calls: [(test function name, positional args after `gpu`)]."""
     dt = rng.choice(DTYPES)
     out = []
     shp = (rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 5, 8]), rng.choice(WIDTHS), rng.choice(WIDTHS),
@@ -45,6 +45,11 @@ def case_calls(rng: random.Random):
            rng.choice([8, 14, 20, 27, 28, 33, 40, 45, 56, 64]), rng.choice([16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 120]), rng.choice([1, 2]))
     out.append(("test_dw3d_fwd", (dt, shv)))
     out.append(("test_dw3d_bwd", (dt, shv)))
+    # round 6: the fused stem (stem_fused.hip, 16-bit storage only): rows of whole 16-byte vectors, T around the six-fold unrolled
+    # time loop and below the kernel length, one to three segments per row, partial last groups, 8 .. 32 channels
+    dh = dt if half else rng.choice([torch.bfloat16, torch.float16])
+    out.append(("test_stem_fused", (dh, (rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 16]), rng.choice([2, 3, 5, 8, 9, 14, 21]),
+                                        rng.choice([8, 16, 24, 40, 56, 72, 104, 128, 136, 160, 264]), rng.choice([8, 16, 24, 24, 32])))))
     return out
 
 
@@ -66,5 +71,5 @@ def run_cases(gpu, cases: int, seed: int, log=None):
                 if log:
                     log(f"FAIL {name} {args}\n{traceback.format_exc(limit=2)}")
         if log and (i + 1) % 10 == 0:
-            log(f"{i + 1} cases ({9 * (i + 1)} kernel checks), {len(fails)} failures")
+            log(f"{i + 1} cases ({12 * (i + 1)} kernel checks), {len(fails)} failures")
     return fails

@@ -202,7 +202,10 @@ def test_pw_fwd_infer(gpu, dtype, shape, panel):
                    out_add=dev(add), out_add_ss=dev(ass), out_act=1 if oact == "relu" else 0)
     torch.cuda.synchronize()
     rt, at = tol_gemm(dtype)
-    report("y", y, ref, rt, at * max(ref.abs().max().item(), 1.0))
+    slack = 0.0
+    if pro and dtype != torch.float32:     # a prologue value on a rounding tie (util.tie_slack), through the output scale
+        slack = tie_slack(xin, dtype, round_to(wt, dtype).abs()) * oss[:, 0].abs().double().view(1, -1, 1, 1, 1)
+    report("y", y, ref, rt, at * max(ref.abs().max().item(), 1.0) + slack)
     # the training form of the same launch still refuses the epilogue operands it cannot honour
     with pytest.raises(Exception):
         ops.pw_fwd(dev(x), dev(wt), stats=torch.zeros((cout, 2), dtype=torch.float64, device=gpu), out_ss=dev(oss))
@@ -217,6 +220,17 @@ def _dyraw(coef, gd, yd, dtype=None):
         return round_to(v, dtype)
     c = coef.double()
     return c[:, 0].view(1, -1, 1, 1, 1) * gd + c[:, 1].view(1, -1, 1, 1, 1) * yd + c[:, 2].view(1, -1, 1, 1, 1)
+
+
+def _dyraw_slack(coef, gd, yd, dtype, wt):
+    """tie slack (util.tie_slack) of a data gradient dx = Wr^T dYraw whose operand dYraw = A g + B yraw + C is evaluated in
+    fp32 and rounded to the 16-bit storage type: where the fp32 value sits on a rounding tie the kernel's fused multiply-adds
+    may land on the other neighbour than torch's association does.  [N, Cin, T, H, W]; zero almost everywhere."""
+    if dtype == torch.float32:
+        return 0.0
+    c = coef.float()
+    v = c[:, 0].view(1, -1, 1, 1, 1) * gd.float() + c[:, 1].view(1, -1, 1, 1, 1) * yd.float() + c[:, 2].view(1, -1, 1, 1, 1)
+    return tie_slack(v, dtype, round_to(wt, dtype).abs().t().contiguous())
 
 
 def _wtol(dtype):
@@ -276,7 +290,8 @@ def test_pw_bwd_oracle(gpu, dtype, shape, slab):
     torch.cuda.synchronize()
     assert ok, "fused kernel should cover this shape"
     rt, at = tol_gemm(dtype)
-    report("dx", dx, dx_ref, rt, at * dx_ref.abs().max().item())
+    # (swish' <= 1.1: the epilogue cannot enlarge an operand flip by more)
+    report("dx", dx, dx_ref, rt, at * dx_ref.abs().max().item() + 1.1 * _dyraw_slack(coef, gyd, yrd, dtype, wt))
     dw_ref = torch.einsum("nothw,ncthw->oc", dy, xin)
     tol = _wtol(dtype)
     report("dw", dw, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
@@ -816,7 +831,7 @@ def test_pw_dgrad(gpu, dtype, shape, epi, panel):
         kw["w_panel"] = _panels(ops, wt, dtype, gpu)[1]     # the production dispatch (model.py always passes the panel)
     ops.pw_dgrad(g.to(gpu), yraw.to(gpu), coef.to(gpu), wt.to(gpu), dx, **kw)
     torch.cuda.synchronize()
-    report("dx", dx, ref, rt, at * ref.abs().max().item())
+    report("dx", dx, ref, rt, at * ref.abs().max().item() + 1.1 * _dyraw_slack(coef, gd, yd, dtype, wt))
     if epi == "swish_bwd":
         dvs = dx.float().cpu().double()
         sref = torch.stack([dvs.sum((2, 3, 4)), (dvs * bd).sum((2, 3, 4))], -1)

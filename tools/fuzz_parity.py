@@ -23,9 +23,9 @@ def main():
         if logf:
             logf.write(msg + "\n")
             logf.flush()
-    log(f"fuzz_parity: {cases} cases x 11 kernel checks, seed {seed}, {torch.cuda.get_device_name(0)}")
+    log(f"fuzz_parity: {cases} cases x 12 kernel checks, seed {seed}, {torch.cuda.get_device_name(0)}")
     fails = fuzz.run_cases(torch.device("cuda:0"), cases, seed, log)
-    log(f"done: {cases} cases ({11 * cases} kernel checks), {len(fails)} failures")
+    log(f"done: {cases} cases ({12 * cases} kernel checks), {len(fails)} failures")
     sys.exit(1 if fails else 0)
 
 

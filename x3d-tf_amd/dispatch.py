@@ -133,3 +133,91 @@ def stage_of(model, name: str) -> int:
     if name.startswith("stages/"):
         return int(name.split("/")[1])
     return len(model.arch.stages)
+
+
+# ---- read / write order of the plan-owned scratch of a backward list ---------------------------------------------------------
+# Which argument of which launch READS or WRITES a scratch buffer the plan shares between launches "by stream order": the
+# weight-gradient slabs, the recomputed-output operands (panel, c0, moment sums), the BatchNorm-backward coefficient tables and
+# sums, the per-(n, c) coefficient table of the SE / BN_b backward.  By struct field and by argument position.
+_STRUCT_ACCESS = {
+    "PwBwdArgs": {"coef": ("coef", "R"), "rc_panel": ("rc_panel", "R"), "rc_c0": ("rc_c0", "R"), "rc_sums": ("rc_sums", "W"),
+                  "dw_slab": ("slab", "W"), "tail_sums_c": ("bsums", "W"), "tail_sums_r": ("bsums", "W")},
+    "PwWgradArgs": {"coef": ("coef", "R"), "dw_slab": ("slab", "W")},
+    "PwDgradArgs": {"coef": ("coef", "R")},
+    "Dw3dBwdArgs": {"coef_nc": ("coef_nc", "R"), "a_sums": ("bsums", "W")},
+    "SeBnbBwdArgs": {"coef_nc": ("coef_nc", "W")},
+}
+_ARG_ACCESS = {
+    "x3d_bn_bwd_finalize": {0: ("bsums", "R"), 4: ("coef", "W")},
+    "x3d_bn_bwd_finalize_rc": {0: ("bsums", "R"), 4: ("coef", "W"), 9: ("rc_panel", "W"), 10: ("rc_c0", "W"), 12: ("rc_sums", "R"),
+                               14: ("coef", "R")},
+    "x3d_pw_bwd_rc_prepare": {1: ("coef", "R"), 2: ("rc_panel", "W"), 3: ("rc_c0", "W")},
+    "x3d_pw_bwd_rc_finish": {0: ("rc_sums", "R"), 2: ("coef", "R")},
+    "x3d_dwt_bwd": {3: ("coef", "R")},
+    "x3d_stem_bwd": {3: ("coef", "R")},
+    "x3d_tail_bwd": {4: ("bsums", "W"), 5: ("bsums", "W")},
+    "x3d_relu_bn_bwd_reduce": {5: ("bsums", "W")},
+}
+
+
+def scratch_accesses(pl) -> List[Tuple[int, str, str, int, str]]:
+    """(index in pl.bwd, entry point, buffer kind, address, "R" | "W") for every access of a backward launch to plan-owned scratch,
+    in list order; a launch's reads come before its writes (an accumulating argument counts as a write)."""
+    out = []
+    for i, item in enumerate(pl.bwd):
+        if item is None:
+            continue
+        name, _, args = item
+        acc = []
+        for pos, (kind, rw) in _ARG_ACCESS.get(name, {}).items():
+            if pos < len(args) and isinstance(args[pos], int) and args[pos]:
+                acc.append((kind, args[pos], rw))
+        st = pl.structs.get((id(pl.bwd), i))
+        if st is not None:
+            fold = getattr(st, "coef_fold", None)
+            folded = isinstance(fold, int) and bool(fold)
+            for fname, (kind, rw) in _STRUCT_ACCESS.get(type(st).__name__, {}).items():
+                v = getattr(st, fname)
+                if isinstance(v, int) and v and not (folded and fname == "coef"):      # (with coef_fold the table is not read)
+                    acc.append((kind, v, rw))
+            if folded and fold in hip.FOLDS:      # the consumer derives the coefficients from the sums itself (and may publish the table)
+                f = hip.FOLDS[fold]
+                if f.sums:
+                    acc.append(("bsums", f.sums, "R"))
+                if f.coef_out:
+                    acc.append(("coef", f.coef_out, "W"))
+            if type(st).__name__ == "SeBnbBwdArgs":
+                for job in st.reduce:
+                    if job.slab:
+                        acc.append(("slab", job.slab, "R"))
+        for a in args:
+            if isinstance(a, C.Array):                                     # x3d_dw_slab_reduce: an array of reduce jobs
+                for job in a:
+                    if isinstance(job, hip.DwReduceJob) and job.slab:
+                        acc.append(("slab", job.slab, "R"))
+        for kind, addr, rw in sorted(acc, key=lambda t: t[2]):             # "R" before "W"
+            out.append((i, name, kind, addr, rw))
+    return out
+
+
+def scratch_hazards(pl) -> List[str]:
+    """Order violations of the scratch accesses of pl.bwd: a buffer read before anything wrote it, a written value overwritten
+    before a launch read it (slabs, recomputed-output operands, coefficient tables: every write must be consumed), sums written
+    again after a finalize read them, a value left unread at the end of the list."""
+    seq = {}
+    for i, name, kind, addr, rw in scratch_accesses(pl):
+        seq.setdefault((kind, addr), []).append((i, name, rw))
+    bad = []
+    for (kind, addr), acc in seq.items():
+        pattern = "".join(rw for _, _, rw in acc)
+        where = f"{kind} buffer {addr:#x}: " + " ".join(f"{rw}@{i}:{name[4:]}" for i, name, rw in acc[:8])
+        if pattern[0] != "W":
+            bad.append("read before any write -- " + where)
+        if pattern[-1] != "R" and kind != "coef":      # (a published coefficient table may have no reader left: every consumer folds)
+            bad.append("last write never read -- " + where)
+        if kind == "bsums":
+            if "RW" in pattern:
+                bad.append("sums written after a finalize read them -- " + where)
+        elif "WW" in pattern:
+            bad.append("overwritten before it was read -- " + where)
+    return bad
