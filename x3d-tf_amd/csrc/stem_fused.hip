@@ -29,6 +29,10 @@
 
 #include "common.h"
 
+#ifndef SF_EXP
+#define SF_EXP 0     // timing experiments (tools/ab_stem_parts.sh): 1 no time-domain math, 2 no commit, 4 no conv_s, 8 no barrier, 16 no MFMA in conv_s, 32 no slab write
+#endif
+
 namespace {
 
 constexpr int SF_THREADS = 512;
@@ -151,8 +155,15 @@ __device__ __forceinline__ void sf_conv_s(const HT* Bs, HT* Ss, const typename H
     const sf_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sf_lds_s16x4_ptr)(&Bs[bs_at(ks * 16 + tr_row, tr_col)]));
     const sf_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sf_lds_s16x4_ptr)(&Bs[bs_at(ks * 16 + tr_row + 4, tr_col)]));
     const sf_s16x8 bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#if !(SF_EXP & 16)
     acc = mfma16<HT>(__builtin_bit_cast(hx8, bs), wfrag[ks], acc);
+#else
+    for (int e = 0; e < 8; e++) acc[e + 8 * ks] += (float)__builtin_bit_cast(hx8, bs)[e] * (float)wfrag[ks][e];   // (timing experiment: no MFMA)
+#endif
   }
+#if (SF_EXP & 32)
+  if (acc[0] != 12345.678f) return;      // (timing experiment: the slab is not written)
+#endif
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     hx4 o;
@@ -258,10 +269,16 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __
     // tick k (PH = k % 6).  Planes past T are zeros (bounds-checked loads): their terms vanish, their stores are dropped.
     auto tick = [&](auto ph, int k, auto do_conv, auto do_time) {
       constexpr int PH = decltype(ph)::value;
+#if !(SF_EXP & 2)
       st.commit(xb[PH & 1], Bs2[PH & 1]);           // plane k  (last readers of this image: conv_s of plane k - 2, last tick)
+#else
+      if (xb[PH & 1].r[0][0] == 0x12345678u) Bs2[0][tid] = (HT)1.f;      // (timing experiment: the loads stay, the commit goes)
+#endif
       st.issue(xb[PH & 1], rx, k + 2, Tn, plane3);
+#if !(SF_EXP & 4)
       if constexpr (decltype(do_conv)::value)       // plane k - 1
         sf_conv_s<HT>(Bs2[(PH + 1) & 1], Ss2[(PH + 1) & 1], wfrag, w, lane);
+#endif
       if constexpr (decltype(do_time)::value) {     // plane j = k - 2: s[j] into the ring, plane j - 2 out
         constexpr int PJ = (PH + 4) % SF_RING;
         const HT* Ss = Ss2[PH & 1];
@@ -274,10 +291,14 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __
           for (int e = 0; e < 4; e++) {
             const float s = (float)sv[e];
             // out[j + 2 - kk] += w[kk] s[j]; kk = 0 opens the slot of plane j + 2  (products and order of dwt_fwd_kernel)
+#if !(SF_EXP & 1)
             ring[(PJ + 2) % SF_RING][i][e] = wk[i][0] * s;
 #pragma unroll
             for (int kk = 1; kk < SF_KT; kk++)
               ring[(PJ + 2 - kk + SF_RING) % SF_RING][i][e] = __builtin_fmaf(wk[i][kk], s, ring[(PJ + 2 - kk + SF_RING) % SF_RING][i][e]);
+#else
+            ring[(PJ + SF_RING - 2) % SF_RING][i][e] = s;
+#endif
           }
           // plane j - 2 is complete: its last term was s[j]
           // (live: a column past Wo holds the row's last pixel in its kw = 0 taps -- stored nowhere, not a sum term)
@@ -305,7 +326,9 @@ __global__ __launch_bounds__(SF_THREADS) void stem_fwd_fused_kernel(const HT* __
           }
         }
       }
+#if !(SF_EXP & 8)
       __syncthreads();
+#endif
     };
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
