@@ -48,7 +48,7 @@ extern "C" {
 /* Version of THIS header: bumped with every incompatible change of a signature or struct.  x3d_version() returns the value
  * the library was built with; a binding must refuse a library whose version differs from the header it was written against
  * (x3d_tf_amd/hip.py does): a stale libx3d_hip.so would otherwise take shifted arguments silently. */
-#define X3D_ABI_VERSION 132
+#define X3D_ABI_VERSION 133
 int x3d_version(void);
 const char* x3d_last_error(void);
 
@@ -469,6 +469,14 @@ int x3d_tail_bwd(void* dy_g, const void* y, const void* c_raw, const void* r_raw
 int x3d_relu_bn_bwd_reduce(const void* dy, const float* dpool, const void* yraw,
                            const float* scale_shift, void* g, double* sums, int N, int C,
                            long long P, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5s even-pixel copy of a block input (ABI 133): dst [planes][ceil(H/2)][ceil(W/2)] = src [planes][H][W] at the even rows and
+ *     columns, planes = N*C*T -- the pixels the stride-(1,2,2) 'valid' shortcut conv samples (reference model.py:360-367).
+ *     With it the shortcut conv's forward, data gradient and weight gradient run as dense launches of x3d_pw_fwd /
+ *     x3d_pw_bwd / x3d_pw_wgrad on the compact tensor (stride = 1, x_stride = 0) instead of the strided gathers.
+ * ------------------------------------------------------------------------------------------ */
+int x3d_subsample2(const void* src, void* dst, long long planes, int H, int W, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7/K10  head: pool5 (GlobalAveragePooling3D of relu(bn(conv5))), fc1 (1x1x1 conv on the pooled

@@ -41,6 +41,11 @@ PW_FWD = [
     # ... whose rows are ONE gather group wide (7 -> 4, 3 -> 2: stage 5 of 112-pixel crops): the early load of the last
     # group would start before the row (before the tensor for its first row) -- these take the next smaller group
     (1, 96, 192, 8, 7, 7, 2, None), (2, 96, 192, 8, 3, 3, 2, None),
+    # round 6: the shortcut convs as DENSE launches on the even-pixel copy of the block input (x3d_subsample2): the compact planes
+    # of X3D-XS .. M (40 / 56, 28, 14, 7 wide) and X3D-L / XL (78, 39, 20, 10 wide; 32 -> 32)
+    (1, 24, 24, 2, 40, 40, 1, None), (2, 24, 24, 1, 56, 56, 1, None), (1, 24, 48, 2, 28, 28, 1, None), (2, 48, 96, 2, 14, 14, 1, None),
+    (2, 96, 192, 4, 7, 7, 1, None), (1, 24, 24, 2, 78, 78, 1, None), (1, 32, 32, 1, 78, 78, 1, None), (1, 24, 48, 2, 39, 39, 1, None),
+    (1, 48, 96, 2, 20, 20, 1, None), (1, 96, 192, 2, 10, 10, 1, None),
 ]
 # ... with the residual tail of the block below folded into the prologue (16-bit storage; prologue "tail": identity shortcut,
 # "tail_conv": shortcut conv with its own BN): x = raw c output, in_add = shortcut, in_store = the block output y
@@ -105,6 +110,10 @@ PW_WGRAD = [
     (1, 432, 192, 13, 5, 5, 1, "swish"),
     (1, 24, 48, 2, 11, 23, 2, None), (1, 32, 32, 4, 9, 27, 2, None), (1, 24, 48, 8, 13, 13, 2, None),   # strided, odd input width: vector gather
     (1, 96, 192, 8, 7, 7, 2, None), (2, 96, 192, 8, 3, 3, 2, None),   # rows one gather group wide (7 -> 4, 3 -> 2)
+    # round 6: the shortcut convs' weight gradient as a dense launch on the even-pixel copy (x3d_subsample2)
+    (1, 24, 24, 2, 40, 40, 1, None), (2, 24, 24, 1, 56, 56, 1, None), (1, 24, 48, 2, 28, 28, 1, None), (2, 48, 96, 2, 14, 14, 1, None),
+    (2, 96, 192, 4, 7, 7, 1, None), (1, 24, 48, 2, 39, 39, 1, None), (1, 48, 96, 2, 20, 20, 1, None), (1, 96, 192, 2, 10, 10, 1, None),
+    (2, 48, 96, 13, 10, 10, 1, None), (2, 24, 24, 13, 40, 40, 1, None),
 ]
 
 # ---- x3d_pw_bwd (fused dgrad + wgrad): N, Cin, Cout, T, H, W, epilogue ---------------------------------------------------
@@ -312,7 +321,7 @@ def pw_bwd_rc_struct(shape, dtype):
     from x3d_tf_amd import hip
     n, cin, cout, t, h, w, epi, tail = shape
     A = _Addr.new
-    return hip.PwBwdArgs(A(), None, None, None, A(), PW_DGRAD_EPI.index(epi), A(), None, None, None, None, A(), None, n, cin,
+    return hip.PwBwdArgs(A(), None, None, None, A(), PW_DGRAD_EPI.index(epi), None if epi == "store" else A(), None, None, None, None, A(), None, n, cin,
                          cout, t, h, w, _code(dtype), A() if tail else None, A() if tail == 2 else None, A() if tail else None,
                          A() if tail == 2 else None, A(), A(), A())
 

@@ -57,6 +57,11 @@ def _kernel_case_names():
                 st = S.pw_bwd_rc_strided_struct(shp, dt)
                 assert hip.load().x3d_pw_bwd_supported(st), f"the strided recomputed-output backward does not cover the registered case {shp}"
                 add(st, f"test_pw_bwd_rc_strided[{shp}, {dt}]")
+                # ... which also runs the DENSE store form on the even-pixel copy (the plans' path since round 6)
+                n_, ci_, co_, t_, xh_, xw_ = shp
+                st = S.pw_bwd_rc_struct((n_, ci_, co_, t_, (xh_ + 1) // 2, (xw_ + 1) // 2, "store", 0), dt)
+                if hip.load().x3d_pw_bwd_supported(st):
+                    add(st, f"test_pw_bwd_rc_strided[{shp}, {dt}, compact]")
         for shp in S.DW:
             add(S.dw_fwd_struct(shp, dt), f"test_dw3d_fwd[{shp}, {dt}]")
             add(S.dw_bwd_struct(shp, dt), f"test_dw3d_bwd[{shp}, {dt}]")
@@ -127,13 +132,15 @@ def test_inference_plan_is_inference_shaped(index):
     k0 = 1 + len(stem)
     assert names[1:k0] == stem
     blocks = m.arch.blocks
+    odd_rows = lambda b: (pl.blocks[blocks.index(b)].wo % 2) == 1      # (only where the gather takes one output per load)
     want = []
     for b in blocks:
+        # (a strided shortcut conv reads the even-pixel copy of the block input: one small copy launch in front of it)
         want += ["x3d_pw_fwd", "x3d_dw3d_fwd"] + (["x3d_se_fwd"] if b.has_se else []) + \
-                (["x3d_pw_fwd"] if b.has_shortcut_conv else []) + ["x3d_pw_fwd"]
+                ((["x3d_subsample2"] if b.stride == 2 and odd_rows(b) else []) + ["x3d_pw_fwd"] if b.has_shortcut_conv else []) + ["x3d_pw_fwd"]
     assert names[k0:k0 + len(want)] == want
     assert names[k0 + len(want):] == ["x3d_pw_fwd", "x3d_pool_fwd", "x3d_dense_fwd", "x3d_dense_fwd", "x3d_softmax_xent", "x3d_view_mean"]
-    assert len(want) <= 5 * len(blocks) and sum(3 + b.has_se + b.has_shortcut_conv for b in blocks) == len(want)
+    assert len(want) <= 6 * len(blocks) and sum(3 + b.has_se + b.has_shortcut_conv * (1 + (b.stride == 2 and odd_rows(b))) for b in blocks) == len(want)
     for B in pl.blocks:                      # the `c` conv carries the epilogue; `a` and the shortcut stay raw
         assert B.sc.out_scale_shift and B.sc.out_add and B.sc.out_act == 1 and not B.sc.stats
         assert bool(B.sc.out_add_scale_shift) == bool(B.spec.has_shortcut_conv)

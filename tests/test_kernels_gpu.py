@@ -416,6 +416,16 @@ def test_pw_bwd_rc_strided(gpu, dtype, shape):
     dw_ref = torch.einsum("nothw,ncthw->oc", dy, xs)
     tol = _wtol(dtype)
     report("dw", dw, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
+    # round 6, the plans' path: the same gradients from the DENSE store form on the even-pixel copy of x (x3d_subsample2)
+    xc = ops.subsample2(dev(x))
+    assert torch.equal(xc, dev(x)[..., ::2, ::2].contiguous())
+    dx2 = torch.empty_like(dx)
+    dw2 = torch.full((cout, cin), 0.5, dtype=torch.float32, device=gpu)
+    ok2 = ops.pw_bwd_rc(dev(gy), xc, dev(wt), dev(coef), dx2, dw2, ops.EPI_STORE, None)
+    torch.cuda.synchronize()
+    if ok2:      # (P % 8 != 0 on the compact plane: the dense form declines, the plan keeps the strided one)
+        report("dx (compact)", dx2, dx_ref, rt, at * dx_ref.abs().max().item())
+        report("dw (compact)", dw2, dw_ref + 0.5, tol, tol * dw_ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", HALF)
@@ -1083,6 +1093,26 @@ def test_stem_fused(gpu, dtype, shape):
     out_s = F.conv3d(F.pad(xd, (1, 1, 1, 1, 0, 0)), wsr.unsqueeze(2), stride=(1, 2, 2))
     (dws64,) = torch.autograd.grad((out_s * round_to(dxs.float(), dtype)).sum(), [wsr])
     report("dw_s vs fp64", dws + 0.25, dws64, 2e-4, 2e-4 * dws64.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 24, 3, 112, 112), (1, 24, 2, 56, 56), (2, 48, 3, 28, 28), (1, 96, 5, 14, 14),     # X3D-M shortcuts
+                                   (1, 32, 2, 156, 156), (1, 32, 2, 78, 78), (2, 72, 1, 39, 39), (1, 136, 3, 20, 20),   # X3D-XL / L: odd 39
+                                   (3, 5, 2, 7, 9), (1, 3, 1, 1, 1), (2, 2, 3, 40, 24)])
+def test_subsample2(gpu, dtype, shape):
+    """x3d_subsample2: the even-pixel copy a strided shortcut conv reads (reference model.py:360-367 samples pixels 0, 2, 4, ...):
+    a pure copy, so bit-exact, on every vector width the launcher picks (16 / 8 / 4-byte loads and element loads, odd extents)."""
+    ops = _ops()
+    g_ = _gen(41)
+    x, _ = rnd(shape, dtype, g_)
+    xg = x.to(gpu)
+    out = ops.subsample2(xg)
+    torch.cuda.synchronize()
+    assert torch.equal(out, xg[..., ::2, ::2].contiguous())
+    buf = torch.empty(xg.numel() + 8, dtype=dtype, device=gpu)      # a 2- / 4-byte aligned source: the narrower vector paths
+    sl = buf[1:1 + xg.numel()].view(shape)
+    sl.copy_(xg)
+    assert sl.data_ptr() % 16 != 0 and torch.equal(ops.subsample2(sl), sl[..., ::2, ::2].contiguous())
 
 
 def test_stem_fused_unsupported(gpu):

@@ -521,3 +521,68 @@ extern "C" int x3d_nthwc_to_ncthw(const void* src, int src_dtype, void* dst, int
   X3D_LAUNCH_CHECK("nthwc_to_ncthw");
   return X3D_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Even-pixel copy of a block input: dst[plane][ho][wo] = src[plane][2 ho][2 wo], Ho = ceil(H / 2), Wo = ceil(W / 2) -- the pixels
+// a stride-(1,2,2) 'valid' 1x1x1 shortcut conv samples (reference model.py:360-367).  Round 6: with this compact tensor the
+// shortcut conv's forward, data gradient and weight gradient are plain dense launches (16-byte coalesced rows) instead of the
+// strided gathers, whose rows of 7 / 14 outputs took one output per 4-byte load (96 -> 192 @14^2: 68 us for 29 MB).
+// One thread = VEC consecutive outputs of an output row: 2 * VEC input elements in one aligned load (VEC = 8 / 4 / 2), or
+// element loads (odd widths).
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst, int H, int W, int Ho, int Wo,
+                                                         long long rows /* planes * Ho */) {
+  const int vpr = (Wo + VEC - 1) / VEC;                       // vectors per output row (VEC > 1: Wo % VEC == 0, host check)
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= rows * vpr) return;
+  const long long row = v / vpr;
+  const int wo0 = (int)(v - row * vpr) * VEC;
+  const long long plane = row / Ho;
+  const int ho = (int)(row - plane * Ho);
+  const T* s = src + (plane * H + 2 * ho) * (long long)W + 2 * wo0;
+  T* d = dst + row * Wo + wo0;
+  if constexpr (VEC == 1) {
+    d[0] = s[0];
+  } else {
+    typedef __attribute__((ext_vector_type(2 * VEC))) T in_t;
+    typedef __attribute__((ext_vector_type(VEC))) T out_t;
+    const in_t a = *(const in_t*)s;
+    out_t o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o[e] = a[2 * e];
+    *(out_t*)d = o;
+  }
+}
+
+template <typename T>
+static void subsample2_launch(const void* src, void* dst, long long planes, int H, int W, hipStream_t st) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long long rows = planes * Ho;
+  int vec = 1;
+  // 2 * vec input elements per load: rows of whole loads (W % (2 vec) == 0), both tensors aligned for their vector
+  for (int v = 16 / (int)sizeof(T); v >= 2; v >>= 1)
+    if ((W % (2 * v)) == 0 && ((uintptr_t)src % (2 * v * sizeof(T))) == 0 && ((uintptr_t)dst % (v * sizeof(T))) == 0) { vec = v; break; }
+  const long long nv = rows * ((Wo + vec - 1) / vec);
+  const unsigned grid = (unsigned)ceil_div_ll(nv, 256);
+#define SS2(V) hipLaunchKernelGGL((subsample2_kernel<T, V>), dim3(grid), dim3(256), 0, st, (const T*)src, (T*)dst, H, W, Ho, Wo, rows)
+  switch (vec) {
+    case 8: if constexpr (sizeof(T) == 2) { SS2(8); } break;
+    case 4: SS2(4); break;
+    case 2: SS2(2); break;
+    default: SS2(1); break;
+  }
+#undef SS2
+}
+
+extern "C" int x3d_subsample2(const void* src, void* dst, long long planes, int H, int W, int dtype, void* stream) {
+  X3D_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0, "subsample2: bad args");
+  X3D_REQUIRE(x3d_dtype_ok(dtype), "subsample2: bad dtype");
+  X3D_REQUIRE(ceil_div_ll(planes * ((H + 1) / 2) * ((W + 1) / 2), 256) < (1ll << 31), "subsample2: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == X3D_F32) subsample2_launch<float>(src, dst, planes, H, W, st);
+  else subsample2_launch<unsigned short>(src, dst, planes, H, W, st);      // (a copy: the 16-bit types move as bits)
+  X3D_LAUNCH_CHECK("subsample2");
+  return X3D_OK;
+}

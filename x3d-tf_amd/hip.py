@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X3D_HIP_LIB") or os.path.join(_HERE, "libx3d_hip.so")   # X3D_HIP_LIB: A/B builds (tools/build_variant.sh)
 
-ABI_VERSION = 132   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
+ABI_VERSION = 133   # X3D_ABI_VERSION of the include/x3d_hip.h the signatures below were written against
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 EPI_STORE, EPI_ADD, EPI_ADD_STRIDED, EPI_SWISH_BWD = 0, 1, 2, 3
@@ -169,6 +169,7 @@ _SIGS = {
     "x3d_tail_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
     "x3d_relu_bn_bwd_reduce": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
     "x3d_pool_fwd": ([_vp, _vp, _vp, _i, _i, _ll, _i, _vp], _i),
+    "x3d_subsample2": ([_vp, _vp, _ll, _i, _i, _i, _vp], _i),
     "x3d_dense_fwd": ([_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "x3d_dense_bwd": ([_vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "x3d_softmax_xent": ([_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp], _i),

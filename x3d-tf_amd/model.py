@@ -115,6 +115,8 @@ PLAN_DEFAULTS = {
     "pw_bwd_rc_wide": True,    # ... also for the 48 -> 216 layer
     "stem_nthwc": True,        # the stem reads the caller's channels-last batch in place (16-bit storage)
     "stem_fused": True,        # ... and runs conv_s -> conv_t as ONE launch each way (x3d_stem_fwd / x3d_stem_bwd): no s_raw, no ds
+    "shortcut_compact": True,  # strided shortcut convs whose output rows are odd (7, 39, 5 wide: one output per 4-byte load in the
+                               #   gather) read an even-pixel copy of the block input instead (x3d_subsample2): dense launches
     "infer_train_plan": False,  # training-shaped launch list at inference
     "bn_fold": False,          # BatchNorm finalize inside the depthwise / tail consumer (x3d_bn_fold)
     "tail_fwd_fold": True,     # residual tail built on load by the next block's `a` conv
@@ -129,7 +131,7 @@ PLAN_DEFAULTS = {
 _ENV_OPTIONS = {   # historical switch -> (option, value the variable's non-default setting selects)
     "X3D_NO_FUSED_PW_BWD": ("fused_pw_bwd", "1", False), "X3D_PW_BWD_RC": ("pw_bwd_rc", "0", False),
     "X3D_PW_BWD_RC_MERGE": ("pw_bwd_rc_merge", "0", False), "X3D_PW_BWD_RC_WIDE": ("pw_bwd_rc_wide", "0", False),
-    "X3D_NO_STEM_NTHWC": ("stem_nthwc", "1", False), "X3D_NO_STEM_FUSED": ("stem_fused", "1", False), "X3D_INFER_TRAIN_PLAN": ("infer_train_plan", "1", True),
+    "X3D_NO_STEM_NTHWC": ("stem_nthwc", "1", False), "X3D_NO_STEM_FUSED": ("stem_fused", "1", False), "X3D_NO_SHORTCUT_COMPACT": ("shortcut_compact", "1", False), "X3D_INFER_TRAIN_PLAN": ("infer_train_plan", "1", True),
     "X3D_BN_FOLD": ("bn_fold", "1", True), "X3D_NO_TAIL_FWD_FOLD": ("tail_fwd_fold", "1", False),
     "X3D_NO_TAIL_FOLD_WST": ("tail_fold_wst", "1", False), "X3D_NO_TAIL_FOLD": ("tail_bwd_fold", "1", False),
     "X3D_NO_STEM_BWD_FOLD": ("stem_bwd_fold", "1", False), "X3D_SIDE_WGRAD": ("side_wgrad", "1", True),
@@ -682,8 +684,15 @@ class X3D:
             if b.has_shortcut_conv:
                 B.r_raw = view(rbuf, n, b.cout, t, ho, wo)
                 B.bn_r = bn_coef(f"{pre}/bn_r", b.cout)
-                sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
-                                   n, b.cin, b.cout, t, hh, ww, b.stride, dt)
+                if b.stride == 2 and wo % 2 == 1 and self.opt["shortcut_compact"]:
+                    # the pixels the strided conv samples, copied once: the conv itself is a dense launch on them
+                    B.xs = pl.act(n, b.cin, t, ho, wo)
+                    pl.rec(F, "x3d_subsample2", x_cur, B.xs, n * b.cin * t, hh, ww, dt)
+                    sr = hip.PwFwdArgs(_p(B.xs), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                       n, b.cin, b.cout, t, ho, wo, 1, dt)
+                else:
+                    sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                       n, b.cin, b.cout, t, hh, ww, b.stride, dt)
                 sr.w_panel = self._wp(f"{pre}/residual/kernel")
                 B.sr = sr
                 pl.rec(F, "x3d_pw_fwd", sr)
@@ -897,8 +906,20 @@ class X3D:
             if b.has_shortcut_conv:
                 B.r_raw = pl.act(n, b.cout, t, ho, wo)
                 B.bn_r = bn_bufs(f"{pre}/bn_r", b.cout)
-                sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
-                                   n, b.cin, b.cout, t, hh, ww, b.stride, dt)
+                B.xs = None
+                if b.stride == 2 and wo % 2 == 1 and self.opt["shortcut_compact"]:
+                    # the pixels the strided conv samples (reference model.py:360-367), copied once per step: the conv's forward and
+                    # both of its gradients are then dense launches -- 16-byte coalesced rows instead of one output per 4-byte load.
+                    # Only where the gather is at its worst (odd output rows): measured per launch on X3D-M (profiles/
+                    # r06_ab_shortcut_compact.txt) the copy costs what the dense launches save at 112 / 56 / 28-wide inputs
+                    # (108 + 39 + 25 us against -111 / -43 / -32) and a quarter of it at 14 -> 7 (15 against -68)
+                    B.xs = pl.act(n, b.cin, t, ho, wo)
+                    pl.rec(F, "x3d_subsample2", x_cur, B.xs, n * b.cin * t, hh, ww, dt)
+                    sr = hip.PwFwdArgs(_p(B.xs), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                       n, b.cin, b.cout, t, ho, wo, 1, dt)
+                else:
+                    sr = hip.PwFwdArgs(_p(x_cur), _p(p[f"{pre}/residual/kernel"]), _p(B.r_raw), None, None, None, ACT_NONE,
+                                       n, b.cin, b.cout, t, hh, ww, b.stride, dt)
                 sr.w_panel = self._wp(f"{pre}/residual/kernel")
                 B.sr = sr
                 pl.rec(F, "x3d_pw_fwd", ("stats", sr, B.bn_r.stats))
@@ -1222,11 +1243,16 @@ class X3D:
                 sr = None
                 per = int(pl.lib.x3d_pw_bwd_rc_panel_elems(b.cout, b.cin)) if (self._fuse_pw_bwd and self._rc_pw_bwd and b.stride == 2
                                                                                 and self.dtype != torch.float32) else 0
+                xs = getattr(B, "xs", None)       # the even-pixel copy of B.x the forward pass made (option shortcut_compact)
                 if per:
                     rcr = (pl.act(per), pl.f32(b.cin), pl.acc64((int(pl.lib.x3d_pw_bwd_rc_sums_elems(b.cout, b.cin)) + 1) // 2))
-                    sr = hip.PwBwdArgs(_p(gten), None, None, None, _p(rt), EPI_STORE, None, None, None, None, None, _p(B.x), None,
-                                       n, b.cin, b.cout, t, B.ho, B.wo, dt, None, None, None, None, _p(rcr[0]), _p(rcr[1]), None,
-                                       b.stride, B.hh, B.ww)
+                    if xs is not None:
+                        sr = hip.PwBwdArgs(_p(gten), None, None, None, _p(rt), EPI_STORE, None, None, None, None, None, _p(xs), None,
+                                           n, b.cin, b.cout, t, B.ho, B.wo, dt, None, None, None, None, _p(rcr[0]), _p(rcr[1]), None)
+                    else:
+                        sr = hip.PwBwdArgs(_p(gten), None, None, None, _p(rt), EPI_STORE, None, None, None, None, None, _p(B.x), None,
+                                           n, b.cin, b.cout, t, B.ho, B.wo, dt, None, None, None, None, _p(rcr[0]), _p(rcr[1]), None,
+                                           b.stride, B.hh, B.ww)
                     if not pl.lib.x3d_pw_bwd_supported(C.byref(sr)):
                         sr = None
                 B.r_bwd_rc = sr is not None
@@ -1244,8 +1270,12 @@ class X3D:
                     else:
                         pl.rec(Bk, "x3d_pw_bwd_rc_finish", ("acc", rcr[2]), w_r, B.bn_r.coef, g_r, b.cout, b.cin, dt)
                 else:
-                    wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
-                                         _p(g_r), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
+                    if xs is not None:
+                        wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(xs), None, None, ACT_NONE,
+                                             _p(g_r), n, b.cin, b.cout, t, B.ho, B.wo, 1, dt)
+                    else:
+                        wr = hip.PwWgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(B.x), None, None, ACT_NONE,
+                                             _p(g_r), n, b.cin, b.cout, t, B.hh, B.ww, b.stride, dt)
                     dr = hip.PwDgradArgs(_p(gten), _p(B.r_raw), _p(B.bn_r.coef), _p(w_r), _p(rt),
                                          EPI_STORE, None, None, None, None, None, n, b.cin, b.cout, t, B.ho, B.wo, dt)
                     dr.w_panel = self._wp(f"{pre}/residual/kernel", True)

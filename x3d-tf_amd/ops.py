@@ -491,3 +491,13 @@ def nthwc_to_ncthw(src, dst):
     hip.call("x3d_nthwc_to_ncthw", ptr(src), hip.dtype_code(src.dtype), ptr(dst),
              hip.dtype_code(dst.dtype), n, c, t * h * w)
     return dst
+
+
+def subsample2(x, out=None):
+    """Even-pixel copy x[..., ::2, ::2] of an NCTHW tensor (x3d_subsample2): what a stride-(1,2,2) shortcut conv samples."""
+    _chk(x, out)
+    n, c, t, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c, t, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device)
+    hip.call("x3d_subsample2", ptr(x), ptr(out), n * c * t, h, w, hip.dtype_code(x.dtype))
+    return out
