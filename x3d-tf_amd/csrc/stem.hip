@@ -389,6 +389,79 @@ __global__ __launch_bounds__(256) void stem_s_wgrad_kernel(const T* __restrict__
 }
 
 
+// ---- the same tile without the per-element index arithmetic (round 6: fp32 storage, and 16-bit rows that are not whole vectors) ----
+// The generic kernel above walks the flattened points of a sample and pays two integer divisions and a bounds test per gathered
+// element (548 us per X3D-S fp32 step, 3 % of BASELINE config 2).  Here a step is ONE segment of 64 consecutive output columns of
+// one output row (n, t, ho): the decomposition is per step and wave-uniform, a tap row (ci, kh, kw) of the im2col tile is the
+// input row 2 ho + kh - 1 at the columns 2 wo + kw - 1 -- a base pointer and a stride of two elements.  The four waves split the
+// 64 points of a step between them as above (exact fp32 products on v_mfma_f32_32x32x2_f32), one atomic flush per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_s_wgrad_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* dw, int Cin,
+                                                                int Cout, int Tn, int H, int W, int Ho, int Wo, int nws,
+                                                                int total_segs, int segs_per_block) {
+  constexpr int LP = 65;
+  __shared__ float smem[2 * 32 * LP];      // one array: both tiles end as the [4][32][32] reduction buffer
+  static_assert(2 * 32 * LP >= 4 * 32 * 32, "reduction buffer");
+  float* const As = smem;                  // dY     [co][p]
+  float* const Bs = smem + 32 * LP;        // im2col [tap][p]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int ntap = Cin * 9;
+  const int seg_begin = blockIdx.x * segs_per_block, seg_end = min(seg_begin + segs_per_block, total_segs);
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc[j] = 0.f;
+  // this thread's items of a step: rows row0 + 4 i (i = 0 .. 7) of both tiles, point pp
+  const int pp = tid & 63, row0 = tid >> 6;
+  float av[8], bv[8];
+  auto load_seg = [&](int seg) {      // this thread's 8 + 8 elements of a segment (zeros outside the image / past the last segment)
+    const int ws = seg % nws;
+    int tmp = seg / nws;
+    const int ho = tmp % Ho; tmp /= Ho;
+    const int t = tmp % Tn;
+    const int n = tmp / Tn;
+    const int wo = ws * 64 + pp;
+    const bool pin = wo < Wo && seg < seg_end;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int row = row0 + 4 * i;
+      av[i] = 0.f; bv[i] = 0.f;
+      if (pin && row < Cout) av[i] = to_f<T>(dy[((((long long)n * Cout + row) * Tn + t) * Ho + ho) * Wo + wo]);
+      if (pin && row < ntap) {
+        const int ci = row / 9, k = row - ci * 9, kh = k / 3, kw = k - kh * 3;      // (row = a loop constant + the wave index: cheap)
+        const int hi = 2 * ho + kh - 1, wi = 2 * wo + kw - 1;
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) bv[i] = to_f<T>(x[((((long long)n * Cin + ci) * Tn + t) * H + hi) * W + wi]);
+      }
+    }
+  };
+  if (seg_begin < seg_end) load_seg(seg_begin);
+  for (int seg = seg_begin; seg < seg_end; ++seg) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      As[(row0 + 4 * i) * LP + pp] = av[i];
+      Bs[(row0 + 4 * i) * LP + pp] = bv[i];
+    }
+    __syncthreads();
+    load_seg(seg + 1);              // in flight behind this segment's products
+    const float* ap = As + r * LP + wid * 16 + half;
+    const float* bp = Bs + r * LP + wid * 16 + half;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+  }
+  // D[row = co][col = tap]: the four waves' partial tiles meet in LDS, one atomic per (co, tap)
+  __syncthreads();
+  float* Ds = smem;              // [4][32][32]
+#pragma unroll
+  for (int j = 0; j < 16; j++) Ds[(wid * 32 + (j & 3) + 8 * (j >> 2) + 4 * half) * 32 + r] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int co = i >> 5, tap = i & 31;
+    if (co < Cout && tap < ntap) atomicAdd(&dw[co * ntap + tap], Ds[i] + Ds[1024 + i] + Ds[2048 + i] + Ds[3072 + i]);
+  }
+}
+
 // ---- bf16 fast path of the stem weight gradient ------------------------------------------------
 // The generic kernel above gathers every im2col element with two integer divisions and a 2-byte load; it is
 // instruction bound (1.39 ms on X3D-M B=64 against ~0.25 ms of HBM time).  Here a step is SEGS segments of
@@ -569,6 +642,22 @@ extern "C" int x3d_stem_s_wgrad(const void* x, const void* dy, float* dw, int N,
 #undef STEM_WG
     X3D_LAUNCH_CHECK("stem_s_wgrad");
     return X3D_OK;
+  }
+  {
+    // row segments (round 6): 2-3 workgroups per CU, an equal share of the segments each
+    const int nws = ceil_div(Wo, 64);
+    const long long total_segs = (long long)N * T * Ho * nws;
+    if (total_segs < (1ll << 31) && x3d_env_int("X3D_STEM_WGRAD_ROWS", 1) != 0) {      // X3D_STEM_WGRAD_ROWS=0: A/B hook (the flattened-point kernel)
+      long long spb2 = ceil_div_ll(total_segs, 3ll * x3d_device_cus());
+      if (spb2 < 8) spb2 = 8;
+      const long long gx2 = ceil_div_ll(total_segs, spb2);
+#define STEM_WGR(TT) hipLaunchKernelGGL((stem_s_wgrad_rows_kernel<TT>), dim3((unsigned)gx2), dim3(256), 0, st, (const TT*)x, (const TT*)dy, dw, \
+                                        Cin, Cout, T, H, W, Ho, Wo, nws, (int)total_segs, (int)spb2)
+      if (dtype == X3D_F32) STEM_WGR(float); else if (dtype == X3D_F16) STEM_WGR(f16); else STEM_WGR(bf16);
+#undef STEM_WGR
+      X3D_LAUNCH_CHECK("stem_s_wgrad");
+      return X3D_OK;
+    }
   }
   if (dtype == X3D_F32)
     hipLaunchKernelGGL((stem_s_wgrad_kernel<float>), dim3((unsigned)gx), dim3(256), 0, st, (const float*)x,
