@@ -14,6 +14,9 @@ g = torch.Generator(device=dev).manual_seed(0)
 for name, cin, cout, t, h, w, kind in [("a bwd s5", 192, 432, 13, 5, 5, "dgrad_add"), ("c bwd s5", 432, 192, 13, 5, 5, "dgrad_swish"),
                                         ("a bwd s4", 96, 216, 13, 10, 10, "dgrad_add"), ("c bwd s4", 216, 96, 13, 10, 10, "dgrad_swish"),
                                         ("c fwd s5", 432, 192, 13, 5, 5, "fwd_swish"), ("a fwd s5", 192, 432, 13, 5, 5, "fwd"),
+                                        ("c fwd s4", 216, 96, 13, 10, 10, "fwd_swish"), ("a fwd s4", 96, 216, 13, 10, 10, "fwd"),
+                                        ("c fwd s3", 108, 48, 13, 20, 20, "fwd_swish"), ("a fwd s3", 48, 108, 13, 20, 20, "fwd"),
+                                        ("c bwd s3", 108, 48, 13, 20, 20, "dgrad_swish"), ("a bwd s3", 48, 108, 13, 20, 20, "dgrad_add"),
                                         ("c bwd s2", 54, 24, 13, 40, 40, "dgrad_swish"), ("a bwd s2", 24, 54, 13, 40, 40, "dgrad_add")]:
     wt = torch.randn((cout, cin), generator=g, device=dev) * 0.1
     if kind.startswith("dgrad"):

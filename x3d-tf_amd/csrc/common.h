@@ -556,6 +556,14 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// the same sum on DPP adds only (the form above is five ds_bpermute round trips PER VALUE, each waited for: the 32 sums at the end
+// of an fp32 pointwise tile walk were ~18,000 cycles of a 64,000-cycle workgroup, in-kernel stamps profiles/r06_f32p_stamps.txt):
+// valid in the UPPER 16 lanes of each half (lane & 16), i.e. lanes 16-31 hold the sum of lanes 0-31, lanes 48-63 that of 32-63
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+  v = row16_sum(v);
+  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: lane 15 of the row below
+  return v;
+}
 
 // block-wide sum of NV floats per thread; result valid in thread 0.  scratch: >= NV * (blockDim/64) floats.
 template <int NV>

@@ -1,11 +1,18 @@
 // x3d_pw_dgrad: pointwise convolution data gradient (see pw_gemm.h)
 #include "pw_gemm_wst.h"
-#include "pw_gemm_f32r.h"
+#include "pw_gemm_f32p.h"
 
 template <typename T>
 static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
-  {   // fp32 storage: weights resident in LDS (pw_gemm_f32r.h) where the block fits
+  {   // fp32 storage: weights resident in LDS, pipelined activation stream (pw_gemm_f32p.h) where the block fits
     int rc = -1;
+    switch (epi) {
+      case X3D_EPI_STORE: rc = f32p_try<PRO_BNBWD, X3D_EPI_STORE>(a, st); break;
+      case X3D_EPI_ADD: rc = f32p_try<PRO_BNBWD, X3D_EPI_ADD>(a, st); break;
+      case X3D_EPI_ADD_STRIDED: rc = f32p_try<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, st); break;
+      case X3D_EPI_SWISH_BWD: rc = f32p_try<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st); break;
+    }
+    if (rc >= 0) return rc;
     switch (epi) {
       case X3D_EPI_STORE: rc = f32r_try<PRO_BNBWD, X3D_EPI_STORE>(a, vec, st); break;
       case X3D_EPI_ADD: rc = f32r_try<PRO_BNBWD, X3D_EPI_ADD>(a, vec, st); break;

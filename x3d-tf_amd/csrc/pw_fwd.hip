@@ -1,6 +1,6 @@
 // x3d_pw_fwd: pointwise convolution forward (see pw_gemm.h)
 #include "pw_gemm_wst.h"
-#include "pw_gemm_f32r.h"
+#include "pw_gemm_f32p.h"
 
 template <typename H>
 static int pw_fwd_h16(PwGemmArgs& a, int vec, int ovec, bool pro, hipStream_t st) {
@@ -67,7 +67,8 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     if (((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->in_add % 16) == 0 && ((uintptr_t)f->in_store % 16) == 0 &&
         ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) v16 = ot = 8;
     if (f->dtype == X3D_F32) {
-      const int rc = f->in_add ? f32r_try<PRO_TAIL, EPI_STATS>(a, 4, st) : f32r_try<PRO_AFFST, EPI_STATS>(a, 4, st);
+      int rc = f->in_add ? f32p_try<PRO_TAIL, EPI_STATS>(a, st) : f32p_try<PRO_AFFST, EPI_STATS>(a, st);
+      if (rc < 0) rc = f->in_add ? f32r_try<PRO_TAIL, EPI_STATS>(a, 4, st) : f32r_try<PRO_AFFST, EPI_STATS>(a, 4, st);
       X3D_REQUIRE(rc >= 0, "pw_fwd: folded tail in fp32 storage: layer not covered by the resident-weights kernel");
       return rc;
     }
@@ -89,7 +90,8 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
   X3D_REQUIRE(!f->out_add && !f->out_add_scale_shift, "pw_fwd: out_add needs out_scale_shift");
   if (f->dtype == X3D_F32) {
     // weights resident in LDS, activations double-buffered (pw_gemm_f32r.h); the strided shortcut keeps the per-tile kernel
-    const int rc = pro ? f32r_try<PRO_AFFINE, EPI_STATS>(a, vec, st) : f32r_try<PRO_NONE, EPI_STATS>(a, vec, st);
+    int rc = pro ? f32p_try<PRO_AFFINE, EPI_STATS>(a, st) : f32p_try<PRO_NONE, EPI_STATS>(a, st);
+    if (rc < 0) rc = pro ? f32r_try<PRO_AFFINE, EPI_STATS>(a, vec, st) : f32r_try<PRO_NONE, EPI_STATS>(a, vec, st);
     if (rc >= 0) return rc;
     return pro ? pw_launch_vec<float, PRO_AFFINE, EPI_STATS>(a, vec, st)
                : pw_launch_vec<float, PRO_NONE, EPI_STATS>(a, vec, st);

@@ -393,10 +393,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwGemmArgs a) {
         const int mt = id / NT;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          const float s1 = half_wave_sum(st1[s][j]);
-          const float s2 = half_wave_sum(st2[s][j]);
+          const float s1 = half_wave_sum_hi(st1[s][j]);
+          const float s2 = half_wave_sum_hi(st2[s][j]);
           const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-          if (r == 0 && m < a.M) {
+          if (r == 16 && m < a.M) {
             if constexpr (EPI == EPI_STATS) {
               if (a.stats) {
                 double* sp = stats_replica(a.stats, a.M, blockIdx.x);

@@ -17,6 +17,9 @@
 
 #define F32R_THREADS 512
 #define F32R_KC 32
+#ifndef F32R_EXP
+#define F32R_EXP 0    // timing experiments (tools/ab_f32r_parts.sh; results WRONG unless 0): 1 no MFMA, 2 no weight load, 4 no epilogue stores, 8 no activation loads, 16 no statistics atomics, 32 no commit, 64 no epilogue
+#endif
 
 __host__ __device__ static inline int f32r_wpitch(int K) { return (((K + F32R_KC - 1) / F32R_KC) * F32R_KC) | 1; }
 static inline size_t f32r_lds_bytes(int K, int MT, int NT) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
 
   // ---- the weight block, once: Ws[m][k] = w(k, m0 + m), zero padding; walked along the contiguous axis of w, four elements
   // per load where rows allow it (a 64 x 432 block is 110 KB: in scalar rounds of 8 loads its latency was ~15 us per workgroup)
-  {
+  if (!(F32R_EXP & 2)) {
     const int total = BM * Kp;
     const bool vec4 = a.wsk == 1 ? ((a.K & 3) == 0 && (a.wsm & 3) == 0) : (a.wsm == 1 && (a.M & 3) == 0 && (a.wsk & 3) == 0);
     if (vec4 && (((uintptr_t)a.w) & 15) == 0) {
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
       const long long p = p0 + (long long)(v % VPR) * VEC;
 #pragma unroll
       for (int e = 0; e < VEC; e++) { xr[i][e] = 0.f; if constexpr (TWO) yr[i][e] = 0.f; }
-      if (k < a.K && p < a.P) {
+      if (!(F32R_EXP & 8) && k < a.K && p < a.P) {
         if (VEC == 1 || p + VEC <= a.P) {
           // (rows of P % 4 != 0 points -- 13 frames of 5 x 5 -- start at any 4-byte address: the compute queues run in unaligned
           // access mode, so the 16-byte loads stay; the scalar staging form took twice the time per chunk)
@@ -233,10 +236,10 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
           const int mt = id / NT;
 #pragma unroll
           for (int j = 0; j < 16; j++) {
-            const float s1 = half_wave_sum(st1[s][j]);
-            const float s2 = half_wave_sum(st2[s][j]);
+            const float s1 = half_wave_sum_hi(st1[s][j]);
+            const float s2 = half_wave_sum_hi(st2[s][j]);
             const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-            if (r == 0 && m < a.M) {
+            if (r == 16 && m < a.M) {
               double* d = a.nc_sums + ((long long)n * a.M + m) * 2;
               atomic_add_d(d, (double)s1);
               atomic_add_d(d + 1, (double)s2);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
 
     for (int kc = 0; kc < nchunks; ++kc, ++step) {
       float* buf = Xs + (step & 1) * KC * BN;
-      commit(tile, kc, buf);
+      if (!(F32R_EXP & 32)) commit(tile, kc, buf);
       __syncthreads();                  // chunk visible; every wave is past the MFMAs of the chunk that used the other buffer
       {                                 // next chunk (of this tile or of the next one) flies under the MFMAs
         int nt_ = tile, nk = kc + 1;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
           const float* wp = Ws + (mt * 32 + r) * WP + k0 + half;
           const float* xp = buf + half * BN + nt * 32 + r;
 #pragma unroll 8
-          for (int kk = 0; kk < KC; kk += 2) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[kk], xp[kk * BN], acc[s], 0, 0, 0);
+          for (int kk = (F32R_EXP & 1) ? KC - 2 : 0; kk < KC; kk += 2) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[kk], xp[kk * BN], acc[s], 0, 0, 0);
         }
       }
     }
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       const int id = wid + NW * s;
+      if ((F32R_EXP & 64) && acc[s][0] != 12345.f) continue;
       if (id < NTILE) {
         const int mt = id / NT, nt = id - mt * NT;
         const long long p = p0 + nt * 32 + r;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
           const long long o = ((long long)n * a.M + m) * a.P + p;
           if constexpr (EPI == EPI_STATS) {
             if (ok) {
-              ((T*)a.y)[o] = val;
+              if (!(F32R_EXP & 4) || val == 12345.f) ((T*)a.y)[o] = val;
               st1[s][j] += val;
               st2[s][j] += val * val;
             }
@@ -366,22 +370,33 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32r_kernel(const PwGemmArgs 
   flush_nc(n_cur);
 
   if constexpr (EPI == EPI_STATS) {
+    // the NT waves of a row block hold partial sums of the same channels: added up in LDS (in double, as the atomics would), then
+    // ONE pair of atomics per channel and workgroup (the per-wave flush was 4 x the atomics on 32 copies of a few hundred
+    // addresses: 10-17 us of a 55-75 us launch, profiles/r06_ab_f32r_parts.txt)
+    float* red = Xs;                    // [NT][BM][2], free once every wave is past its last MFMA
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       const int id = wid + NW * s;
       if (id < NTILE) {
-        const int mt = id / NT;
+        const int mt = id / NT, nt = id - mt * NT;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          const float s1 = half_wave_sum(st1[s][j]);
-          const float s2 = half_wave_sum(st2[s][j]);
-          const int m = m0 + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-          if (r == 0 && m < a.M && a.stats) {
-            double* sp = stats_replica(a.stats, a.M, blockIdx.x);
-            atomic_add_d(&sp[m * 2], (double)s1);
-            atomic_add_d(&sp[m * 2 + 1], (double)s2);
-          }
+          const float s1 = half_wave_sum_hi(st1[s][j]);
+          const float s2 = half_wave_sum_hi(st2[s][j]);
+          const int ml = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+          if (r == 16) { red[(nt * BM + ml) * 2] = s1; red[(nt * BM + ml) * 2 + 1] = s2; }
         }
+      }
+    }
+    __syncthreads();
+    if (tid < BM * 2 && a.stats && !(F32R_EXP & 16)) {
+      const int ml = tid >> 1, q = tid & 1, m = m0 + ml;
+      if (m < a.M) {
+        double t = 0.0;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) t += (double)red[(nt * BM + ml) * 2 + q];
+        atomic_add_d(&stats_replica(a.stats, a.M, blockIdx.x)[m * 2 + q], t);
       }
     }
   }
@@ -400,7 +415,7 @@ static inline bool f32r_shape(const PwGemmArgs& a, int max_mt, int* MT, int* NT)
   if (mt > max_mt) mt = max_mt;
   for (; mt >= 1; mt--) {
     const int nt = mt == 1 ? 8 : 4;
-    if (f32r_lds_bytes(a.K, mt, nt) <= 150 * 1024) { *MT = mt; *NT = nt; return true; }
+    if (f32r_lds_bytes(a.K, mt, nt) <= 160 * 1024) { *MT = mt; *NT = nt; return true; }   // (K = 432: 64 rows x 449 + the two chunk buffers = 152 KB)
   }
   return false;
 }
