@@ -13,6 +13,7 @@ static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
       case X3D_EPI_SWISH_BWD: rc = f32p_try<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st); break;
     }
     if (rc >= 0) return rc;
+    X3D_REQUIRE(!a.fold.sums, "pw_dgrad: coef_fold is not taken by the kernel behind this call (x3d_pw_coef_fold_supported() == 0)");
     switch (epi) {
       case X3D_EPI_STORE: rc = f32r_try<PRO_BNBWD, X3D_EPI_STORE>(a, vec, st); break;
       case X3D_EPI_ADD: rc = f32r_try<PRO_BNBWD, X3D_EPI_ADD>(a, vec, st); break;
@@ -70,7 +71,6 @@ extern "C" int x3d_pw_dgrad(const x3d_pw_dgrad_args* d, void* stream) {
   X3D_REQUIRE(d && d->g && d->w && d->dx, "pw_dgrad: null pointer");
   X3D_REQUIRE((d->coef || d->coef_fold) && d->yraw, "pw_dgrad: coef (or coef_fold) / yraw required (every conv on the path feeds a BN)");
   X3D_REQUIRE(x3d_describe.out || bn_bwd_fold_ok(d->coef_fold), "pw_dgrad: incomplete coef_fold");
-  X3D_REQUIRE(!d->coef_fold || d->dtype != X3D_F32, "pw_dgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
   X3D_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0 && d->H > 0 && d->W > 0,
               "pw_dgrad: bad extents");
   X3D_REQUIRE(x3d_dtype_ok(d->dtype), "pw_dgrad: bad dtype");
@@ -117,5 +117,7 @@ extern "C" int x3d_pw_coef_fold_supported(const x3d_pw_dgrad_args* dgrad, const 
   static const char* const ok[] = {"pw_bwd_wst_kernel<", "pw_bwd_wsta_kernel<", "pw_wgrad_bf16_v2_kernel<"};
   for (const char* p : ok) if (strncmp(name, p, strlen(p)) == 0) return 1;
   if (strncmp(name, "pw_gemm_wst_kernel<", 19) == 0) return dgrad != nullptr;
+  if (strncmp(name, "pw_f32p_kernel<", 15) == 0) return dgrad != nullptr;          // fp32 storage: the pipelined data-gradient kernel ...
+  if (strncmp(name, "pw_wgrad_f32r_kernel<", 21) == 0) return wgrad != nullptr;    // ... and the tile-group weight-gradient kernel
   return 0;
 }

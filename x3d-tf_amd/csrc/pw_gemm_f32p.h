@@ -132,7 +132,8 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
           c0 = a.coef[k * 2]; c1 = a.coef2 ? a.coef2[k * 2] : 1.0f;
           c2 = a.coef[k * 2 + 1] + (a.coef2 ? a.coef2[k * 2 + 1] : 0.f);
         } else {
-          c0 = a.coef[k * 4]; c1 = a.coef[k * 4 + 1]; c2 = a.coef[k * 4 + 2];
+          // (coef_fold: derived from the BatchNorm-backward sums; workgroup 0 publishes dgamma / dbeta / the table)
+          bn_bwd_coef_load(a.coef, a.fold, k, blockIdx.x == 0, c0, c1, c2);
         }
       }
       Pk[k * 4] = c0; Pk[k * 4 + 1] = c1; Pk[k * 4 + 2] = c2;

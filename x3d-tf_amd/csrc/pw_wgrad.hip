@@ -260,15 +260,15 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
   // its grid -- so the dispatch is not run a second time in query mode on every replayed step (round 5 did)
   X3D_REQUIRE(!w->dw_slab || ((uintptr_t)w->dw_slab % 16) == 0, "pw_wgrad: dw_slab must be 16-byte aligned");
   if (w->dtype == X3D_F32) {
-    X3D_REQUIRE(!w->coef_fold, "pw_wgrad: coef_fold is not taken by the fp32 kernels (x3d_pw_coef_fold_supported() == 0)");
     if (a.stride == 1 && a.P >= 4 && x3d_env_int("X3D_PW_F32R", 1) != 0) {      // tile groups of <= 8, long double-buffered runs (pw_wgrad_f32r.h)
       PwWgradRArgs ra;
       memset(&ra, 0, sizeof(ra));
-      ra.g = a.g; ra.yraw = a.yraw; ra.coef = a.coef; ra.x = a.x; ra.xcoef = a.xcoef; ra.xgate = a.xgate; ra.xact = a.xact;
+      ra.g = a.g; ra.yraw = a.yraw; ra.coef = a.coef; ra.fold = a.fold; ra.x = a.x; ra.xcoef = a.xcoef; ra.xgate = a.xgate; ra.xact = a.xact;
       ra.dw = a.dw; ra.slab = a.slab; ra.slab_parts = a.slab_parts; ra.N = a.N; ra.Cout = a.Cout; ra.Cin = a.Cin; ra.P = a.P;
       const int rc = xpro ? wgrad_f32r_pick<true>(ra, st) : wgrad_f32r_pick<false>(ra, st);
       if (rc >= 0) return rc;
     }
+    X3D_REQUIRE(!w->coef_fold, "pw_wgrad: coef_fold is not taken by the generic fp32 kernel (x3d_pw_coef_fold_supported() == 0)");
     if (x3d_parts_query) return X3D_OK;     // (query mode: the generic fp32 kernel has no slab form, the count stays 0)
     X3D_REQUIRE(!a.slab, "pw_wgrad: dw_slab given to a kernel without the slab form");
     return pw_wgrad_dispatch<float>(a, vec, xpro, st);

@@ -14,6 +14,7 @@
 
 struct PwWgradRArgs {
   const void* g; const void* yraw; const float* coef;
+  BnBwdFold fold;            // sums != NULL: the dY coefficients are derived from the BatchNorm-backward sums (x3d_hip.h coef_fold; never published here)
   const void* x; const float* xcoef; const float* xgate; int xact;
   float* dw;
   float* slab;               // NULL | partial weight gradients [gridDim.x][Cout][Cin], plain stores (x3d_hip.h dw_slab)
@@ -50,8 +51,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32r_kernel(const PwWgradRArgs a
 
   for (int row = tid; row < RA; row += 256) {
     const int co = co0 + row;
-    const bool ok = co < a.Cout && a.coef;
-    Ca[row * 4] = ok ? a.coef[co * 4] : 1.f; Ca[row * 4 + 1] = ok ? a.coef[co * 4 + 1] : 0.f; Ca[row * 4 + 2] = ok ? a.coef[co * 4 + 2] : 0.f;
+    const bool ok = co < a.Cout && (a.coef || a.fold.sums);
+    float cA = 1.f, cB = 0.f, cC = 0.f;
+    if (ok) bn_bwd_coef_load(a.coef, a.fold, co, false, cA, cB, cC);
+    Ca[row * 4] = cA; Ca[row * 4 + 1] = cB; Ca[row * 4 + 2] = cC;
   }
   if constexpr (XPRO) {
     for (int row = tid; row < RB; row += 256) {
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32r_kernel(const PwWgradRArgs a
       if (co < a.Cout && p < a.P) {
         const long long o = ((long long)n * a.Cout + co) * a.P + p;
         load4((const float*)a.g, o, p, rg[i]);
-        if (a.coef) load4((const float*)a.yraw, o, p, ry[i]);
+        if (a.coef || a.fold.sums) load4((const float*)a.yraw, o, p, ry[i]);
       }
     }
 #pragma unroll

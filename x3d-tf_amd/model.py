@@ -1065,7 +1065,7 @@ class X3D:
         # (include/x3d_hip.h x3d_bn_bwd_fold: the persistent weights-stationary kernels and the 16-bit weight-gradient kernel
         # -- stages 4 / 5 and conv5, 37 launches of an X3D-M step) the consumers derive the table themselves, the same bits, and
         # one of them -- never the weight-gradient launch -- publishes dgamma / dbeta and the table; no launch is recorded.
-        fold_coef = self.opt["coef_fold"] and self.dtype != torch.float32 and not pl.side_on
+        fold_coef = self.opt["coef_fold"] and not pl.side_on
         pl.bwd_folds = getattr(pl, "bwd_folds", [])
 
         def fold_bn_bwd(bn, count, gamma, dgamma, dbeta, consumers):
