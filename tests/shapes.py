@@ -13,6 +13,7 @@ HALF_DTYPES = [BF16, F16]
 
 # ---- x3d_pw_fwd: N, Cin, Cout, T, H, W, stride, prologue ------------------------------------------------------------
 PW_FWD = [
+    (2, 48, 108, 2, 5, 13, 1, None), (1, 108, 48, 1, 3, 43, 1, "swish"),   # P = 130 / 129: a row's partial 16-byte vector is vector 0 of a 128-point tile (fp32 pipelined kernel: early start in front of the tile)
     (2, 24, 54, 4, 12, 12, 1, None),       # bottleneck a (stage 2 widths)
     (2, 54, 24, 3, 10, 10, 1, "swish"),    # bottleneck c with BN_b + SE gate + swish folded
     (2, 24, 48, 4, 12, 12, 2, None),       # strided shortcut (valid, samples pixels 0,2,..)
@@ -84,6 +85,7 @@ PW_FWD_INFER = [(n, ci, co, t, h, w, pro, ("identity", "conv")[i % 2], "relu")
 
 # ---- x3d_pw_dgrad: N, Cin, Cout, T, H, W  x  epilogue -----------------------------------------------------------------
 PW_DGRAD = [
+    (2, 48, 108, 2, 5, 13), (1, 108, 48, 1, 3, 43),   # P = 130 / 129 (see PW_FWD)
     (2, 24, 54, 4, 12, 12), (1, 54, 24, 3, 10, 10), (1, 48, 108, 13, 5, 5), (1, 96, 216, 2, 7, 7),
     (1, 216, 96, 2, 7, 7), (1, 200, 40, 1, 4, 8),
     (1, 54, 24, 4, 14, 14), (1, 48, 108, 2, 28, 28),   # strided add with rows of 2k / 4k points (pair / quad groups)
@@ -95,6 +97,7 @@ PW_DGRAD_EPI = ["store", "add", "add_strided", "swish_bwd"]
 
 # ---- x3d_pw_wgrad: N, Cin, Cout, T, H, W, stride, prologue --------------------------------------------------------------
 PW_WGRAD = [
+    (1, 32, 32, 1, 2, 17, 1, None), (2, 48, 108, 1, 33, 2, 1, "swish"),   # P = 34 / 66: the partial vector is vector 0 of the last 32-point step
     (2, 24, 54, 4, 12, 12, 1, None), (2, 54, 24, 3, 10, 10, 1, "swish"), (2, 24, 48, 4, 12, 12, 2, None),
     (1, 48, 108, 13, 5, 5, 1, None), (1, 96, 216, 2, 7, 7, 1, None), (1, 216, 96, 2, 7, 7, 1, "swish"),
     (1, 192, 432, 1, 7, 7, 1, None), (1, 432, 192, 1, 7, 7, 1, "swish"), (1, 24, 24, 2, 9, 11, 2, None),

@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libx3d_hip.so")
 SOURCES = ["api.cpp", "pw_fwd.hip", "pw_fwd_infer.hip", "pw_fwd_tail.hip", "pw_dgrad.hip", "pw_wgrad.hip", "pw_pack.hip", "pw_bwd_fused.hip", "pw_bwd_wst.hip", "pw_bwd_wsta.hip", "pw_bwd_rc.hip", "dw_fwd.hip", "dw_bwd.hip", "dw_pd.hip", "dw_s1.hip", "dw_s2.hip", "dw_pk.hip", "dw_mx.hip", "dw_mxg.hip", "elem.hip", "stem.hip", "stem_fused.hip",
            "se.hip", "head.hip", "views.hip"]
-HEADERS = ["common.h", "pw_gemm.h", "pw_gemm_bf16.h", "pw_gemm_ws.h", "pw_gemm_wst.h", "pw_gemm_f32r.h", "pw_gemm_f32p.h", "pw_wgrad_f32r.h", "pw_wgrad_bf16.h", "dw_common.h", os.path.join("..", "..", "include", "x3d_hip.h")]
+HEADERS = ["common.h", "pw_gemm.h", "pw_gemm_bf16.h", "pw_gemm_ws.h", "pw_gemm_wst.h", "pw_gemm_f32r.h", "pw_gemm_f32p.h", "pw_wgrad_f32r.h", "pw_wgrad_f32p.h", "pw_wgrad_bf16.h", "dw_common.h", os.path.join("..", "..", "include", "x3d_hip.h")]
 assert sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) == sorted(h for h in HEADERS if os.sep not in h), "HEADERS out of date"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value",
          # hipcc SLP-packs adjacent fp32 mul/add into v_pk_mul + v_pk_add (no FMA, weights no longer SGPR operands):

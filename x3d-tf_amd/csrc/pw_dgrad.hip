@@ -9,7 +9,8 @@ static int pw_dgrad_dispatch(PwGemmArgs& a, int epi, int vec, hipStream_t st) {
     switch (epi) {
       case X3D_EPI_STORE: rc = f32p_try<PRO_BNBWD, X3D_EPI_STORE>(a, st); break;
       case X3D_EPI_ADD: rc = f32p_try<PRO_BNBWD, X3D_EPI_ADD>(a, st); break;
-      case X3D_EPI_ADD_STRIDED: rc = f32p_try<PRO_BNBWD, X3D_EPI_ADD_STRIDED>(a, st); break;
+      // (X3D_EPI_ADD_STRIDED -- the first block of a stage, large planes, an integer division per output element -- stays with
+      // pw_gemm_f32r.h: 54 -> 24 on 13x80x80 391 us there, 523 us in the pipelined kernel)
       case X3D_EPI_SWISH_BWD: rc = f32p_try<PRO_BNBWD, X3D_EPI_SWISH_BWD>(a, st); break;
     }
     if (rc >= 0) return rc;
@@ -118,6 +119,6 @@ extern "C" int x3d_pw_coef_fold_supported(const x3d_pw_dgrad_args* dgrad, const 
   for (const char* p : ok) if (strncmp(name, p, strlen(p)) == 0) return 1;
   if (strncmp(name, "pw_gemm_wst_kernel<", 19) == 0) return dgrad != nullptr;
   if (strncmp(name, "pw_f32p_kernel<", 15) == 0) return dgrad != nullptr;          // fp32 storage: the pipelined data-gradient kernel ...
-  if (strncmp(name, "pw_wgrad_f32r_kernel<", 21) == 0) return wgrad != nullptr;    // ... and the tile-group weight-gradient kernel
+  if (strncmp(name, "pw_wgrad_f32r_kernel<", 21) == 0 || strncmp(name, "pw_wgrad_f32p_kernel<", 21) == 0) return wgrad != nullptr;    // ... and the tile-group weight-gradient kernel
   return 0;
 }

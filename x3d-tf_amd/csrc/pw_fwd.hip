@@ -67,7 +67,9 @@ extern "C" int x3d_pw_fwd(const x3d_pw_fwd_args* f, void* stream) {
     if (((uintptr_t)f->x % 16) == 0 && ((uintptr_t)f->in_add % 16) == 0 && ((uintptr_t)f->in_store % 16) == 0 &&
         ((uintptr_t)f->y % 16) == 0 && pw_ragged_rows(a.P, eb)) v16 = ot = 8;
     if (f->dtype == X3D_F32) {
-      int rc = f->in_add ? f32p_try<PRO_TAIL, EPI_STATS>(a, st) : f32p_try<PRO_AFFST, EPI_STATS>(a, st);
+      // (the stem's BatchNorm fold -- one launch, 24 -> 54 on 13x80x80, one chunk a tile -- stays with pw_gemm_f32r.h: 221 us there, 265 us
+      // in the pipelined kernel, profiles/r06_f32p_layers.txt)
+      int rc = f->in_add ? f32p_try<PRO_TAIL, EPI_STATS>(a, st) : -1;
       if (rc < 0) rc = f->in_add ? f32r_try<PRO_TAIL, EPI_STATS>(a, 4, st) : f32r_try<PRO_AFFST, EPI_STATS>(a, 4, st);
       X3D_REQUIRE(rc >= 0, "pw_fwd: folded tail in fp32 storage: layer not covered by the resident-weights kernel");
       return rc;

@@ -191,14 +191,17 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
     constexpr int S = decltype(SET)::value;
     const int pcol = ld.p0 + pv * 4;
     const bool colok = !(F32P_EXP & 8) && ld.tile < tile_end && pcol < P;
-    int vo = vrow;
+    // (the early start of a partial vector may reach in front of the tile: with row 0 / vector 0 the per-thread offset would go
+    // negative -- 16 bytes move from the scalar to the per-thread offset; at p0 = 0 the partial vector is never vector 0, P >= 4)
+    const int sb = (RAG && ld.p0 > 0) ? 16 : 0;
+    int vo = vrow + sb;
     if constexpr (RAG) { if (pcol + 4 > P) vo -= (4 - q4) * 4; }
     const int klim = a.K - ld.kc * KC;                          // rows of this chunk inside K
     const int rowbase = ld.tile < tile_end ? ld.n * a.K + ld.kc * KC : 0;   // scalar (past the last tile: every offset is F32P_OOB)
 #pragma unroll
     for (int i = 0; i < NXV; i++) {
       const int v = (colok && kl0 + i * RS < klim) ? vo : F32P_OOB;
-      const int so = ((rowbase + i * RS) * P + ld.p0) * 4;
+      const int so = ((rowbase + i * RS) * P + ld.p0) * 4 - sb;
       xr[S][i] = __builtin_bit_cast(f32p_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, v, so, 0));
       if constexpr (TWO) yr[S][i] = __builtin_bit_cast(f32p_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, v, so, 0));
       if constexpr (GATE) gr[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgt, (kl0 + i * RS < klim) ? kl0 * 4 : F32P_OOB,

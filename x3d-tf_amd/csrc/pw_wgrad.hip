@@ -22,7 +22,7 @@ struct PwWgradArgs {
 };
 
 #include "pw_wgrad_bf16.h"
-#include "pw_wgrad_f32r.h"
+#include "pw_wgrad_f32p.h"
 
 template <typename T, int VEC, int TPW, bool XPRO, bool STRIDED>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwWgradArgs a) {
@@ -265,7 +265,8 @@ extern "C" int x3d_pw_wgrad(const x3d_pw_wgrad_args* w, void* stream) {
       memset(&ra, 0, sizeof(ra));
       ra.g = a.g; ra.yraw = a.yraw; ra.coef = a.coef; ra.fold = a.fold; ra.x = a.x; ra.xcoef = a.xcoef; ra.xgate = a.xgate; ra.xact = a.xact;
       ra.dw = a.dw; ra.slab = a.slab; ra.slab_parts = a.slab_parts; ra.N = a.N; ra.Cout = a.Cout; ra.Cin = a.Cin; ra.P = a.P;
-      const int rc = xpro ? wgrad_f32r_pick<true>(ra, st) : wgrad_f32r_pick<false>(ra, st);
+      int rc = xpro ? wgrad_f32p_pick<true>(ra, st) : wgrad_f32p_pick<false>(ra, st);      // pipelined operand streams (pw_wgrad_f32p.h)
+      if (rc < 0) rc = xpro ? wgrad_f32r_pick<true>(ra, st) : wgrad_f32r_pick<false>(ra, st);
       if (rc >= 0) return rc;
     }
     X3D_REQUIRE(!w->coef_fold, "pw_wgrad: coef_fold is not taken by the generic fp32 kernel (x3d_pw_coef_fold_supported() == 0)");
