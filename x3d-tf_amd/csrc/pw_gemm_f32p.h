@@ -71,56 +71,6 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   F32P_STAMP(0);
   if (tile_begin >= tile_end) return;
 
-  // ---- the weight block, once: Ws[m][k] = w(k, m0 + m), zero padding (pw_gemm_f32r.h)
-  if (!(F32P_EXP & 2)) {
-    const int total = BM * Kp;
-    const bool vec4 = a.wsk == 1 ? ((a.K & 3) == 0 && (a.wsm & 3) == 0) : (a.wsm == 1 && (a.M & 3) == 0 && (a.wsk & 3) == 0);
-    if (vec4 && (((uintptr_t)a.w) & 15) == 0) {
-      constexpr int UW = 4;
-      for (int base = 0; base < total / 4; base += F32R_THREADS * UW) {
-        f32x4 wv[UW];
-        int dk[UW], dm[UW];
-#pragma unroll
-        for (int u = 0; u < UW; u++) {
-          const int i = (base + u * F32R_THREADS + tid) * 4;
-          int k, m;
-          if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
-          else { k = i / BM; m = i - k * BM; }
-          const bool in = i < total;
-          dk[u] = in ? k : -1; dm[u] = m;
-          wv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (in && k < a.K && m0 + m < a.M) wv[u] = *(const f32x4*)(a.w + (long long)k * a.wsk + (long long)(m0 + m) * a.wsm);
-        }
-#pragma unroll
-        for (int u = 0; u < UW; u++) {
-          if (dk[u] < 0) continue;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            if (a.wsk == 1) Ws[dm[u] * WP + dk[u] + e] = wv[u][e];
-            else Ws[(dm[u] + e) * WP + dk[u]] = wv[u][e];
-          }
-        }
-      }
-    } else {
-      constexpr int UW = 8;
-      for (int base = 0; base < total; base += F32R_THREADS * UW) {
-        float wv[UW];
-        int dst[UW];
-#pragma unroll
-        for (int u = 0; u < UW; u++) {
-          const int i = base + u * F32R_THREADS + tid;
-          int k, m;
-          if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
-          else { k = i / BM; m = i - k * BM; }
-          const bool in = i < total;
-          dst[u] = in ? m * WP + k : -1;
-          wv[u] = (in && k < a.K && m0 + m < a.M) ? a.w[(long long)k * a.wsk + (long long)(m0 + m) * a.wsm] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < UW; u++) if (dst[u] >= 0) Ws[dst[u]] = wv[u];
-      }
-    }
-  }
   // ---- prologue rows (the same for every sample: the gate travels with the data)
   if constexpr (PRO != PRO_NONE) {
     for (int k = tid; k < Kp; k += F32R_THREADS) {
@@ -464,7 +414,6 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
     advance(cp);
   };
 
-  fill_em(cp.n);
   {
     issue(std::integral_constant<int, 0>());
     advance(ld);
@@ -472,6 +421,58 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
     advance(ld);
     if constexpr (D == 3) { issue(std::integral_constant<int, 2>()); advance(ld); }
   }
+  // ---- the weight block, once: Ws[m][k] = w(k, m0 + m), zero padding (pw_gemm_f32r.h) -- behind the first D activation loads, whose
+  // latency it covers (a 64 x 432 block is 110 KB: 6 us in front of the first barrier when it came first, in rounds of 4 loads)
+  if (!(F32P_EXP & 2)) {
+    const int total = BM * Kp;
+    const bool vec4 = a.wsk == 1 ? ((a.K & 3) == 0 && (a.wsm & 3) == 0) : (a.wsm == 1 && (a.M & 3) == 0 && (a.wsk & 3) == 0);
+    if (vec4 && (((uintptr_t)a.w) & 15) == 0) {
+      constexpr int UW = 8;
+      for (int base = 0; base < total / 4; base += F32R_THREADS * UW) {
+        f32x4 wv[UW];
+        int dk[UW], dm[UW];
+#pragma unroll
+        for (int u = 0; u < UW; u++) {
+          const int i = (base + u * F32R_THREADS + tid) * 4;
+          int k, m;
+          if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
+          else { k = i / BM; m = i - k * BM; }
+          const bool in = i < total;
+          dk[u] = in ? k : -1; dm[u] = m;
+          wv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (in && k < a.K && m0 + m < a.M) wv[u] = *(const f32x4*)(a.w + (long long)k * a.wsk + (long long)(m0 + m) * a.wsm);
+        }
+#pragma unroll
+        for (int u = 0; u < UW; u++) {
+          if (dk[u] < 0) continue;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (a.wsk == 1) Ws[dm[u] * WP + dk[u] + e] = wv[u][e];
+            else Ws[(dm[u] + e) * WP + dk[u]] = wv[u][e];
+          }
+        }
+      }
+    } else {
+      constexpr int UW = 8;
+      for (int base = 0; base < total; base += F32R_THREADS * UW) {
+        float wv[UW];
+        int dst[UW];
+#pragma unroll
+        for (int u = 0; u < UW; u++) {
+          const int i = base + u * F32R_THREADS + tid;
+          int k, m;
+          if (a.wsk == 1) { m = i / Kp; k = i - m * Kp; }
+          else { k = i / BM; m = i - k * BM; }
+          const bool in = i < total;
+          dst[u] = in ? m * WP + k : -1;
+          wv[u] = (in && k < a.K && m0 + m < a.M) ? a.w[(long long)k * a.wsk + (long long)(m0 + m) * a.wsm] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UW; u++) if (dst[u] >= 0) Ws[dst[u]] = wv[u];
+      }
+    }
+  }
+  fill_em(cp.n);
   F32P_STAMP(1);
   __syncthreads();                      // prologue rows in place (the commit reads them)
   F32P_STAMP(2);
