@@ -12,7 +12,10 @@
 //     the thread-invariant part of every address is a scalar offset;
 //   * the SE gate of a row is loaded with the row (no per-sample table refill between barriers);
 //   * the epilogue stores / loads are buffer operations with a per-lane base and scalar row offsets;
-//   * the statistics of the NT waves of a row block are added in LDS: one pair of atomics per channel and workgroup.
+//   * the statistics of the NT waves of a row block are added in LDS: one pair of atomics per channel and workgroup; the sums
+//     over the 32 lanes of a half wave are DPP adds (as shuffles -- ds_bpermute round trips, each waited for -- the 32 sums were
+//     18,000 of the 64,000 cycles of a workgroup: in-kernel stamps, profiles/r06_f32p_stamps.txt);
+//   * the row groups of one tile range take consecutive slots of one XCD (its L2 serves all but the first read of a tile).
 // Arithmetic, operand order and the k order inside an output element are pw_gemm_f32r.h's (and pw_gemm.h's): same results up
 // to the order of the statistics atomics.
 #pragma once
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   const int vrow = (kl0 * P + pv * 4) * 4;                   // byte offset of the thread's vector in (row 0, tile column 0)
 
   struct Cursor { int tile, kc, n, p0; };
-  Cursor ld, cm, cp;     // loads (D + 1 steps ahead), commit (one step ahead), MFMAs
+  Cursor ld, cm, cp;     // loads (D steps ahead), commit, MFMAs (the same step)
   ld.tile = tile_begin; ld.kc = 0; ld.n = tile_begin / tiles_per_n; ld.p0 = (tile_begin - ld.n * tiles_per_n) * BN;
   cp = ld; cm = ld;
   auto advance = [&](Cursor& c) __attribute__((always_inline)) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
                                                                                                    (rowbase + i * RS) * 4, 0));
     }
   };
-  // the commit of one step in PIECES (sub() deals them out between its MFMAs): pre = the step's scalars and prologue rows;
+  // the commit of one step in pieces: pre = the step's scalars and prologue rows;
   // elem(i, e) = one element of staging vector i through the prologue; store(i) = vector i to LDS (and to ystore)
   struct CommitState { int pcol, klim, rowbase; bool colok, sh1, sh2, sh3; };
   CommitState cs;
@@ -351,15 +354,21 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
     }
   };
 
-  // ---- the step loop.  Sub-step of step c: barrier | MFMAs of step c (buffer c & 1) with the COMMIT of step c + 1 (register set
-  // (c + 1) % D -> buffer (c + 1) & 1) between them -- its wait for the loads, its prologue arithmetic and its LDS writes run in
-  // the shadow of the matrix pipeline -- | issue step c + 1 + D into the freed set | epilogue if step c ends a tile
+  // ---- the step loop.  Sub-step of step c: commit step c (register set c % D -> buffer c & 1) | barrier | issue step c + D into the
+  // freed set | MFMAs of step c | epilogue if step c ends a tile
   int par = 0, n_pending = -1;
   auto sub = [&](auto SET) __attribute__((always_inline)) {
     float* buf = Xs + par * KC * BN;
-    float* nbuf = Xs + (par ^ 1) * KC * BN;
     par ^= 1;
+    if (!(F32P_EXP & 32)) {
+      commit_pre();
+#pragma unroll
+      for (int p = 0; p < NPIECE; p++) commit_piece(SET, p, buf);
+    }
+    advance(cm);
     if (!(F32P_EXP & 64)) __syncthreads();                    // step c visible; every wave is past the MFMAs that read the other buffer
+    issue(SET);
+    advance(ld);
     const bool last = cp.kc == nchunks - 1 && cp.tile < tile_end;
     if (last) eload();
     const int k0 = cp.kc * KC;
@@ -375,26 +384,16 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
         for (int i = 0; i < KC / 2; i++) { av[s][i] = wp[2 * i]; bv[s][i] = xp[2 * i * BN]; }
       }
     }
-    // the commit's pieces dealt out between the MFMAs, fenced (a dependent chain: left to itself the wave sits at each MFMA for
-    // the 16 passes of the one before it, then runs the commit with the matrix pipeline idle)
-    constexpr int NM = TPW * KC / 2, PPM = (NPIECE + NM - 1) / NM;
-    if (!(F32P_EXP & 32)) commit_pre();
-    __builtin_amdgcn_sched_barrier(0);
+    // (tried: the commit of step c + 1 inside step c, its pieces dealt out between the 16 MFMAs of the dependent chain behind
+    // scheduling fences -- 3 % SLOWER over the 14 layer shapes of tools/bench_f32r.py than this order, the same block left to the
+    // compiler's order the same within 1 %: profiles/r06_f32p_sched.txt.  The matrix pipeline is saturated by the four waves of a
+    // SIMD whenever they are in their MFMA runs; the commit does not hide inside them)
 #pragma unroll
-    for (int m = 0; m < NM; m++) {
+    for (int m = 0; m < TPW * KC / 2; m++) {
       const int s = m / (KC / 2), i = m % (KC / 2);
       if ((NTILE % NW == 0 || wid + NW * s < NTILE) && !((F32P_EXP & 1) && i != 0))
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][i], acc[s], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(F32P_EXP & 32)) {
-#pragma unroll
-        for (int p = m * PPM; p < (m + 1) * PPM && p < NPIECE; p++) commit_piece(SET, p, nbuf);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    advance(cm);
-    issue(SET);
-    advance(ld);
     if (last && (!(F32P_EXP & 4) || acc[0][0] == 12345.f)) {
       epilogue();
       if constexpr (EPI == X3D_EPI_SWISH_BWD) {
@@ -474,14 +473,8 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   }
   fill_em(cp.n);
   F32P_STAMP(1);
-  __syncthreads();                      // prologue rows in place (the commit reads them)
+  __syncthreads();                      // weights and tables in place
   F32P_STAMP(2);
-  commit_pre();
-#pragma unroll
-  for (int p = 0; p < NPIECE; p++) commit_piece(std::integral_constant<int, 0>(), p, Xs);
-  advance(cm);
-  issue(std::integral_constant<int, 0>());
-  advance(ld);
   // (no early exit inside the unrolled body: the structurizer routes a break through the loop header, whose waits must then hold
   // for a set issued one sub-step ago -- vmcnt(0).  Up to D - 1 sub-steps past the last tile run on zeros: out-of-range loads,
   // no epilogue)
@@ -489,9 +482,9 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   F32P_STAMP(3);
   for (int step = 0; step < nsteps; step += D) {
     F32P_STAMP(4 + step);
+    sub(std::integral_constant<int, 0>());
     sub(std::integral_constant<int, 1>());
     if constexpr (D == 3) sub(std::integral_constant<int, 2>());
-    sub(std::integral_constant<int, 0>());
   }
 
   F32P_STAMP(60);
