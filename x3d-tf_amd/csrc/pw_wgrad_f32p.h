@@ -11,6 +11,13 @@
 #pragma once
 #include "pw_wgrad_f32r.h"
 
+#ifdef WGP_STAMPS      // in-kernel stamps of workgroup 0 (tools/f32p_stamps.py wgrad): s_memtime at the phase boundaries
+__device__ unsigned long long wgp_stamps[64];
+#define WGP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (i) < 64) wgp_stamps[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int x3d_debug_wgp_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(wgp_stamps), sizeof(wgp_stamps)) == hipSuccess ? 0 : 1; }
+#else
+#define WGP_STAMP(i) do { } while (0)
+#endif
 constexpr int WGP_OOB = 0x7fffff00;   // buffer offset past every tensor (host check): loads return 0
 typedef __attribute__((ext_vector_type(4))) unsigned int wgp_u32x4;
 
@@ -42,6 +49,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32p_kernel(const PwWgradRArgs a
   const int s_begin = chunk * a.steps_per_block;
   const int s_end = min(s_begin + a.steps_per_block, steps_per_n);
   if (s_begin >= s_end) return;
+  WGP_STAMP(0);
   const bool two = a.coef || a.fold.sums;    // dY = A g + B yraw + C (else g as it is)
 
   for (int row = tid; row < RA; row += 256) {
@@ -179,14 +187,18 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32p_kernel(const PwWgradRArgs a
   issue(std::integral_constant<int, 0>(), s_begin);
   issue(std::integral_constant<int, 1>(), s_begin + 1);
   if constexpr (D == 3) issue(std::integral_constant<int, 2>(), s_begin + 2);
+  WGP_STAMP(1);
   __syncthreads();        // tables in place
+  WGP_STAMP(2);
   // (no early exit inside the unrolled body -- pw_gemm_f32p.h: up to D - 1 sub-steps past the run multiply zeros)
   for (int step = s_begin; step < s_end; step += D) {
+    WGP_STAMP(3 + (step - s_begin) / D);
     sub(std::integral_constant<int, 0>(), step);
     sub(std::integral_constant<int, 1>(), step + 1);
     if constexpr (D == 3) sub(std::integral_constant<int, 2>(), step + 2);
   }
 
+  WGP_STAMP(60);
 #pragma unroll
   for (int s = 0; s < TPW; s++) {
     const int id = wid + 4 * s;
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32p_kernel(const PwWgradRArgs a
       }
     }
   }
+  WGP_STAMP(61);
 }
 
 template <int MTG, int NTG, bool XPRO, bool RAG>
