@@ -36,6 +36,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int f32p_u32x4;
 
 template <int MT, int NT, int PRO, int EPI, bool RAG>
 __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs a) {
+  static_assert(EPI == EPI_STATS || EPI == X3D_EPI_STORE || EPI == X3D_EPI_ADD || EPI == X3D_EPI_SWISH_BWD, "epilogue not built here (strided add, inference: pw_gemm_f32r.h)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef float T;
   constexpr int BM = MT * 32, BN = NT * 32, KC = F32R_KC, NW = F32R_THREADS / 64;
@@ -322,21 +323,6 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ry, vo, so, 0);
           } else if constexpr (EPI == X3D_EPI_ADD) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val + eop[EADD ? s : 0][j]), ry, vo, so, 0);
-          } else if constexpr (EPI == X3D_EPI_ADD_STRIDED) {
-            const int m = mb + ro;
-            if (pok && ro < mlim) {
-              const int hw = a.eH * a.eW;
-              const int t = p / hw;
-              const int rem = p - t * hw;
-              const int h = rem / a.eW, w = rem - h * a.eW;
-              if (((h | w) & 1) == 0) {
-                const int Hh = (a.eH + 1) >> 1, Wh = (a.eW + 1) >> 1;
-                const long long T_ = a.P / hw;
-                const long long oa = ((((long long)n * a.M + m) * T_ + t) * Hh + (h >> 1)) * Wh + (w >> 1);
-                val += ((const T*)a.add)[oa];
-              }
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ry, vo, so, 0);
           } else if constexpr (EPI == X3D_EPI_SWISH_BWD) {
             const float b = eop[EADD ? s : 0][j];
             const float* em = Em + (mt * 32 + 4 * half + ro) * 4;
