@@ -188,6 +188,7 @@ DW = [
     (2, 5, 4, 16, 16, 1), (2, 5, 4, 16, 16, 2),       # even, SW=2
     (1, 3, 3, 7, 7, 1), (1, 3, 3, 14, 14, 2),         # 7x7 planes, SW=1
     (1, 2, 5, 39, 39, 2), (1, 2, 2, 20, 20, 1),       # X3D-L odd case 39 -> 20 (pads 1/1)
+    (2, 3, 5, 39, 39, 1), (1, 2, 4, 78, 78, 2), (1, 3, 3, 25, 37, 1), (1, 2, 2, 41, 43, 1),   # odd row length of 16-bit outputs, strips of four: every second row starts 2 mod 4, several samples / channels (the plane is an odd number of elements: the parity alternates), last strip of 3 / 1 / 3 outputs
     (1, 2, 3, 56, 56, 1), (1, 2, 3, 112, 112, 2),     # X3D-M stage-2 planes, SW=4, H-tiled
     (1, 2, 1, 9, 23, 2), (1, 1, 2, 10, 13, 1),        # T=1 / non-square / odd widths
     (1, 2, 16, 28, 28, 1),                            # vec 4 path for bf16
