@@ -1577,3 +1577,52 @@ def test_adam_finite_and_label_range(gpu):
     assert torch.isfinite(rows[0]) and torch.isnan(rows[1]) and torch.isnan(rows[2])
     assert dl[1].abs().sum().item() == 0 and dl[2].abs().sum().item() == 0 and dl[0].abs().sum().item() > 0
     report("probs", probs, torch.softmax(logits.double().cpu(), -1), 1e-5, 1e-7)
+
+
+@pytest.mark.gpu
+def test_pw_f32_tensors_over_2gb(gpu):
+    """fp32 storage, tensors of more than 2 GB (52 x 54 x 16x112x112 floats = 2.25 GB).  The pipelined fp32 kernels address a whole tensor with
+    32-bit buffer offsets and hand such launches to the resident-weights kernels behind the same entry points (pw_gemm_f32r.h /
+    pw_wgrad_f32r.h; per-sample buffer resources were measured: the limit goes, the X3D-S step pays 1.7 %) -- this is the case that keeps
+    those kernels under test.  Size-independent properties: a sample's forward output / data gradient does not depend on the batch it is in
+    (bit-identical to a launch of the last two samples alone), the statistics are the sums of the stored output, the weight gradient is
+    the sum over sub-batches."""
+    ops = _ops()
+    from x3d_tf_amd import hip
+    n, cin, cout, t, h, w = 52, 24, 54, 16, 112, 112
+    names = [hip.kernel_name(st) for st in (S.pw_fwd_struct((n, cin, cout, t, h, w, 1, None), S.F32, False),
+                                            S.pw_dgrad_struct((n, cin, cout, t, h, w), "add", S.F32, False),
+                                            S.pw_wgrad_struct((n, cin, cout, t, h, w, 1, None), S.F32))]
+    assert [k.split("<")[0] for k in names] == ["pw_f32r_kernel", "pw_f32r_kernel", "pw_wgrad_f32r_kernel"], names
+    g_ = torch.Generator(device=gpu).manual_seed(11)
+    x = torch.randn((n, cin, t, h, w), generator=g_, device=gpu)
+    wt = torch.randn((cout, cin), generator=g_, device=gpu) * 0.2
+    # forward
+    stats = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+    y = ops.pw_fwd(x, wt, stats=stats)
+    assert y.numel() * 4 > (1 << 31)
+    y2 = ops.pw_fwd(x[-2:].contiguous(), wt, stats=torch.zeros((cout, 2), dtype=torch.float64, device=gpu))
+    torch.cuda.synchronize()
+    assert torch.equal(y[-2:], y2), "forward: the last samples of the 2 GB launch differ from the same samples alone"
+    ref = torch.einsum("oc,cp->op", wt.double(), x[-1].reshape(cin, -1).double())
+    assert (y[-1].reshape(cout, -1).double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    s_ref = torch.stack([torch.stack([y[:, c].double().sum(), (y[:, c].double() ** 2).sum()]) for c in range(cout)])
+    assert (stats - s_ref).abs().max().item() <= 2e-4 * s_ref.abs().max().item()
+    # data gradient (dY = A g + B yraw + C, dx = W^T dY + add) and weight gradient on the same g / yraw
+    g = y                                                   # any 2 GB tensor of the right shape
+    yraw = torch.randn(y.shape, generator=g_, device=gpu)
+    coef = torch.randn((cout, 4), generator=g_, device=gpu) * 0.5
+    add = torch.randn(x.shape, generator=g_, device=gpu)
+    dx = torch.empty_like(x)
+    ops.pw_dgrad(g, yraw, coef, wt, dx, ops.EPI_ADD, add=add)
+    dx2 = torch.empty_like(x[-2:])
+    ops.pw_dgrad(g[-2:].contiguous(), yraw[-2:].contiguous(), coef, wt, dx2, ops.EPI_ADD, add=add[-2:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(dx[-2:], dx2), "data gradient: the last samples of the 2 GB launch differ from the same samples alone"
+    dw = torch.zeros((cout, cin), device=gpu)
+    ops.pw_wgrad(g, yraw, coef, x, dw)
+    dws = torch.zeros((cout, cin), device=gpu)
+    for i in range(0, n, 13):
+        ops.pw_wgrad(g[i:i + 13].contiguous(), yraw[i:i + 13].contiguous(), coef, x[i:i + 13].contiguous(), dws)
+    torch.cuda.synchronize()
+    assert (dw - dws).abs().max().item() <= 1e-4 * dws.abs().max().item(), "weight gradient: 2 GB launch vs the sum over sub-batches"
