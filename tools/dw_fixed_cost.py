@@ -14,8 +14,11 @@ def timed(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 g = torch.Generator(device=dev).manual_seed(0)
-for (n, c, t, h, w) in [(60, 162, 16, 39, 39), (30, 162, 32, 39, 39), (120, 162, 8, 39, 39), (60, 162, 16, 40, 40), (60, 162, 16, 36, 36), (60, 162, 16, 39, 40), (60, 162, 16, 40, 39),
-                        (60, 72, 16, 78, 78), (60, 72, 16, 80, 80), (60, 306, 16, 20, 20)]:
+SHAPES = [(60, 162, 16, 39, 39), (30, 162, 32, 39, 39), (120, 162, 8, 39, 39), (60, 162, 16, 40, 40), (60, 162, 16, 36, 36), (60, 162, 16, 39, 40), (60, 162, 16, 40, 39),
+                        (60, 72, 16, 78, 78), (60, 72, 16, 80, 80), (60, 306, 16, 20, 20)]
+if len(sys.argv) > 1:      # python tools/dw_fixed_cost.py 38x39 41x39 ...   (H x W, N = 60, C = 162, T = 16)
+    SHAPES = [(60, 162, 16, int(a.split('x')[0]), int(a.split('x')[1])) for a in sys.argv[1:]]
+for (n, c, t, h, w) in SHAPES:
     x = torch.randn((n, c, t, h, w), generator=g, device=dev).half()
     wt = torch.randn((c, 3, 3, 3), generator=g, device=dev) * 0.2
     ss = torch.randn((c, 2), generator=g, device=dev)
