@@ -795,7 +795,10 @@ def test_dw3d_fwd(gpu, dtype, shape):
     report("pool", pool, ys.double().sum((2, 3, 4)), _stol(dtype), 10 * _stol(dtype) * max(1.0, float(ys[0, 0].numel()) ** 0.5))
     # no prologue
     y2 = ops.dw3d_fwd(x.to(gpu), wt.to(gpu), stride)
-    report("y_noprologue", y2, O.depthwise3x3x3(xd, round_to(wt, dtype) if mx else wt.double(), stride), rt, at * ref.abs().max().item())
+    ref2 = O.depthwise3x3x3(xd, round_to(wt, dtype) if mx else wt.double(), stride)
+    # (the absolute part scales with THIS reference: the prologue form's can be tiny or all zeros -- one channel whose BN + ReLU clips
+    # everything, fuzz seed 62 -- and sums of 27 products that cancel to 1e-5 of their terms need it)
+    report("y_noprologue", y2, ref2, rt, at * ref2.abs().max().item())
 
 
 @pytest.mark.parametrize("panel", [False, True])
