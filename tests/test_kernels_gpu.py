@@ -1629,3 +1629,44 @@ def test_pw_f32_tensors_over_2gb(gpu):
         ops.pw_wgrad(g[i:i + 13].contiguous(), yraw[i:i + 13].contiguous(), coef, x[i:i + 13].contiguous(), dws)
     torch.cuda.synchronize()
     assert (dw - dws).abs().max().item() <= 1e-4 * dws.abs().max().item(), "weight gradient: 2 GB launch vs the sum over sub-batches"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(32, 96, 216, 13, 10, 10), (32, 432, 192, 13, 5, 5), (32, 24, 54, 13, 40, 40)])   # N, Cin, Cout, T, H, W
+def test_pw_f32_full_size_fp64(gpu, shape):
+    """The pipelined fp32 pointwise kernels at BASELINE config 2's real layer sizes (X3D-S, 32 clips of 13x160x160: stages 4, 5 and 2)
+    against fp64 arithmetic on the GPU -- independent of the CPU oracle: forward with statistics, data gradient with the residual add,
+    weight gradient.  Limit 2e-5 of the largest value (the kernel tests' fp32 tol_gemm); measured on an MI355X: forward 2.3e-7 ... 1.0e-6,
+    statistics 1.8e-9 ... 3.5e-8, data gradient 2.9e-7 ... 5.7e-7, weight gradient (10 400 ... 665 600 points in partial fp32 tiles) 3.5e-7 ... 6.9e-7."""
+    ops = _ops()
+    n, cin, cout, t, h, w = shape
+    g_ = torch.Generator(device=gpu).manual_seed(21)
+    x = torch.randn((n, cin, t, h, w), generator=g_, device=gpu)
+    wt = torch.randn((cout, cin), generator=g_, device=gpu) * (2.0 / cin) ** 0.5
+    stats = torch.zeros((cout, 2), dtype=torch.float64, device=gpu)
+    y = ops.pw_fwd(x, wt, stats=stats)
+    xd, wd = x.double().reshape(n, cin, -1), wt.double()
+    ref = torch.einsum("oc,ncp->nop", wd, xd)
+    torch.cuda.synchronize()
+    err = (y.double().reshape(n, cout, -1) - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-5, f"forward {err:.2e}"
+    s_ref = torch.stack([ref.sum((0, 2)), (ref ** 2).sum((0, 2))], 1)
+    assert ((stats - s_ref).abs().max() / s_ref.abs().max()).item() <= 2e-5, "statistics"
+    gy = torch.randn((n, cout, t, h, w), generator=g_, device=gpu)
+    yraw = torch.randn((n, cout, t, h, w), generator=g_, device=gpu)
+    coef = torch.randn((cout, 4), generator=g_, device=gpu) * 0.5
+    add = torch.randn(x.shape, generator=g_, device=gpu)
+    dx = torch.empty_like(x)
+    ops.pw_dgrad(gy, yraw, coef, wt, dx, ops.EPI_ADD, add=add)
+    cd = coef.double()
+    dy = cd[:, 0].view(1, -1, 1) * gy.double().reshape(n, cout, -1) + cd[:, 1].view(1, -1, 1) * yraw.double().reshape(n, cout, -1) + cd[:, 2].view(1, -1, 1)
+    ref_dx = torch.einsum("oc,nop->ncp", wd, dy) + add.double().reshape(n, cin, -1)
+    torch.cuda.synchronize()
+    err = (dx.double().reshape(n, cin, -1) - ref_dx).abs().max().item() / ref_dx.abs().max().item()
+    assert err <= 2e-5, f"data gradient {err:.2e}"
+    dw = torch.zeros((cout, cin), device=gpu)
+    ops.pw_wgrad(gy, yraw, coef, x, dw)
+    ref_dw = torch.einsum("nop,ncp->oc", dy, xd)
+    torch.cuda.synchronize()
+    err = (dw.double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+    assert err <= 2e-5, f"weight gradient {err:.2e}"
