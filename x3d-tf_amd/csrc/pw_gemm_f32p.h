@@ -127,9 +127,9 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   const int vrow = (kl0 * P + pv * 4) * 4;                   // byte offset of the thread's vector in (row 0, tile column 0)
 
   struct Cursor { int tile, kc, n, p0; };
-  Cursor ld, cm, cp;     // loads (D steps ahead), commit, MFMAs (the same step)
+  Cursor ld, cp;         // loads (D steps ahead); commit + MFMAs + epilogue
   ld.tile = tile_begin; ld.kc = 0; ld.n = tile_begin / tiles_per_n; ld.p0 = (tile_begin - ld.n * tiles_per_n) * BN;
-  cp = ld; cm = ld;
+  cp = ld;
   auto advance = [&](Cursor& c) __attribute__((always_inline)) {
     if (++c.kc == nchunks) {
       c.kc = 0; ++c.tile; c.p0 += BN;
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   f32x4 ckv[PRO != PRO_NONE ? NXV : 1];
   float cv[NXV][4];
   auto commit_pre = [&]() __attribute__((always_inline)) {
-    cs.pcol = cm.p0 + pv * 4;
-    cs.colok = cm.tile < tile_end && cs.pcol < P;
+    cs.pcol = cp.p0 + pv * 4;
+    cs.colok = cp.tile < tile_end && cs.pcol < P;
     const bool part = RAG && cs.pcol + 4 > P;
     cs.sh1 = part && q4 == 1; cs.sh2 = part && q4 == 2; cs.sh3 = part && q4 == 3;
-    cs.klim = a.K - cm.kc * KC;
-    cs.rowbase = cm.n * a.K + cm.kc * KC;
+    cs.klim = a.K - cp.kc * KC;
+    cs.rowbase = cp.n * a.K + cp.kc * KC;
     if constexpr (PRO != PRO_NONE) {
 #pragma unroll
-      for (int i = 0; i < NXV; i++) ckv[i] = *(const f32x4*)(Pk + (cm.kc * KC + kl0 + i * RS) * 4);     // zeros past K
+      for (int i = 0; i < NXV; i++) ckv[i] = *(const f32x4*)(Pk + (cp.kc * KC + kl0 + i * RS) * 4);     // zeros past K
     }
   };
   // element e of a loaded vector; the partial vector of a ragged row was loaded 4 - q4 elements early: rotate (selects, no branch)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
   auto commit_store = [&](int i, float* buf) __attribute__((always_inline)) {
     const int kl = kl0 + i * RS;
     if constexpr (SIDE) {     // y of the block below (the stem), kept for its other readers: written by the first row group
-      const int so = ((cs.rowbase + i * RS) * P + cm.p0) * 4;
+      const int so = ((cs.rowbase + i * RS) * P + cp.p0) * 4;
       const bool ok = rg == 0 && cs.colok && kl < cs.klim;
       if constexpr (RAG) {    // element stores: the row may end inside the vector
 #pragma unroll
@@ -351,7 +351,6 @@ __global__ __launch_bounds__(F32R_THREADS) void pw_f32p_kernel(const PwGemmArgs 
 #pragma unroll
       for (int p = 0; p < NPIECE; p++) commit_piece(SET, p, buf);
     }
-    advance(cm);
     if (!(F32P_EXP & 64)) __syncthreads();                    // step c visible; every wave is past the MFMAs that read the other buffer
     issue(SET);
     advance(ld);
